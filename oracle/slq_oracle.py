@@ -1,0 +1,492 @@
+"""CPU oracle for the Lanczos/Arnoldi-with-adjoint + SLQ + Hutchinson hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the product package imports this file; only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg do.
+
+This is a NumPy (fp64 by default, dtype-preserving) *restatement* of the reference algorithm,
+written from the reference's source text (file:line cited per function, relative to
+``/root/reference/src/matfree_extensions``).  The reference is pure-Python JAX; JAX and ``matfree``
+are not installable in the build container (``ModuleNotFoundError``), so the reference itself was
+never executed.
+
+Pinning status: the reference ships **no stored golden vectors** for this path; its
+tests are known-answer *property* tests (decomposition identities, custom-VJP == autodiff-VJP,
+k = n exactness).  This oracle is pinned against exactly those known-answer tests in
+``tests/test_oracle_*.py`` (identities at the reference's tolerances; adjoints against an independent
+torch-autograd differentiation of an independently written forward pass, and against central finite
+differences).  PRNG-key dependent values (``jax.random`` streams, ``matfree.test_util`` matrices) are
+**parity unpinned**: parity is defined per explicit probe matrix / explicit test matrix.
+
+Reference quirks reproduced on purpose are marked ``# Q<n>``.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+# --------------------------------------------------------------------------------------
+# Operators: A(theta) v, A(theta)^T lam, and d/dtheta [cot^T A(theta) v]
+# --------------------------------------------------------------------------------------
+
+
+class DenseOp:
+    """matvec(v, A) = A @ v  (tests/test_lanczos/test_tridiag_forward.py:18)."""
+
+    def apply(self, v, A):
+        return A @ v
+
+    def apply_t(self, lam, A):
+        return A.T @ lam
+
+    def param_vjp(self, v, cot, A):
+        return (np.outer(cot, v),)
+
+
+class DenseSymOp:
+    """matvec(v, P) = (P + P^T) @ v  (tests/test_lanczos/test_tridiag_adjoint.py:20-21)."""
+
+    def apply(self, v, P):
+        return (P + P.T) @ v
+
+    def apply_t(self, lam, P):
+        return (P + P.T) @ lam
+
+    def param_vjp(self, v, cot, P):
+        o = np.outer(cot, v)
+        return (o + o.T,)
+
+
+class CooOp:
+    """matvec(v, vals) = COO(vals, (row, col)) @ v  (benchmark.py:64-68, exp_util.py:35-42).
+
+    The reference differentiates w.r.t. *all* stored values of the symmetric-expanded matrix.
+    """
+
+    def __init__(self, row, col, n):
+        self.row = np.asarray(row, dtype=np.int64)
+        self.col = np.asarray(col, dtype=np.int64)
+        self.n = int(n)
+
+    def apply(self, v, vals):
+        out = np.zeros(self.n, dtype=np.result_type(v, vals))
+        np.add.at(out, self.row, vals * v[self.col])
+        return out
+
+    def apply_t(self, lam, vals):
+        out = np.zeros(self.n, dtype=np.result_type(lam, vals))
+        np.add.at(out, self.col, vals * lam[self.row])
+        return out
+
+    def param_vjp(self, v, cot, vals):
+        return (cot[self.row] * v[self.col],)
+
+
+def softplus(x, beta=1.0, threshold=20.0):
+    """util/gp_util.py:187-201 (constraint_greater_than): torch-style thresholded softplus."""
+    x = np.asarray(x)
+    small = x * beta < threshold
+    xs = np.where(small, x, 1.0)
+    return np.where(small, np.log1p(np.exp(beta * xs)) / beta, x)
+
+
+def softplus_grad(x, beta=1.0, threshold=20.0):
+    x = np.asarray(x)
+    small = x * beta < threshold
+    xs = np.where(small, x, 1.0)
+    return np.where(small, 1.0 / (1.0 + np.exp(-beta * xs)), 1.0)
+
+
+def rbf_kernel_matrix(Xa, Xb, lengthscale, outputscale):
+    """util/gp_util.py:160-176: k(x,y) = s * exp(-max(0, |x/l|^2 + |y/l|^2 - 2 (x/l).(y/l)) / 2)."""
+    xa = Xa / lengthscale
+    xb = Xb / lengthscale
+    sq = (xa * xa).sum(-1)[:, None] + (xb * xb).sum(-1)[None, :] - 2.0 * (xa @ xb.T)
+    sq = np.maximum(0.0, sq)
+    return outputscale * np.exp(-0.5 * sq)
+
+
+class RbfGramOp:
+    """K(X,X; raw_l, raw_s) + noise I, matrix-free semantics of util/gp_util.py:225-226,525-549.
+
+    params = (raw_lengthscale [() or (d,)], raw_outputscale (), raw_noise ());
+    lengthscale = softplus(raw_l), outputscale = softplus(raw_s), noise = minval + softplus(raw_noise).
+    Row-chunked so that n up to a few 1e4 stays in memory.
+    """
+
+    def __init__(self, X, noise_minval=0.0, chunk=2048):
+        self.X = np.asarray(X)
+        self.n, self.d = self.X.shape
+        self.noise_minval = noise_minval
+        self.chunk = chunk
+
+    def constrained(self, raw_l, raw_s, raw_noise):
+        return softplus(raw_l), softplus(raw_s), self.noise_minval + softplus(raw_noise)
+
+    def apply(self, v, raw_l, raw_s, raw_noise):
+        ls, s, noise = self.constrained(raw_l, raw_s, raw_noise)
+        out = np.empty(v.shape, dtype=np.result_type(v, self.X))
+        for a in range(0, self.n, self.chunk):
+            b = min(self.n, a + self.chunk)
+            K = rbf_kernel_matrix(self.X[a:b], self.X, ls, s)
+            out[..., a:b] = v @ K.T  # supports v of shape (n,) or (p, n)
+        return out + noise * v
+
+    def apply_t(self, lam, raw_l, raw_s, raw_noise):
+        return self.apply(lam, raw_l, raw_s, raw_noise)  # symmetric
+
+    def param_vjp(self, v, cot, raw_l, raw_s, raw_noise):
+        """d/d(raw) of sum_b cot_b^T A v_b ; v, cot of shape (n,) or (p, n)."""
+        ls, s, noise = self.constrained(raw_l, raw_s, raw_noise)
+        V = np.atleast_2d(v)
+        C = np.atleast_2d(cot)
+        ard = np.ndim(raw_l) > 0
+        g_l = np.zeros(self.d if ard else (), dtype=np.float64)
+        g_s = 0.0
+        for a in range(0, self.n, self.chunk):
+            b = min(self.n, a + self.chunk)
+            K = rbf_kernel_matrix(self.X[a:b], self.X, ls, s)
+            S = C[:, a:b].T @ V  # (chunk, n): sum_b cot_b[i] v_b[j]
+            W = S * K
+            g_s += W.sum() / s
+            if ard:
+                for c in range(self.d):
+                    diff2 = (self.X[a:b, c][:, None] - self.X[None, :, c]) ** 2
+                    g_l[c] += (W * diff2).sum() / ls[c] ** 3
+            else:
+                diff2 = ((self.X[a:b, None, :] - self.X[None, :, :]) ** 2).sum(-1)
+                g_l += (W * diff2).sum() / ls**3
+        g_noise = float((C * V).sum())
+        return (
+            g_l * softplus_grad(raw_l),
+            g_s * softplus_grad(raw_s),
+            g_noise * softplus_grad(raw_noise),
+        )
+
+
+# --------------------------------------------------------------------------------------
+# A5: Arnoldi forward (arnoldi.py:57-101)
+# --------------------------------------------------------------------------------------
+
+
+def arnoldi_forward(op, k, v, *params, reortho="full", reortho_vjp="match"):
+    """Returns Q (n,k), H (k,k), r (n,) un-normalised, c = 1/|v|.
+
+    Classical Gram-Schmidt against all (zero-padded) columns, optional second pass whose
+    coefficients are NOT added to h (arnoldi.py:87-92).
+    """
+    if reortho not in ("none", "full"):
+        raise TypeError(f"Unexpected input for {reortho}: either of ['none', 'full'] expected.")
+    n = v.shape[0]
+    if k < 1 or k > n:
+        raise ValueError(f"Parameter depth {k} is outside the expected range")
+    # Q1 (arnoldi.py:26): the forward pass sees `reortho_vjp`, never `reortho`; with the default
+    # "match" that string is != "none", hence the second pass always runs.
+    second_pass = reortho_vjp != "none"
+    Q = np.zeros((n, k), dtype=v.dtype)
+    H = np.zeros((k, k), dtype=v.dtype)
+    length0 = np.sqrt(v @ v)
+    length = length0
+    w = v
+    for i in range(k):
+        q = w / length
+        Q[:, i] = q
+        w = op.apply(q, *params)
+        h = Q.T @ w
+        w = w - Q @ h
+        if second_pass:
+            w = w - Q @ (Q.T @ w)
+        length = np.sqrt(w @ w)
+        if i + 1 < k:  # Q2 (arnoldi.py:98): the out-of-range write at i = k-1 is dropped
+            h[i + 1] = length
+        H[:, i] = h
+    return Q, H, w, 1.0 / length0
+
+
+# --------------------------------------------------------------------------------------
+# A6: Arnoldi adjoint (arnoldi.py:104-220)
+# --------------------------------------------------------------------------------------
+
+
+def arnoldi_adjoint(op, params, *, Q, H, r, c, dQ, dH, dr, dc, reortho="full"):
+    """VJP of arnoldi_forward.  Returns (dv, dparams-tuple).  Valid for non-symmetric A."""
+    n, k = Q.shape
+    tril = np.tril(np.ones((k, k)))
+    lower_mask = tril - 0.5 * np.eye(k)  # arnoldi.py:112-117
+    ps_mask = np.tril(np.ones((k, k)), 1)  # arnoldi.py:133
+
+    eta = dH[:, -1] - Q.T @ dr  # arnoldi.py:120
+    lam = dr + Q @ eta  # arnoldi.py:121
+    Lam = np.zeros_like(Q)
+    Gam = np.zeros((k, k), dtype=Q.dtype)
+    Pi_xi = dQ.T + np.outer(eta, r)  # arnoldi.py:127   (k, n)
+    e1 = np.zeros(k)
+    e1[0] = 1.0
+    Pi_gamma = -dc * c * np.outer(e1, e1) + H @ dH.T - dQ.T @ Q  # arnoldi.py:128
+
+    beta_minus = np.concatenate([np.ones(1), np.diag(H, -1)])  # arnoldi.py:137
+    alpha = np.diag(H)
+    beta_plus = H - np.diag(np.diag(H)) - np.diag(np.diag(H, -1), -1)  # arnoldi.py:139
+
+    P = Q.T.copy()
+    dparams = None
+    for idx in range(k - 1, -1, -1):
+        if reortho == "full":  # arnoldi.py:200-204 (cumulative row masking of P)
+            P = ps_mask[idx][:, None] * P
+            pvec = ps_mask[idx] * dH[:, idx]
+            lam = lam - P.T @ (P @ lam) + P.T @ pvec
+        q = Q[:, idx]
+        z = op.apply_t(lam, *params)  # arnoldi.py:207-208: one vjp gives A^T lam and d/dtheta
+        inc = op.param_vjp(q, lam, *params)
+        dparams = inc if dparams is None else tuple(a + b for a, b in zip(dparams, inc))
+        Gam[idx, :] = lower_mask[idx] * (Pi_gamma[idx] - z @ Q)  # arnoldi.py:212-213
+        Lam[:, idx] = lam  # arnoldi.py:216
+        xi = Pi_xi[idx] + (Gam + Gam.T)[idx, :] @ Q.T  # arnoldi.py:217
+        lam = (xi - (alpha[idx] * lam - z) - beta_plus[idx] @ Lam.T) / beta_minus[idx]
+    return lam * c, dparams
+
+
+# --------------------------------------------------------------------------------------
+# A3: full-reortho tridiagonalisation through Arnoldi (lanczos.py:152-169) and its VJP
+# --------------------------------------------------------------------------------------
+
+
+def tridiag_full(op, k, v, *params):
+    """Returns ((basis (k,n), (diag (k,), offdiag (k-1,))), (q_rem (n,), beta_rem))."""
+    Q, H, r, _c = arnoldi_forward(op, k, v, *params, reortho="full")
+    T = 0.5 * (H + H.T)
+    rn = np.linalg.norm(r)
+    return (Q.T, (np.diag(T).copy(), np.diag(T, 1).copy())), (r / rn, rn)
+
+
+def tridiag_full_vjp(op, k, v, params, cot):
+    """cot mirrors the output pytree: ((dbasis (k,n), (ddiag, doff)), (dq_rem, dbeta_rem))."""
+    (dbasis, (ddiag, doff)), (dq, db) = cot
+    Q, H, r, c = arnoldi_forward(op, k, v, *params, reortho="full")
+    rn = np.linalg.norm(r)
+    u = r / rn
+    dH = np.diag(ddiag) + 0.5 * (np.diag(doff, 1) + np.diag(doff, -1))
+    dr = (dq - u * (u @ dq)) / rn + db * u
+    return arnoldi_adjoint(
+        op, params, Q=Q, H=H, r=r, c=c, dQ=dbasis.T, dH=dH, dr=dr, dc=0.0, reortho="full"
+    )
+
+
+# --------------------------------------------------------------------------------------
+# A4: three-term Lanczos without re-orthogonalisation (lanczos.py:215-285)
+# --------------------------------------------------------------------------------------
+
+
+def tridiag_none(op, k, v, *params):
+    """Same return pytree as tridiag_full.  vectors (k+1,n), diags (k,), offdiags (k,)."""
+    n = v.shape[0]
+    xs = np.zeros((k + 1, n), dtype=v.dtype)
+    a = np.zeros(k, dtype=v.dtype)
+    b = np.zeros(k, dtype=v.dtype)
+    xs[0] = v / np.linalg.norm(v)
+    prev = np.zeros_like(v)
+    bprev = 0.0
+    for i in range(k):
+        w = op.apply(xs[i], *params)
+        a[i] = xs[i] @ w
+        rr = w - a[i] * xs[i] - bprev * prev
+        b[i] = np.linalg.norm(rr)
+        xs[i + 1] = rr / b[i]
+        prev, bprev = xs[i], b[i]
+    return (xs[:-1], (a, b[:-1])), (xs[-1], b[-1])
+
+
+# A8: its adjoint (lanczos.py:288-335)
+def tridiag_none_vjp(op, k, v, params, cot):
+    (dxs_, (da, db_)), (dx_last, db_last) = cot
+    (xs_, (a, b_)), (x_last, b_last) = tridiag_none(op, k, v, *params)
+    xs = np.concatenate([xs_, x_last[None]])
+    b = np.concatenate([b_, [b_last]])
+    dxs = np.concatenate([dxs_, dx_last[None]])
+    db = np.concatenate([db_, [db_last]])
+    xi = -dxs[-1]
+    lam_plus = np.zeros_like(xi)
+    dparams = None
+    for j in range(k - 1, -1, -1):
+        xplus, x = xs[j + 1], xs[j]
+        xi = xi / b[j]
+        mu = db[j] - lam_plus @ x + xplus @ xi
+        nu = da[j] + x @ xi
+        lam = -xi + mu * xplus + nu * x
+        # Q4 (lanczos.py:328): A lam (not A^T lam), parameter-gradient of x^T A(theta) lam
+        Alam = op.apply(lam, *params)
+        inc = op.param_vjp(lam, x, *params)
+        dparams = inc if dparams is None else tuple(p + q for p, q in zip(dparams, inc))
+        xi = -dxs[j] - Alam + a[j] * lam + b[j] * lam_plus - b[j] * nu * xplus
+        lam_plus = lam
+    # Q3 (lanczos.py:305,311): the "lambda_1" used for the initial-vector gradient is the final xi
+    dvec = ((xi @ xs[0]) * xs[0] - xi) / np.linalg.norm(v)
+    return dvec, dparams
+
+
+def tridiag(op, k, v, *params, reortho):
+    """lanczos.py:142-149 dispatcher."""
+    if reortho == "full":
+        return tridiag_full(op, k, v, *params)
+    if reortho == "none":
+        return tridiag_none(op, k, v, *params)
+    raise ValueError(f"reortho={reortho} unsupported. Choose eiter {'full', 'none'}.")
+
+
+# --------------------------------------------------------------------------------------
+# A1: SLQ integrand  |v|^2 e1^T f(T) e1  (lanczos.py:14-61) with value-and-gradient
+# --------------------------------------------------------------------------------------
+
+MATFUNS = {
+    "log": (np.log, lambda x: 1.0 / x),
+    "exp": (np.exp, np.exp),
+    "inv": (lambda x: 1.0 / x, lambda x: -1.0 / x**2),
+    "sqrt": (np.sqrt, lambda x: 0.5 / np.sqrt(x)),
+    "identity": (lambda x: x, lambda x: np.ones_like(x)),
+}
+
+
+def dense_tridiag(diag, off):
+    return np.diag(diag) + np.diag(off, 1) + np.diag(off, -1)
+
+
+def quadform_from_tridiag(diag, off, matfun="log"):
+    """e1^T f(T) e1 via eigh (lanczos.py:48-59) and its gradient w.r.t. (diag, off).
+
+    Gradient = Frechet derivative through divided differences (what differentiating eigh yields
+    for distinct eigenvalues): G = U (F o u0 u0^T) U^T, ddiag = diag(G), doff = 2 diag(G, 1).
+    """
+    f, df = MATFUNS[matfun] if isinstance(matfun, str) else matfun
+    lam, U = np.linalg.eigh(dense_tridiag(diag, off))
+    fl = f(lam)
+    u0 = U[0]
+    val = u0 @ (fl * u0)
+    dl = lam[:, None] - lam[None, :]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        F = (fl[:, None] - fl[None, :]) / dl
+    close = np.abs(dl) <= 1e-13 * np.maximum(np.abs(lam[:, None]), np.abs(lam[None, :]))
+    Fd = 0.5 * (df(lam)[:, None] + df(lam)[None, :])
+    F = np.where(close, Fd, F)
+    G = U @ (F * np.outer(u0, u0)) @ U.T
+    return val, (np.diag(G).copy(), 2.0 * np.diag(G, 1).copy()), (lam, U)
+
+
+def integrand_spd_value_and_grad(op, k, v0, params, *, matfun="log", reortho="full"):
+    """Value, d/dv0 and d/dparams of lanczos.integrand_spd(matfun, k, matvec)(v0, *params)."""
+    scale = np.linalg.norm(v0)
+    u = v0 / scale
+    (basis, (diag, off)), (q, b) = tridiag(op, k, u, *params, reortho=reortho)
+    g, (ddiag, doff), _ = quadform_from_tridiag(diag, off, matfun)
+    value = scale**2 * g
+    cot = ((np.zeros_like(basis), (ddiag, doff)), (np.zeros_like(q), 0.0))
+    if reortho == "full":
+        du, dparams = tridiag_full_vjp(op, k, u, params, cot)
+    else:
+        du, dparams = tridiag_none_vjp(op, k, u, params, cot)
+    dv0 = 2.0 * scale * g * u + scale * (du - u * (u @ du))
+    dparams = tuple(scale**2 * d for d in dparams)
+    return value, dv0, dparams
+
+
+# A9: integrand_spd_custom_vjp_reuse (lanczos.py:64-139): inexact, first-order-only gradient
+def integrand_spd_reuse_value_and_grad(op, k, v0, params, *, matfun="log", reortho="full"):
+    f, df = MATFUNS[matfun]
+    scale = np.linalg.norm(v0)
+    u = v0 / scale
+    (basis, (diag, off)), _ = tridiag(op, k, u, *params, reortho=reortho)
+    lam, U = np.linalg.eigh(dense_tridiag(diag, off))
+    value = scale**2 * (U[0] @ (f(lam) * U[0]))
+    sol = U @ (df(lam) * U[0])  # lanczos.py:116
+    w1, w2 = scale**2 * (basis.T @ sol), u  # lanczos.py:117
+    dparams = op.param_vjp(w2, w1, *params)  # lanczos.py:128: vjp of p -> (A(p) w2)^T w1
+    return value, np.zeros_like(v0), dparams  # lanczos.py:131-134: zero gradient w.r.t. v0
+
+
+# --------------------------------------------------------------------------------------
+# A10: Hutchinson (hutchinson.py:8-65; matfree.hutchinson.hutchinson / sampler_rademacher)
+# --------------------------------------------------------------------------------------
+
+_M64 = (1 << 64) - 1
+
+
+def _splitmix64(z):
+    z = (z + np.uint64(0x9E3779B97F4A7C15)) & np.uint64(_M64)
+    z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & np.uint64(_M64)
+    z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & np.uint64(_M64)
+    return z ^ (z >> np.uint64(31))
+
+
+def rademacher(seed, num, n, first_probe=0, dtype=np.float64):
+    """Counter-based +-1 stream shared bit-for-bit with the HIP sampler (csrc/mfx_sampler.hip).
+
+    Element (b, i) depends only on (seed, first_probe + b, i), so any sharding of the probes over
+    ranks yields the same global probe matrix.  (The reference's jax.random streams cannot be
+    reproduced without JAX: parity is per explicit probe matrix.)
+    """
+    with np.errstate(over="ignore"):
+        b = np.arange(first_probe, first_probe + num, dtype=np.uint64)[:, None]
+        i = np.arange(n, dtype=np.uint64)[None, :]
+        key = _splitmix64(np.uint64(seed) ^ (b * np.uint64(0xD1342543DE82EF95)))
+        bits = _splitmix64(key + i)
+    return np.where((bits >> np.uint64(63)) == 1, 1.0, -1.0).astype(dtype)
+
+
+def hutchinson_value_and_grad(op, k, probes, params, **kw):
+    """mean over probes of the integrand and of its parameter gradient (hutchinson.py:12-15)."""
+    vals, grads = [], None
+    for v in probes:
+        val, _dv, dp = integrand_spd_value_and_grad(op, k, v, params, **kw)
+        vals.append(val)
+        grads = dp if grads is None else tuple(a + b for a, b in zip(grads, dp))
+    num = len(probes)
+    return np.mean(vals), tuple(g / num for g in grads), np.asarray(vals)
+
+
+def hutchinson_batch(estimate, keys, *params):
+    """hutchinson.py:57-65: mean over `num` sequential sub-estimates."""
+    return np.mean([estimate(key, *params) for key in keys], axis=0)
+
+
+def krylov_logdet_slq(op, k, probe_batches, params, **kw):
+    """util/gp_util.py:552-576: mean/std over sequential probe batches."""
+    values = [hutchinson_value_and_grad(op, k, pb, params, **kw)[0] for pb in probe_batches]
+    if len(values) == 1:
+        return values[0], {"std": 0.0, "std_rel": 0.0}
+    mean, std = np.mean(values), np.std(values)
+    return mean, {"std_abs": std, "std_rel": std / abs(mean)}
+
+
+# --------------------------------------------------------------------------------------
+# Test-matrix helpers (property-equivalent stand-ins for matfree.test_util, exp_util.hilbert)
+# --------------------------------------------------------------------------------------
+
+
+def symmetric_matrix_from_eigenvalues(eigvals, seed=0):
+    """Any SPD matrix with the prescribed spectrum; the reference uses this helper only in
+    property tests, so the particular orthogonal factor is immaterial."""
+    n = len(eigvals)
+    rng = np.random.default_rng(seed)
+    Qm, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    return (Qm * np.asarray(eigvals)) @ Qm.T
+
+
+def hilbert(n):
+    a = np.arange(n)
+    return 1.0 / (1.0 + a[:, None] + a[None, :])  # util/exp_util.py:113-115
+
+
+def spd_diag_plus_lowrank(n=512, rank=4, seed=0):
+    """BASELINE config C1: diag(1 + 9 i/(n-1)) + U U^T, U ~ N(0,1)/sqrt(n)."""
+    rng = np.random.default_rng(seed)
+    U = rng.standard_normal((n, rank)) / np.sqrt(n)
+    return np.diag(1.0 + 9.0 * np.arange(n) / (n - 1)) + U @ U.T
+
+
+def laplacian_2d_plus_identity(m):
+    """BASELINE config C3 throughput stand-in: 5-pt Laplacian on an m x m grid + I, as COO."""
+    idx = np.arange(m * m).reshape(m, m)
+    rows, cols, vals = [idx.ravel()], [idx.ravel()], [np.full(m * m, 5.0)]
+    for a, b in ((idx[:-1], idx[1:]), (idx[:, :-1], idx[:, 1:])):
+        rows += [a.ravel(), b.ravel()]
+        cols += [b.ravel(), a.ravel()]
+        vals += [np.full(a.size, -1.0)] * 2
+    return np.concatenate(rows), np.concatenate(cols), np.concatenate(vals), m * m
