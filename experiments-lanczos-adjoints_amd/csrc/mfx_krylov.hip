@@ -1,0 +1,929 @@
+// libmfx: the Krylov inner loops -- Arnoldi/Lanczos forward recurrences and their adjoints.
+//
+// Layout: a batch of p vectors is (p, n) row-major; the basis is (p, k, n).  Every HBM-bound kernel
+// below uses grid = (ceil(n / 2048), p): one workgroup (4 waves) owns a 2048-element slice of ONE
+// probe's vectors, each thread owns 8 elements (2 x float4 / 4 x double2, 16-B coalesced loads) and
+// keeps them in registers across the whole multi-row sweep.  Dot products are reduced
+// lane -> wave (shuffles) -> workgroup (LDS) and written as per-slice partials (p, kmax, nslices);
+// the consumer kernel re-reduces the partials in its prologue (deterministic, no atomics, and no
+// host round trip: the whole k-loop is enqueued on one stream).
+//
+// Reference: arnoldi.py:57-101 (forward), :104-220 (adjoint); lanczos.py:215-285, :288-335.
+#include <initializer_list>
+
+#include "mfx_internal.h"
+
+namespace mfx {
+
+// ------------------------------------------------------------------------------------------------
+// thread-owned elements
+// ------------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__device__ __forceinline__ void load_own(T (&dst)[kEpt], const T* __restrict__ base, int64_t slice0,
+                                         int64_t n, int tid) {
+  constexpr int U = kEpt / VEC;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t off = slice0 + (int64_t)(u * kBlock + tid) * VEC;
+    if (off < n) {
+      Pack<T, VEC> p = load_pack<T, VEC>(base + off);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) dst[u * VEC + e] = p.v[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) dst[u * VEC + e] = T(0);
+    }
+  }
+}
+
+template <typename T, int VEC>
+__device__ __forceinline__ void store_own(const T (&src)[kEpt], T* __restrict__ base, int64_t slice0,
+                                          int64_t n, int tid) {
+  constexpr int U = kEpt / VEC;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t off = slice0 + (int64_t)(u * kBlock + tid) * VEC;
+    if (off < n) {
+      Pack<T, VEC> p;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) p.v[e] = src[u * VEC + e];
+      store_pack<T, VEC>(base + off, p);
+    }
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ T reduce_partials(const T* __restrict__ part, int nblk) {
+  double acc = 0.0;  // few hundred terms at most; fp64 keeps the reduction order-insensitive
+  for (int q = 0; q < nblk; ++q) acc += (double)part[q];
+  return (T)acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K-dots: partial[b][j][blk] = sum_{i in slice} rows[b][j][i] * x[b][i],  j < m
+//   forward  h = Q^T w            (arnoldi.py:87)      adjoint  P lam, z^T Q   (arnoldi.py:204,212)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void k_dots(const T* __restrict__ rows, int64_t rows_ldb,
+                                                 int64_t row_stride, int m,
+                                                 const T* __restrict__ x, int64_t ldx, int64_t n,
+                                                 T* __restrict__ partial, int kmax, int nblk) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* sm = reinterpret_cast<T*>(smem_raw);  // [4][m]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int b = blockIdx.y, blk = blockIdx.x;
+  const int64_t slice0 = (int64_t)blk * kSlice;
+  T xr[kEpt];
+  load_own<T, VEC>(xr, x + (int64_t)b * ldx, slice0, n, tid);
+  const T* rb = rows + (int64_t)b * rows_ldb;
+
+  for (int j = 0; j < m; ++j) {
+    T rr[kEpt];
+    load_own<T, VEC>(rr, rb + (int64_t)j * row_stride, slice0, n, tid);
+    T acc = T(0);
+#pragma unroll
+    for (int e = 0; e < kEpt; ++e) acc += rr[e] * xr[e];
+    acc = wave_sum(acc);
+    if (lane == 0) sm[wid * m + j] = acc;
+  }
+  __syncthreads();
+  for (int j = tid; j < m; j += kBlock)
+    partial[((int64_t)b * kmax + j) * nblk + blk] = sm[j] + sm[m + j] + sm[2 * m + j] + sm[3 * m + j];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K-update: coef_j = s1 * sum_blk partial_in[b][j][:] + s2 * extra[b][j];   y = x - sum_j coef_j row_j
+//   optional: hout[b][j] = coef_j (H column, arnoldi.py:99), second store y2, fused second dots
+//   (re-orthogonalisation pass, arnoldi.py:91-92) and fused |y|^2 partial (arnoldi.py:95).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct UpdateArgs {
+  const T* rows;
+  int64_t rows_ldb, row_stride;
+  int m;
+  const T* partial_in;  // (p, kmax, nblk) or null
+  T s1;
+  const T* extra;  // null or extra[b*extra_ldb + j*extra_stride]
+  int64_t extra_ldb, extra_stride;
+  T s2;
+  T* hout;  // null or hout[b*hout_ldb + j*hout_stride]
+  int64_t hout_ldb, hout_stride;
+  const T* x;  // null = zeros
+  int64_t ldx;
+  T* y;
+  int64_t ldy;
+  T* y2;  // optional second destination
+  int64_t ldy2;
+  int64_t n;
+  T* partial_out;   // DOTS
+  T* partial_norm;  // NORM: (p, nblk)
+  int kmax, nblk;
+};
+
+template <typename T, int VEC, bool DOTS, bool NORM>
+__global__ __launch_bounds__(kBlock) void k_update(UpdateArgs<T> a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* coef = reinterpret_cast<T*>(smem_raw);  // [m]
+  T* sm = coef + a.m;                         // [4][m] (DOTS) ; [4] (NORM) after that
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int b = blockIdx.y, blk = blockIdx.x;
+  const int64_t slice0 = (int64_t)blk * kSlice;
+  const int m = a.m;
+  for (int j = tid; j < m; j += kBlock) {
+    T c = T(0);
+    if (a.partial_in) c = a.s1 * reduce_partials(a.partial_in + ((int64_t)b * a.kmax + j) * a.nblk, a.nblk);
+    if (a.extra) c += a.s2 * a.extra[(int64_t)b * a.extra_ldb + (int64_t)j * a.extra_stride];
+    coef[j] = c;
+    if (a.hout && blk == 0) a.hout[(int64_t)b * a.hout_ldb + (int64_t)j * a.hout_stride] = c;
+  }
+  __syncthreads();
+  T xr[kEpt];
+  if (a.x) {
+    load_own<T, VEC>(xr, a.x + (int64_t)b * a.ldx, slice0, a.n, tid);
+  } else {
+#pragma unroll
+    for (int e = 0; e < kEpt; ++e) xr[e] = T(0);
+  }
+  const T* rb = a.rows + (int64_t)b * a.rows_ldb;
+
+  for (int j = 0; j < m; ++j) {
+    T rr[kEpt];
+    load_own<T, VEC>(rr, rb + (int64_t)j * a.row_stride, slice0, a.n, tid);
+    const T c = coef[j];
+#pragma unroll
+    for (int e = 0; e < kEpt; ++e) xr[e] -= c * rr[e];
+  }
+  store_own<T, VEC>(xr, a.y + (int64_t)b * a.ldy, slice0, a.n, tid);
+  if (a.y2) store_own<T, VEC>(xr, a.y2 + (int64_t)b * a.ldy2, slice0, a.n, tid);
+  if constexpr (DOTS) {
+
+    for (int j = 0; j < m; ++j) {
+      T rr[kEpt];
+      load_own<T, VEC>(rr, rb + (int64_t)j * a.row_stride, slice0, a.n, tid);
+      T acc = T(0);
+#pragma unroll
+      for (int e = 0; e < kEpt; ++e) acc += rr[e] * xr[e];
+      acc = wave_sum(acc);
+      if (lane == 0) sm[wid * m + j] = acc;
+    }
+    __syncthreads();
+    for (int j = tid; j < m; j += kBlock)
+      a.partial_out[((int64_t)b * a.kmax + j) * a.nblk + blk] =
+          sm[j] + sm[m + j] + sm[2 * m + j] + sm[3 * m + j];
+  }
+  if constexpr (NORM) {
+    T* smn = sm + (DOTS ? 4 * m : 0);
+    T acc = T(0);
+#pragma unroll
+    for (int e = 0; e < kEpt; ++e) acc += xr[e] * xr[e];
+    acc = wave_sum(acc);
+    if (lane == 0) smn[wid] = acc;
+    __syncthreads();
+    if (tid == 0) a.partial_norm[(int64_t)b * a.nblk + blk] = smn[0] + smn[1] + smn[2] + smn[3];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K-sumsq: partial_norm[b][blk] = sum x^2          (arnoldi.py:67, lanczos.py:222)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void k_sumsq(const T* __restrict__ x, int64_t ldx, int64_t n,
+                                                  T* __restrict__ partial_norm, int nblk) {
+  __shared__ T smn[4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int b = blockIdx.y, blk = blockIdx.x;
+  T xr[kEpt];
+  load_own<T, VEC>(xr, x + (int64_t)b * ldx, (int64_t)blk * kSlice, n, tid);
+  T acc = T(0);
+#pragma unroll
+  for (int e = 0; e < kEpt; ++e) acc += xr[e] * xr[e];
+  acc = wave_sum(acc);
+  if (lane == 0) smn[wid] = acc;
+  __syncthreads();
+  if (tid == 0) partial_norm[(int64_t)b * nblk + blk] = smn[0] + smn[1] + smn[2] + smn[3];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K-scale: len = sqrt(sum_blk partial_norm[b][:]) (or given scale[b]);  y = x * f,
+//   mode 0: f = 1/len   (normalise: arnoldi.py:80, lanczos.py:258)      mode 1: f = scale[b]      mode 2: f = -1
+//   optional scalar outputs: len_out[b*ld] = len, inv_out[b] = 1/len.  y may be null (scalars only).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void k_scale(const T* __restrict__ x, int64_t ldx,
+                                                  T* __restrict__ y, int64_t ldy, int64_t n,
+                                                  const T* __restrict__ partial_norm, int nblk,
+                                                  const T* __restrict__ scale, int mode,
+                                                  T* __restrict__ len_out, int64_t len_ld,
+                                                  T* __restrict__ inv_out) {
+  __shared__ T f_sh;
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y, blk = blockIdx.x;
+  if (tid == 0) {
+    T f;
+    if (mode == 0) {
+      const T len = sqrt(reduce_partials(partial_norm + (int64_t)b * nblk, nblk));
+      f = T(1) / len;
+      if (blk == 0) {
+        if (len_out) len_out[(int64_t)b * len_ld] = len;
+        if (inv_out) inv_out[b] = f;
+      }
+    } else if (mode == 1) {
+      f = scale[b];
+    } else {
+      f = T(-1);
+    }
+    f_sh = f;
+  }
+  __syncthreads();
+  if (!y) return;
+  const T f = f_sh;
+  T xr[kEpt];
+  load_own<T, VEC>(xr, x + (int64_t)b * ldx, (int64_t)blk * kSlice, n, tid);
+#pragma unroll
+  for (int e = 0; e < kEpt; ++e) xr[e] *= f;
+  store_own<T, VEC>(xr, y + (int64_t)b * ldy, (int64_t)blk * kSlice, n, tid);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Arnoldi-adjoint small setup, one workgroup per probe (arnoldi.py:120,128):
+//   eta_j = dH[j][k-1] - (Q^T dr)_j ;  Pi_gamma = -dc c e1 e1^T + H dH^T   (dQ^T Q subtracted later)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_adj_setup(const T* __restrict__ H, const T* __restrict__ dH, const T* __restrict__ c,
+                            const T* __restrict__ dc, const T* __restrict__ part_qtdr, int kmax,
+                            int nblk, int k, T* __restrict__ eta, T* __restrict__ pig) {
+  const int b = blockIdx.x;
+  const T* Hb = H + (int64_t)b * k * k;
+  const T* dHb = dH + (int64_t)b * k * k;
+  for (int j = threadIdx.x; j < k; j += blockDim.x) {
+    T e = dHb[(int64_t)j * k + (k - 1)];
+    if (part_qtdr) e -= reduce_partials(part_qtdr + ((int64_t)b * kmax + j) * nblk, nblk);
+    eta[(int64_t)b * k + j] = e;
+  }
+  for (int ij = threadIdx.x; ij < k * k; ij += blockDim.x) {
+    const int i = ij / k, j = ij % k;
+    double acc = 0.0;
+    for (int l = 0; l < k; ++l) acc += (double)Hb[(int64_t)i * k + l] * (double)dHb[(int64_t)j * k + l];
+    if (i == 0 && j == 0 && dc) acc -= (double)dc[b] * (double)c[b];
+    pig[(int64_t)b * k * k + ij] = (T)acc;
+  }
+}
+
+// Pi_gamma[b][col][j] -= (dQ[:,col] . Q[:,j])  from dots partials   (arnoldi.py:128, "- dQ.T @ Q")
+template <typename T>
+__global__ void k_pig_sub(T* __restrict__ pig, int k, int col, const T* __restrict__ partial, int kmax,
+                          int nblk) {
+  const int b = blockIdx.x;
+  for (int j = threadIdx.x; j < k; j += blockDim.x)
+    pig[((int64_t)b * k + col) * k + j] -= reduce_partials(partial + ((int64_t)b * kmax + j) * nblk, nblk);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Arnoldi-adjoint combine (arnoldi.py:212-220), step idx:
+//   Gamma[idx][j] = lower[idx][j] (Pi_gamma[idx][j] - (z^T Q)_j)            j <= idx
+//   g_j = (Gamma + Gamma^T)[idx][j]                                          all j < k
+//   out = (dQ[idx] + eta_idx r + sum_j g_j q_j - alpha lam + z - sum_{j>idx} H[idx][j] Lam_j) / beta_minus
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct CombineArgs {
+  const T *Q, *Lam, *H, *pig, *eta, *r, *dQ, *z, *partial;
+  T* Gam;
+  T* out;
+  int64_t n;
+  int k, idx, kmax, nblk;
+};
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void k_adj_combine(CombineArgs<T> a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* g = reinterpret_cast<T*>(smem_raw);  // [k]
+  T* hp = g + a.k;                         // [k]
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y, blk = blockIdx.x;
+  const int k = a.k, idx = a.idx;
+  const int64_t kk = (int64_t)k * k;
+  const T* Hb = a.H + (int64_t)b * kk;
+  T* Gb = a.Gam + (int64_t)b * kk;
+  for (int j = tid; j < k; j += kBlock) {
+    T gj;
+    if (j <= idx) {
+      const T zq = reduce_partials(a.partial + ((int64_t)b * a.kmax + j) * a.nblk, a.nblk);
+      const T low = (j < idx) ? T(1) : T(0.5);
+      const T gam = low * (a.pig[(int64_t)b * kk + (int64_t)idx * k + j] - zq);
+      if (blk == 0) Gb[(int64_t)idx * k + j] = gam;
+      gj = (j < idx) ? gam : T(2) * gam;
+      hp[j] = T(0);
+    } else {
+      gj = Gb[(int64_t)j * k + idx];  // written by the combine kernel of step j (earlier launch)
+      hp[j] = Hb[(int64_t)idx * k + j];
+    }
+    g[j] = gj;
+  }
+  __syncthreads();
+  const T alpha = Hb[(int64_t)idx * k + idx];
+  const T bminus = (idx == 0) ? T(1) : Hb[(int64_t)idx * k + idx - 1];
+  const T eta_i = a.eta[(int64_t)b * k + idx];
+  const int64_t slice0 = (int64_t)blk * kSlice;
+  const int64_t n = a.n;
+  const T* Qb = a.Q + (int64_t)b * k * n;
+  const T* Lb = a.Lam + (int64_t)b * k * n;
+  T acc[kEpt], t[kEpt];
+  load_own<T, VEC>(acc, a.z + (int64_t)b * n, slice0, n, tid);
+  load_own<T, VEC>(t, Lb + (int64_t)idx * n, slice0, n, tid);
+#pragma unroll
+  for (int e = 0; e < kEpt; ++e) acc[e] -= alpha * t[e];
+  load_own<T, VEC>(t, a.r + (int64_t)b * n, slice0, n, tid);
+#pragma unroll
+  for (int e = 0; e < kEpt; ++e) acc[e] += eta_i * t[e];
+  if (a.dQ) {
+    load_own<T, VEC>(t, a.dQ + ((int64_t)b * k + idx) * n, slice0, n, tid);
+#pragma unroll
+    for (int e = 0; e < kEpt; ++e) acc[e] += t[e];
+  }
+
+  for (int j = 0; j < k; ++j) {
+    load_own<T, VEC>(t, Qb + (int64_t)j * n, slice0, n, tid);
+    const T gj = g[j];
+#pragma unroll
+    for (int e = 0; e < kEpt; ++e) acc[e] += gj * t[e];
+  }
+
+  for (int j = idx + 1; j < k; ++j) {
+    load_own<T, VEC>(t, Lb + (int64_t)j * n, slice0, n, tid);
+    const T hj = hp[j];
+#pragma unroll
+    for (int e = 0; e < kEpt; ++e) acc[e] -= hj * t[e];
+  }
+  const T inv = T(1) / bminus;
+#pragma unroll
+  for (int e = 0; e < kEpt; ++e) acc[e] *= inv;
+  store_own<T, VEC>(acc, a.out + (int64_t)b * n, slice0, n, tid);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Lanczos (no re-orthogonalisation) adjoint kernels, lanczos.py:317-335
+//   dots:  d0 = lam_plus . x_j ; d1 = x_{j+1} . xi ; d2 = x_j . xi        (xi not yet divided by b_j)
+//   lam :  mu = db_j - d0 + d1/b_j ; nu = da_j + d2/b_j ; lam = -xi/b_j + mu x_{j+1} + nu x_j
+//   xi' : -dx_j - A lam + a_j lam + b_j lam_plus - b_j nu x_{j+1}
+// ------------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void k_lz_adj_dots(const T* __restrict__ xj, const T* __restrict__ xj1,
+                                                        int64_t ldxs, const T* __restrict__ xi,
+                                                        const T* __restrict__ lam_plus, int64_t ldlp,
+                                                        int64_t n, T* __restrict__ partial, int nblk) {
+  __shared__ T sm[4][3];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int b = blockIdx.y, blk = blockIdx.x;
+  const int64_t slice0 = (int64_t)blk * kSlice;
+  T x0[kEpt], x1[kEpt], xv[kEpt], lp[kEpt];
+  load_own<T, VEC>(x0, xj + (int64_t)b * ldxs, slice0, n, tid);
+  load_own<T, VEC>(x1, xj1 + (int64_t)b * ldxs, slice0, n, tid);
+  load_own<T, VEC>(xv, xi + (int64_t)b * n, slice0, n, tid);
+  if (lam_plus) {
+    load_own<T, VEC>(lp, lam_plus + (int64_t)b * ldlp, slice0, n, tid);
+  } else {
+#pragma unroll
+    for (int e = 0; e < kEpt; ++e) lp[e] = T(0);
+  }
+  T d0 = 0, d1 = 0, d2 = 0;
+#pragma unroll
+  for (int e = 0; e < kEpt; ++e) {
+    d0 += lp[e] * x0[e];
+    d1 += x1[e] * xv[e];
+    d2 += x0[e] * xv[e];
+  }
+  d0 = wave_sum(d0);
+  d1 = wave_sum(d1);
+  d2 = wave_sum(d2);
+  if (lane == 0) {
+    sm[wid][0] = d0;
+    sm[wid][1] = d1;
+    sm[wid][2] = d2;
+  }
+  __syncthreads();
+  if (tid < 3) partial[((int64_t)b * 3 + tid) * nblk + blk] = sm[0][tid] + sm[1][tid] + sm[2][tid] + sm[3][tid];
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void k_lz_adj_lambda(const T* __restrict__ xj, const T* __restrict__ xj1,
+                                                          int64_t ldxs, const T* __restrict__ xi,
+                                                          int64_t n, const T* __restrict__ partial, int nblk,
+                                                          const T* __restrict__ beta, const T* __restrict__ dalpha,
+                                                          const T* __restrict__ dbeta, int k, int j,
+                                                          T* __restrict__ lam_out, int64_t ldlam,
+                                                          T* __restrict__ munu /* (p,2) */) {
+  __shared__ T sc[3];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y, blk = blockIdx.x;
+  if (tid == 0) {
+    const T bj = beta[(int64_t)b * k + j];
+    const T d0 = reduce_partials(partial + ((int64_t)b * 3 + 0) * nblk, nblk);
+    const T d1 = reduce_partials(partial + ((int64_t)b * 3 + 1) * nblk, nblk);
+    const T d2 = reduce_partials(partial + ((int64_t)b * 3 + 2) * nblk, nblk);
+    const T mu = dbeta[(int64_t)b * k + j] - d0 + d1 / bj;
+    const T nu = dalpha[(int64_t)b * k + j] + d2 / bj;
+    sc[0] = mu;
+    sc[1] = nu;
+    sc[2] = T(1) / bj;
+    if (blk == 0) {
+      munu[(int64_t)b * 2 + 0] = mu;
+      munu[(int64_t)b * 2 + 1] = nu;
+    }
+  }
+  __syncthreads();
+  const T mu = sc[0], nu = sc[1], ib = sc[2];
+  const int64_t slice0 = (int64_t)blk * kSlice;
+  T x0[kEpt], x1[kEpt], xv[kEpt];
+  load_own<T, VEC>(x0, xj + (int64_t)b * ldxs, slice0, n, tid);
+  load_own<T, VEC>(x1, xj1 + (int64_t)b * ldxs, slice0, n, tid);
+  load_own<T, VEC>(xv, xi + (int64_t)b * n, slice0, n, tid);
+#pragma unroll
+  for (int e = 0; e < kEpt; ++e) xv[e] = -xv[e] * ib + mu * x1[e] + nu * x0[e];
+  store_own<T, VEC>(xv, lam_out + (int64_t)b * ldlam, slice0, n, tid);
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void k_lz_adj_xi(const T* __restrict__ dxj, int64_t lddxs,
+                                                      const T* __restrict__ Alam, const T* __restrict__ lam,
+                                                      int64_t ldlam, const T* __restrict__ lam_plus,
+                                                      int64_t ldlp, const T* __restrict__ xj1, int64_t ldxs,
+                                                      int64_t n, const T* __restrict__ alpha,
+                                                      const T* __restrict__ beta, int k, int j,
+                                                      const T* __restrict__ munu, T* __restrict__ xi_out) {
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y, blk = blockIdx.x;
+  const T aj = alpha[(int64_t)b * k + j], bj = beta[(int64_t)b * k + j];
+  const T nu = munu[(int64_t)b * 2 + 1];
+  const int64_t slice0 = (int64_t)blk * kSlice;
+  T acc[kEpt], t[kEpt];
+  load_own<T, VEC>(acc, Alam + (int64_t)b * n, slice0, n, tid);
+#pragma unroll
+  for (int e = 0; e < kEpt; ++e) acc[e] = -acc[e];
+  if (dxj) {
+    load_own<T, VEC>(t, dxj + (int64_t)b * lddxs, slice0, n, tid);
+#pragma unroll
+    for (int e = 0; e < kEpt; ++e) acc[e] -= t[e];
+  }
+  load_own<T, VEC>(t, lam + (int64_t)b * ldlam, slice0, n, tid);
+#pragma unroll
+  for (int e = 0; e < kEpt; ++e) acc[e] += aj * t[e];
+  if (lam_plus) {
+    load_own<T, VEC>(t, lam_plus + (int64_t)b * ldlp, slice0, n, tid);
+#pragma unroll
+    for (int e = 0; e < kEpt; ++e) acc[e] += bj * t[e];
+  }
+  load_own<T, VEC>(t, xj1 + (int64_t)b * ldxs, slice0, n, tid);
+#pragma unroll
+  for (int e = 0; e < kEpt; ++e) acc[e] -= bj * nu * t[e];
+  store_own<T, VEC>(acc, xi_out + (int64_t)b * n, slice0, n, tid);
+}
+
+// Lanczos forward coefficients: coef[b][0..m) for r = w - a x_i - b_{i-1} x_{i-1} (lanczos.py:281-282)
+// rows = xs[i-1], xs[i] (m = 2) or xs[0] (m = 1): coef = (beta_{i-1}, a) / (a)
+template <typename T>
+__global__ void k_lz_coef(const T* __restrict__ partial, int kmax, int nblk, const T* __restrict__ beta,
+                          int k, int i, T* __restrict__ alpha, T* __restrict__ coef /* (p,2) */) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= gridDim.x * blockDim.x) return;
+  const T a = reduce_partials(partial + ((int64_t)b * kmax) * nblk, nblk);
+  alpha[(int64_t)b * k + i] = a;
+  if (i == 0) {
+    coef[(int64_t)b * 2 + 0] = a;
+  } else {
+    coef[(int64_t)b * 2 + 0] = beta[(int64_t)b * k + i - 1];
+    coef[(int64_t)b * 2 + 1] = a;
+  }
+}
+
+// final Lanczos-adjoint initial-vector gradient: dvec = ((xi.x0) x0 - xi) / |v|  (lanczos.py:311)
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void k_lz_adj_dvec(const T* __restrict__ x0, int64_t ldxs,
+                                                        const T* __restrict__ xi, int64_t n,
+                                                        const T* __restrict__ partial, int kmax, int nblk,
+                                                        const T* __restrict__ vnorm, T* __restrict__ dv) {
+  __shared__ T sc[2];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y, blk = blockIdx.x;
+  if (tid == 0) {
+    sc[0] = reduce_partials(partial + ((int64_t)b * kmax) * nblk, nblk);
+    sc[1] = T(1) / vnorm[b];
+  }
+  __syncthreads();
+  const T d = sc[0], inv = sc[1];
+  const int64_t slice0 = (int64_t)blk * kSlice;
+  T a[kEpt], x[kEpt];
+  load_own<T, VEC>(a, xi + (int64_t)b * n, slice0, n, tid);
+  load_own<T, VEC>(x, x0 + (int64_t)b * ldxs, slice0, n, tid);
+#pragma unroll
+  for (int e = 0; e < kEpt; ++e) a[e] = (d * x[e] - a[e]) * inv;
+  store_own<T, VEC>(a, dv + (int64_t)b * n, slice0, n, tid);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side launch helpers
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+static int pick_vec(int64_t n, std::initializer_list<const void*> ptrs) {
+  constexpr int V = VecWidth<T>::value;
+  if (n % V != 0) return 1;
+  for (const void* p : ptrs)
+    if (p && (reinterpret_cast<uintptr_t>(p) % 16) != 0) return 1;
+  return V;
+}
+
+#define MFX_VEC_SWITCH(vec, ...)                \
+  if ((vec) > 1) {                              \
+    constexpr int VEC = VecWidth<T>::value;     \
+    __VA_ARGS__;                                \
+  } else {                                      \
+    constexpr int VEC = 1;                      \
+    __VA_ARGS__;                                \
+  }
+
+template <typename T>
+struct Ctx {
+  int64_t n, k, p;
+  int nblk, kmax, vec;
+  hipStream_t stream;
+  dim3 grid() const { return dim3(nblk, (unsigned)p); }
+};
+
+template <typename T>
+static int launch_dots(const Ctx<T>& c, const T* rows, int64_t rows_ldb, int64_t row_stride, int m,
+                       const T* x, int64_t ldx, T* partial) {
+  if (m <= 0) return MFX_OK;
+  const size_t sh = (size_t)4 * m * sizeof(T);
+  MFX_VEC_SWITCH(c.vec, (k_dots<T, VEC><<<c.grid(), kBlock, sh, c.stream>>>(
+                            rows, rows_ldb, row_stride, m, x, ldx, c.n, partial, c.kmax, c.nblk)));
+  MFX_CHECK_LAUNCH();
+  return MFX_OK;
+}
+
+template <typename T>
+static int launch_update(const Ctx<T>& c, UpdateArgs<T> a, bool dots, bool norm) {
+  a.n = c.n;
+  a.kmax = c.kmax;
+  a.nblk = c.nblk;
+  const size_t sh = (size_t)(a.m + (dots ? 4 * a.m : 0) + 4) * sizeof(T);
+  if (dots && norm) {
+    MFX_VEC_SWITCH(c.vec, (k_update<T, VEC, true, true><<<c.grid(), kBlock, sh, c.stream>>>(a)));
+  } else if (dots) {
+    MFX_VEC_SWITCH(c.vec, (k_update<T, VEC, true, false><<<c.grid(), kBlock, sh, c.stream>>>(a)));
+  } else if (norm) {
+    MFX_VEC_SWITCH(c.vec, (k_update<T, VEC, false, true><<<c.grid(), kBlock, sh, c.stream>>>(a)));
+  } else {
+    MFX_VEC_SWITCH(c.vec, (k_update<T, VEC, false, false><<<c.grid(), kBlock, sh, c.stream>>>(a)));
+  }
+  MFX_CHECK_LAUNCH();
+  return MFX_OK;
+}
+
+template <typename T>
+static int launch_sumsq(const Ctx<T>& c, const T* x, int64_t ldx, T* partial_norm) {
+  MFX_VEC_SWITCH(c.vec, (k_sumsq<T, VEC><<<c.grid(), kBlock, 0, c.stream>>>(x, ldx, c.n, partial_norm, c.nblk)));
+  MFX_CHECK_LAUNCH();
+  return MFX_OK;
+}
+
+template <typename T>
+static int launch_scale(const Ctx<T>& c, const T* x, int64_t ldx, T* y, int64_t ldy, const T* partial_norm,
+                        const T* scale, int mode, T* len_out, int64_t len_ld, T* inv_out) {
+  dim3 grid = y ? c.grid() : dim3(1, (unsigned)c.p);
+  MFX_VEC_SWITCH(c.vec, (k_scale<T, VEC><<<grid, kBlock, 0, c.stream>>>(x, ldx, y, ldy, c.n, partial_norm, c.nblk,
+                                                                        scale, mode, len_out, len_ld, inv_out)));
+  MFX_CHECK_LAUNCH();
+  return MFX_OK;
+}
+
+static int apply_any(const mfx_operator* op, int mode, const void* x, int64_t ldx, const void* aux,
+                     int64_t ldaux, void* y, int64_t ldy, int64_t p, void* ws, int64_t ws_bytes,
+                     hipStream_t stream) {
+  if (op->kind == MFX_OP_CALLBACK) return op_apply_cb(op, mode, x, ldx, aux, ldaux, y, ldy, p, stream);
+  ScopedTimer t(0, stream);
+  return op_apply(op, x, ldx, y, ldy, p, mode == 1 ? 1 : 0, ws, ws_bytes, stream);
+}
+
+struct KrylovWs {
+  void *w, *p1, *p2, *pn, *small, *opws;
+  int64_t opws_bytes;
+};
+
+static int64_t carve_ws(const mfx_operator* op, int64_t n, int64_t k, int64_t p, void* ws, int64_t ws_bytes,
+                        KrylovWs* out) {
+  const size_t es = dtype_size(op->dtype);
+  const int64_t nblk = num_slices(n);
+  const int64_t kmax = k + 1;
+  Carver cv(ws, ws_bytes);
+  KrylovWs r;
+  r.w = cv.take(2 * p * n * es);                // two (p, n) scratch vectors
+  r.p1 = cv.take(p * kmax * nblk * es);         // dots partials
+  r.p2 = cv.take(p * kmax * nblk * es);         // second-pass partials
+  r.pn = cv.take(p * 3 * nblk * es);            // norm / 3-dot partials
+  r.small = cv.take((2 * p * k * k + 4 * p * k + 8 * p) * es);  // Gamma, Pi_gamma, eta, coefficients
+  r.opws_bytes = op_workspace_bytes(op, p);
+  r.opws = cv.take(r.opws_bytes);
+  if (out) *out = r;
+  return cv.off;
+}
+
+// ------------------------------------------------------------------------------------------------
+// drivers
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+static int arnoldi_forward_t(const mfx_operator* op, const T* v0, int64_t n, int64_t k, int64_t p,
+                             int second_pass, T* Q, T* H, T* r, T* cinv, const KrylovWs& ws,
+                             hipStream_t stream) {
+  Ctx<T> c{n, k, p, (int)num_slices(n), (int)(k + 1), pick_vec<T>(n, {v0, Q, r, ws.w}), stream};
+  T* P1 = static_cast<T*>(ws.p1);
+  T* P2 = static_cast<T*>(ws.p2);
+  T* PN = static_cast<T*>(ws.pn);
+  const int64_t ldq = k * n;
+  MFX_CHECK_HIP(hipMemsetAsync(H, 0, sizeof(T) * p * k * k, stream));
+  {
+    ScopedTimer t(2, stream);
+    MFX_TRY(launch_sumsq<T>(c, v0, n, PN));
+    MFX_TRY(launch_scale<T>(c, v0, n, Q, ldq, PN, nullptr, 0, nullptr, 0, cinv));  // q_0, c = 1/|v|
+  }
+  T* w = r;  // the running vector lives in the remainder output (arnoldi.py:75 returns it as r)
+  for (int64_t i = 0; i < k; ++i) {
+    const int m = (int)(i + 1);
+    MFX_TRY(apply_any(op, 0, Q + i * n, ldq, nullptr, 0, w, n, p, ws.opws, ws.opws_bytes, stream));
+    ScopedTimer t(2, stream);
+    MFX_TRY(launch_dots<T>(c, Q, ldq, n, m, w, n, P1));
+    UpdateArgs<T> a{};
+    a.rows = Q; a.rows_ldb = ldq; a.row_stride = n; a.m = m;
+    a.partial_in = P1; a.s1 = T(1);
+    a.hout = H + i; a.hout_ldb = k * k; a.hout_stride = k;  // H[:, i] (arnoldi.py:99)
+    a.x = w; a.ldx = n; a.y = w; a.ldy = n;
+    a.partial_out = P2; a.partial_norm = PN;
+    if (second_pass) {
+      MFX_TRY(launch_update<T>(c, a, true, false));
+      UpdateArgs<T> a2{};
+      a2.rows = Q; a2.rows_ldb = ldq; a2.row_stride = n; a2.m = m;
+      a2.partial_in = P2; a2.s1 = T(1);  // second-pass coefficients are not added to h (arnoldi.py:92)
+      a2.x = w; a2.ldx = n; a2.y = w; a2.ldy = n; a2.partial_norm = PN;
+      MFX_TRY(launch_update<T>(c, a2, false, true));
+    } else {
+      MFX_TRY(launch_update<T>(c, a, false, true));
+    }
+    if (i + 1 < k) {  // Q2: H[k][k-1] does not exist; the last vector stays un-normalised in r
+      MFX_TRY(launch_scale<T>(c, w, n, Q + (i + 1) * n, ldq, PN, nullptr, 0, H + (i + 1) * k + i, k * k, nullptr));
+    }
+  }
+  return MFX_OK;
+}
+
+template <typename T>
+static int arnoldi_adjoint_t(const mfx_operator* op, int64_t n, int64_t k, int64_t p, const T* Q, const T* H,
+                             const T* r, const T* cinv, const T* dQ, const T* dH, const T* dr, const T* dc,
+                             int reortho, T* dv, T* Lam, const mfx_op_grads* grads, const KrylovWs& ws,
+                             hipStream_t stream) {
+  Ctx<T> c{n, k, p, (int)num_slices(n), (int)(k + 1), pick_vec<T>(n, {Q, r, dQ, dr, dv, Lam, ws.w}), stream};
+  T* P1 = static_cast<T*>(ws.p1);
+  T* lam = static_cast<T*>(ws.w);  // current lambda (p, n)
+  T* z = lam + p * n;              // A^T lambda     (p, n)
+  T* Gam = static_cast<T*>(ws.small);
+  T* pig = Gam + p * k * k;
+  T* eta = pig + p * k * k;
+  const int64_t ldq = k * n;
+  MFX_CHECK_HIP(hipMemsetAsync(Gam, 0, sizeof(T) * p * k * k, stream));
+  {
+    ScopedTimer t(2, stream);
+    if (dr) MFX_TRY(launch_dots<T>(c, Q, ldq, n, (int)k, dr, n, P1));
+    k_adj_setup<T><<<(unsigned)p, 256, 0, stream>>>(H, dH, cinv, dc, dr ? P1 : nullptr, c.kmax, c.nblk, (int)k, eta, pig);
+    MFX_CHECK_LAUNCH();
+    if (dQ) {
+      for (int64_t col = 0; col < k; ++col) {
+        MFX_TRY(launch_dots<T>(c, Q, ldq, n, (int)k, dQ + col * n, ldq, P1));
+        k_pig_sub<T><<<(unsigned)p, 64, 0, stream>>>(pig, (int)k, (int)col, P1, c.kmax, c.nblk);
+        MFX_CHECK_LAUNCH();
+      }
+    }
+    // lambda_k = dr + Q eta  (arnoldi.py:121)
+    UpdateArgs<T> a{};
+    a.rows = Q; a.rows_ldb = ldq; a.row_stride = n; a.m = (int)k;
+    a.extra = eta; a.extra_ldb = k; a.extra_stride = 1; a.s2 = T(-1);
+    a.x = dr; a.ldx = n; a.y = lam; a.ldy = n;
+    MFX_TRY(launch_update<T>(c, a, false, false));
+  }
+  for (int64_t idx = k - 1; idx >= 0; --idx) {
+    T* lam_idx = Lam + idx * n;  // Lambda[:, idx] (arnoldi.py:216), leading dimension ldq
+    {
+      ScopedTimer t(2, stream);
+      if (reortho == MFX_REORTHO_FULL) {
+        const int m = (int)((idx + 2 < k) ? idx + 2 : k);  // rows of P not yet masked (arnoldi.py:201)
+        MFX_TRY(launch_dots<T>(c, Q, ldq, n, m, lam, n, P1));
+        UpdateArgs<T> a{};
+        a.rows = Q; a.rows_ldb = ldq; a.row_stride = n; a.m = m;
+        a.partial_in = P1; a.s1 = T(1);
+        a.extra = dH + idx; a.extra_ldb = k * k; a.extra_stride = k; a.s2 = T(-1);  // - P^T (mask o dH[:, idx])
+        a.x = lam; a.ldx = n; a.y = lam_idx; a.ldy = ldq;
+        MFX_TRY(launch_update<T>(c, a, false, false));
+      } else {
+        MFX_CHECK_HIP(hipMemcpy2DAsync(lam_idx, sizeof(T) * ldq, lam, sizeof(T) * n, sizeof(T) * n, p,
+                                       hipMemcpyDeviceToDevice, stream));
+      }
+    }
+    // z = A^T lambda (+ parameter gradient for callback operators), arnoldi.py:207-209
+    MFX_TRY(apply_any(op, 1, lam_idx, ldq, Q + idx * n, ldq, z, n, p, ws.opws, ws.opws_bytes, stream));
+    ScopedTimer t(2, stream);
+    MFX_TRY(launch_dots<T>(c, Q, ldq, n, (int)(idx + 1), z, n, P1));
+    CombineArgs<T> ca{Q, Lam, H, pig, eta, r, dQ, z, P1, Gam, lam, n, (int)k, (int)idx, c.kmax, c.nblk};
+    const size_t sh = (size_t)2 * k * sizeof(T);
+    MFX_VEC_SWITCH(c.vec, (k_adj_combine<T, VEC><<<c.grid(), kBlock, sh, stream>>>(ca)));
+    MFX_CHECK_LAUNCH();
+  }
+  {
+    ScopedTimer t(2, stream);
+    MFX_TRY(launch_scale<T>(c, lam, n, dv, n, nullptr, cinv, 1, nullptr, 0, nullptr));  // dv = lambda c
+  }
+  if (op->kind != MFX_OP_CALLBACK && grads) {
+    ScopedTimer t(1, stream);
+    MFX_TRY(op_vjp_params(op, Lam, n, Q, n, p * k, grads, ws.opws, ws.opws_bytes, stream));
+  }
+  return MFX_OK;
+}
+
+template <typename T>
+static int lanczos_forward_t(const mfx_operator* op, const T* v0, int64_t n, int64_t k, int64_t p, T* xs,
+                             T* alpha, T* beta, T* vnorm, const KrylovWs& ws, hipStream_t stream) {
+  Ctx<T> c{n, k, p, (int)num_slices(n), (int)(k + 1), pick_vec<T>(n, {v0, xs, ws.w}), stream};
+  T* P1 = static_cast<T*>(ws.p1);
+  T* PN = static_cast<T*>(ws.pn);
+  T* w = static_cast<T*>(ws.w);
+  T* coef = static_cast<T*>(ws.small);
+  const int64_t ldx = (k + 1) * n;
+  {
+    ScopedTimer t(2, stream);
+    MFX_TRY(launch_sumsq<T>(c, v0, n, PN));
+    MFX_TRY(launch_scale<T>(c, v0, n, xs, ldx, PN, nullptr, 0, vnorm, 1, nullptr));
+  }
+  for (int64_t i = 0; i < k; ++i) {
+    MFX_TRY(apply_any(op, 0, xs + i * n, ldx, nullptr, 0, w, n, p, ws.opws, ws.opws_bytes, stream));
+    ScopedTimer t(2, stream);
+    MFX_TRY(launch_dots<T>(c, xs + i * n, ldx, n, 1, w, n, P1));  // a = x_i . A x_i
+    k_lz_coef<T><<<1, (unsigned)p, 0, stream>>>(P1, c.kmax, c.nblk, beta, (int)k, (int)i, alpha, coef);
+    MFX_CHECK_LAUNCH();
+    UpdateArgs<T> a{};
+    const int m = i == 0 ? 1 : 2;
+    a.rows = xs + (i == 0 ? 0 : (i - 1) * n); a.rows_ldb = ldx; a.row_stride = n; a.m = m;
+    a.extra = coef; a.extra_ldb = 2; a.extra_stride = 1; a.s2 = T(1);
+    a.x = w; a.ldx = n; a.y = w; a.ldy = n; a.partial_norm = PN;
+    MFX_TRY(launch_update<T>(c, a, false, true));
+    MFX_TRY(launch_scale<T>(c, w, n, xs + (i + 1) * n, ldx, PN, nullptr, 0, beta + i, k, nullptr));
+  }
+  return MFX_OK;
+}
+
+template <typename T>
+static int lanczos_adjoint_t(const mfx_operator* op, int64_t n, int64_t k, int64_t p, const T* xs, const T* alpha,
+                             const T* beta, const T* vnorm, const T* dxs, const T* dalpha, const T* dbeta, T* dv,
+                             T* Lam, const mfx_op_grads* grads, const KrylovWs& ws, hipStream_t stream) {
+  Ctx<T> c{n, k, p, (int)num_slices(n), (int)(k + 1), pick_vec<T>(n, {xs, dxs, dv, Lam, ws.w}), stream};
+  T* P1 = static_cast<T*>(ws.p1);
+  T* PN = static_cast<T*>(ws.pn);
+  T* xi = static_cast<T*>(ws.w);
+  T* y = xi + p * n;
+  T* munu = static_cast<T*>(ws.small);
+  const int64_t ldx = (k + 1) * n, ldl = k * n;
+  // xi = -dx_k (lanczos.py:304)
+  if (dxs) {
+    MFX_TRY(launch_scale<T>(c, dxs + k * n, ldx, xi, n, nullptr, nullptr, 2, nullptr, 0, nullptr));
+  } else {
+    MFX_CHECK_HIP(hipMemsetAsync(xi, 0, sizeof(T) * p * n, stream));
+  }
+  for (int64_t j = k - 1; j >= 0; --j) {
+    const T* xj = xs + j * n;
+    const T* xj1 = xs + (j + 1) * n;
+    const T* lam_plus = (j + 1 < k) ? Lam + (j + 1) * n : nullptr;
+    T* lam_j = Lam + j * n;
+    {
+      ScopedTimer t(2, stream);
+      MFX_VEC_SWITCH(c.vec, (k_lz_adj_dots<T, VEC><<<c.grid(), kBlock, 0, stream>>>(xj, xj1, ldx, xi, lam_plus, ldl, n, PN, c.nblk)));
+      MFX_CHECK_LAUNCH();
+      MFX_VEC_SWITCH(c.vec, (k_lz_adj_lambda<T, VEC><<<c.grid(), kBlock, 0, stream>>>(
+                                xj, xj1, ldx, xi, n, PN, c.nblk, beta, dalpha, dbeta, (int)k, (int)j, lam_j, ldl, munu)));
+      MFX_CHECK_LAUNCH();
+    }
+    // A lambda (Q4: not A^T), parameter gradient of x_j^T A(theta) lambda (lanczos.py:328-329)
+    MFX_TRY(apply_any(op, 2, lam_j, ldl, xj, ldx, y, n, p, ws.opws, ws.opws_bytes, stream));
+    ScopedTimer t(2, stream);
+    MFX_VEC_SWITCH(c.vec, (k_lz_adj_xi<T, VEC><<<c.grid(), kBlock, 0, stream>>>(
+                              dxs ? dxs + j * n : nullptr, ldx, y, lam_j, ldl, lam_plus, ldl, xj1, ldx, n, alpha, beta,
+                              (int)k, (int)j, munu, xi)));
+    MFX_CHECK_LAUNCH();
+  }
+  {
+    ScopedTimer t(2, stream);
+    MFX_TRY(launch_dots<T>(c, xs, ldx, n, 1, xi, n, P1));  // xi . x_0 (Q3: "lambda_1" is the final xi)
+    MFX_VEC_SWITCH(c.vec, (k_lz_adj_dvec<T, VEC><<<c.grid(), kBlock, 0, stream>>>(xs, ldx, xi, n, P1, c.kmax, c.nblk, vnorm, dv)));
+    MFX_CHECK_LAUNCH();
+  }
+  if (op->kind != MFX_OP_CALLBACK && grads) {
+    // d/dtheta sum_j x_j^T A(theta) lambda_j : L = xs (ld (k+1) n per probe), R = Lambda
+    ScopedTimer t(1, stream);
+    for (int64_t b = 0; b < p; ++b)
+      MFX_TRY(op_vjp_params(op, xs + b * ldx, n, Lam + b * ldl, n, k, grads, ws.opws, ws.opws_bytes, stream));
+  }
+  return MFX_OK;
+}
+
+static int check_common(const mfx_operator* op, int64_t n, int64_t k, int64_t p) {
+  MFX_REQUIRE(op != nullptr, MFX_ERR_INVALID, "operator is NULL");
+  MFX_REQUIRE(op->dtype == MFX_F32 || op->dtype == MFX_F64, MFX_ERR_UNSUPPORTED, "unsupported dtype %d", op->dtype);
+  MFX_REQUIRE(n >= 1 && p >= 1, MFX_ERR_INVALID, "n=%lld, p=%lld must be positive", (long long)n, (long long)p);
+  MFX_REQUIRE(op->n == n, MFX_ERR_INVALID, "operator size %lld != n=%lld", (long long)op->n, (long long)n);
+  MFX_REQUIRE(k >= 1 && k <= n, MFX_ERR_INVALID, "Parameter depth %lld is outside the expected range", (long long)k);
+  MFX_REQUIRE(p <= 65535, MFX_ERR_UNSUPPORTED, "p=%lld exceeds the grid limit 65535", (long long)p);
+  MFX_REQUIRE((int64_t)(4 * (k + 1) + (k + 1) + 4) * 8 <= 64 * 1024, MFX_ERR_UNSUPPORTED, "k=%lld too large", (long long)k);
+  return MFX_OK;
+}
+
+}  // namespace mfx
+
+using namespace mfx;
+
+extern "C" {
+
+int64_t mfx_workspace_bytes(const mfx_operator* op, int64_t n, int64_t k, int64_t p) {
+  if (!op) return -1;
+  return carve_ws(op, n, k, p, nullptr, 0, nullptr);
+}
+
+int mfx_op_apply(const mfx_operator* op, const void* x, int64_t ldx, void* y, int64_t ldy, int64_t p,
+                 int transpose, void* ws, int64_t ws_bytes, void* stream) {
+  MFX_REQUIRE(op && x && y, MFX_ERR_INVALID, "null argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (op->kind == MFX_OP_CALLBACK) return op_apply_cb(op, transpose ? 1 : 0, x, ldx, nullptr, 0, y, ldy, p, s);
+  ScopedTimer t(0, s);
+  return op_apply(op, x, ldx, y, ldy, p, transpose, ws, ws_bytes, s);
+}
+
+int mfx_op_vjp_params(const mfx_operator* op, const void* L, int64_t ldl, const void* R, int64_t ldr,
+                      int64_t batch, const mfx_op_grads* grads, void* ws, int64_t ws_bytes, void* stream) {
+  MFX_REQUIRE(op && L && R && grads, MFX_ERR_INVALID, "null argument");
+  MFX_REQUIRE(op->kind != MFX_OP_CALLBACK, MFX_ERR_UNSUPPORTED, "callback operators own their parameter gradients");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  ScopedTimer t(1, s);
+  return op_vjp_params(op, L, ldl, R, ldr, batch, grads, ws, ws_bytes, s);
+}
+
+#define MFX_DRIVER_PROLOGUE()                                                                   \
+  MFX_TRY(check_common(op, n, k, p));                                                           \
+  KrylovWs kws;                                                                                 \
+  const int64_t need = carve_ws(op, n, k, p, ws, ws_bytes, &kws);                                \
+  MFX_REQUIRE(ws && need <= ws_bytes, MFX_ERR_WORKSPACE, "workspace too small: need %lld bytes", \
+              (long long)need);                                                                 \
+  hipStream_t s = static_cast<hipStream_t>(stream)
+
+int mfx_arnoldi_forward(const mfx_operator* op, const void* v0, int64_t n, int64_t k, int64_t p,
+                        int second_pass, void* Q, void* H, void* r, void* c, void* ws, int64_t ws_bytes,
+                        void* stream) {
+  MFX_REQUIRE(v0 && Q && H && r && c, MFX_ERR_INVALID, "null argument");
+  MFX_DRIVER_PROLOGUE();
+  if (op->dtype == MFX_F32)
+    return arnoldi_forward_t<float>(op, (const float*)v0, n, k, p, second_pass, (float*)Q, (float*)H, (float*)r, (float*)c, kws, s);
+  return arnoldi_forward_t<double>(op, (const double*)v0, n, k, p, second_pass, (double*)Q, (double*)H, (double*)r, (double*)c, kws, s);
+}
+
+int mfx_arnoldi_adjoint(const mfx_operator* op, int64_t n, int64_t k, int64_t p, const void* Q, const void* H,
+                        const void* r, const void* c, const void* dQ, const void* dH, const void* dr,
+                        const void* dc, int reortho, void* dv, void* Lambda, const mfx_op_grads* grads, void* ws,
+                        int64_t ws_bytes, void* stream) {
+  MFX_REQUIRE(Q && H && r && c && dH && dv && Lambda, MFX_ERR_INVALID, "null argument");
+  MFX_REQUIRE(reortho == MFX_REORTHO_NONE || reortho == MFX_REORTHO_FULL, MFX_ERR_INVALID, "bad reortho flag %d", reortho);
+  MFX_DRIVER_PROLOGUE();
+  if (op->dtype == MFX_F32)
+    return arnoldi_adjoint_t<float>(op, n, k, p, (const float*)Q, (const float*)H, (const float*)r, (const float*)c,
+                                    (const float*)dQ, (const float*)dH, (const float*)dr, (const float*)dc, reortho,
+                                    (float*)dv, (float*)Lambda, grads, kws, s);
+  return arnoldi_adjoint_t<double>(op, n, k, p, (const double*)Q, (const double*)H, (const double*)r, (const double*)c,
+                                   (const double*)dQ, (const double*)dH, (const double*)dr, (const double*)dc, reortho,
+                                   (double*)dv, (double*)Lambda, grads, kws, s);
+}
+
+int mfx_lanczos_forward(const mfx_operator* op, const void* v0, int64_t n, int64_t k, int64_t p, void* xs,
+                        void* alpha, void* beta, void* vnorm, void* ws, int64_t ws_bytes, void* stream) {
+  MFX_REQUIRE(v0 && xs && alpha && beta && vnorm, MFX_ERR_INVALID, "null argument");
+  MFX_DRIVER_PROLOGUE();
+  MFX_REQUIRE(p <= 1024, MFX_ERR_UNSUPPORTED, "lanczos (reortho none) supports p <= 1024 probes per call");
+  if (op->dtype == MFX_F32)
+    return lanczos_forward_t<float>(op, (const float*)v0, n, k, p, (float*)xs, (float*)alpha, (float*)beta, (float*)vnorm, kws, s);
+  return lanczos_forward_t<double>(op, (const double*)v0, n, k, p, (double*)xs, (double*)alpha, (double*)beta, (double*)vnorm, kws, s);
+}
+
+int mfx_lanczos_adjoint(const mfx_operator* op, int64_t n, int64_t k, int64_t p, const void* xs, const void* alpha,
+                        const void* beta, const void* vnorm, const void* dxs, const void* dalpha, const void* dbeta,
+                        void* dv, void* Lambda, const mfx_op_grads* grads, void* ws, int64_t ws_bytes, void* stream) {
+  MFX_REQUIRE(xs && alpha && beta && vnorm && dalpha && dbeta && dv && Lambda, MFX_ERR_INVALID, "null argument");
+  MFX_DRIVER_PROLOGUE();
+  if (op->dtype == MFX_F32)
+    return lanczos_adjoint_t<float>(op, n, k, p, (const float*)xs, (const float*)alpha, (const float*)beta,
+                                    (const float*)vnorm, (const float*)dxs, (const float*)dalpha, (const float*)dbeta,
+                                    (float*)dv, (float*)Lambda, grads, kws, s);
+  return lanczos_adjoint_t<double>(op, n, k, p, (const double*)xs, (const double*)alpha, (const double*)beta,
+                                   (const double*)vnorm, (const double*)dxs, (const double*)dalpha, (const double*)dbeta,
+                                   (double*)dv, (double*)Lambda, grads, kws, s);
+}
+
+}  // extern "C"

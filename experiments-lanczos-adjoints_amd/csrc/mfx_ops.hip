@@ -1,0 +1,520 @@
+// libmfx: operators A(theta) -- apply, transpose-apply and the deferred parameter-gradient sweep
+//   d/dtheta sum_b L_b^T A(theta) R_b        (arnoldi.py:207-209, lanczos.py:328-329)
+// for DENSE, CSR and matrix-free RBF-Gram operators, plus the CALLBACK trampoline.
+//
+// The RBF kernels in this file are the generic VALU path (any dtype, any number of probes); the
+// fp32 MFMA path for wide probe batches lives in mfx_rbf_mfma.hip and is selected in rbf_apply().
+#include "mfx_internal.h"
+
+namespace mfx {
+
+// ================================================================================================
+// DENSE   (tests/test_lanczos/test_tridiag_forward.py:18 `p @ s`)
+// ================================================================================================
+// y[b][i] = sum_j A[i][j] x[b][j] : one wave per row, PB probes per pass
+template <typename T, int PB>
+__global__ __launch_bounds__(256) void k_dense_apply(const T* __restrict__ A, int64_t lda, int64_t n,
+                                                     const T* __restrict__ x, int64_t ldx, T* __restrict__ y,
+                                                     int64_t ldy, int64_t p) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 4 + wid;
+  const int64_t b0 = (int64_t)blockIdx.y * PB;
+  if (i >= n) return;
+  T acc[PB];
+#pragma unroll
+  for (int q = 0; q < PB; ++q) acc[q] = T(0);
+  const T* row = A + i * lda;
+  for (int64_t j = lane; j < n; j += 64) {
+    const T a = row[j];
+#pragma unroll
+    for (int q = 0; q < PB; ++q)
+      if (b0 + q < p) acc[q] += a * x[(b0 + q) * ldx + j];
+  }
+#pragma unroll
+  for (int q = 0; q < PB; ++q) {
+    const T s = wave_sum(acc[q]);
+    if (lane == 0 && b0 + q < p) y[(b0 + q) * ldy + i] = s;
+  }
+}
+
+// y[b][j] = sum_i A[i][j] x[b][i] : lane = column, the 4 waves split the rows
+template <typename T, int PB>
+__global__ __launch_bounds__(256) void k_dense_apply_t(const T* __restrict__ A, int64_t lda, int64_t n,
+                                                       const T* __restrict__ x, int64_t ldx, T* __restrict__ y,
+                                                       int64_t ldy, int64_t p) {
+  __shared__ T sm[4][PB][64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t j = (int64_t)blockIdx.x * 64 + lane;
+  const int64_t b0 = (int64_t)blockIdx.y * PB;
+  T acc[PB];
+#pragma unroll
+  for (int q = 0; q < PB; ++q) acc[q] = T(0);
+  if (j < n) {
+    for (int64_t i = wid; i < n; i += 4) {
+      const T a = A[i * lda + j];
+#pragma unroll
+      for (int q = 0; q < PB; ++q)
+        if (b0 + q < p) acc[q] += a * x[(b0 + q) * ldx + i];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < PB; ++q) sm[wid][q][lane] = acc[q];
+  __syncthreads();
+  if (wid == 0 && j < n) {
+#pragma unroll
+    for (int q = 0; q < PB; ++q)
+      if (b0 + q < p) y[(b0 + q) * ldy + j] = sm[0][q][lane] + sm[1][q][lane] + sm[2][q][lane] + sm[3][q][lane];
+  }
+}
+
+// dA[i][j] += sum_bt L[bt][i] R[bt][j]
+template <typename T>
+__global__ __launch_bounds__(256) void k_dense_grad(const T* __restrict__ L, int64_t ldl, const T* __restrict__ R,
+                                                    int64_t ldr, int64_t batch, int64_t n, T* __restrict__ dA) {
+  const int tj = threadIdx.x & 15, ti = threadIdx.x >> 4;
+  const int64_t i = (int64_t)blockIdx.y * 16 + ti, j = (int64_t)blockIdx.x * 16 + tj;
+  if (i >= n || j >= n) return;
+  double acc = 0.0;
+  for (int64_t bt = 0; bt < batch; ++bt) acc += (double)L[bt * ldl + i] * (double)R[bt * ldr + j];
+  dA[i * n + j] += (T)acc;
+}
+
+// ================================================================================================
+// CSR   (experiments/benchmarks/.../suite_sparse/benchmark.py:64-68, exp_util.py:35-42)
+// ================================================================================================
+// 8 lanes per row; `perm` (optional) maps a stored position to its slot in val (transpose structure)
+template <typename T>
+__global__ __launch_bounds__(256) void k_csr_apply(const int32_t* __restrict__ crow, const int32_t* __restrict__ col,
+                                                   const int32_t* __restrict__ perm, const T* __restrict__ val,
+                                                   int64_t n, const T* __restrict__ x, int64_t ldx,
+                                                   T* __restrict__ y, int64_t ldy) {
+  const int sub = threadIdx.x & 7;
+  const int64_t row = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+  const int64_t b = blockIdx.y;
+  T acc = T(0);
+  if (row < n) {
+    const T* xb = x + b * ldx;
+    for (int32_t e = crow[row] + sub; e < crow[row + 1]; e += 8) {
+      const T v = perm ? val[perm[e]] : val[e];
+      acc += v * xb[col[e]];
+    }
+  }
+  acc += __shfl_down(acc, 4, 8);
+  acc += __shfl_down(acc, 2, 8);
+  acc += __shfl_down(acc, 1, 8);
+  if (row < n && sub == 0) y[b * ldy + row] = acc;
+}
+
+// dval[e] += sum_bt L[bt][row_e] R[bt][col_e]   (SDDMM on the sparsity pattern)
+template <typename T>
+__global__ __launch_bounds__(256) void k_csr_grad(const int32_t* __restrict__ row, const int32_t* __restrict__ col,
+                                                  int64_t nnz, const T* __restrict__ L, int64_t ldl,
+                                                  const T* __restrict__ R, int64_t ldr, int64_t batch,
+                                                  T* __restrict__ dval) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= nnz) return;
+  const int64_t r = row[e], c = col[e];
+  double acc = 0.0;
+  for (int64_t bt = 0; bt < batch; ++bt) acc += (double)L[bt * ldl + r] * (double)R[bt * ldr + c];
+  dval[e] += (T)acc;
+}
+
+// ================================================================================================
+// RBF Gram  K_ij = s exp(-max(0, |x_i/l|^2 + |x_j/l|^2 - 2 (x_i/l).(x_j/l)) / 2) + noise delta_ij
+//   (util/gp_util.py:160-176 kernel, :225-226 noise inside the lazy kernel, :525-549 gram matvec)
+// ================================================================================================
+__device__ __forceinline__ float exp_neg_half(float d) { return __expf(-0.5f * d); }
+__device__ __forceinline__ double exp_neg_half(double d) { return exp(-0.5 * d); }
+
+// xs[i][c] = X[i][c] / l_c (zero padded to DPAD), sq[i] = |xs_i|^2
+template <typename T>
+__global__ void k_rbf_prep(const T* __restrict__ X, int64_t n, int d, int dpad, const T* __restrict__ ls, int ard,
+                           T* __restrict__ xs, T* __restrict__ sq) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  T s = T(0);
+  for (int c = 0; c < dpad; ++c) {
+    T v = T(0);
+    if (c < d) v = X[i * d + c] / ls[ard ? c : 0];
+    xs[i * dpad + c] = v;
+    s += v * v;
+  }
+  sq[i] = s;
+}
+
+constexpr int kRbfTJ = 128;
+
+template <typename T, int DPAD, int PB>
+__global__ __launch_bounds__(256) void k_rbf_apply(const T* __restrict__ xs, const T* __restrict__ sq, int64_t n,
+                                                   const T* __restrict__ outputscale, const T* __restrict__ noise,
+                                                   const T* __restrict__ x, int64_t ldx, T* __restrict__ y,
+                                                   int64_t ldy, int64_t p) {
+  __shared__ __attribute__((aligned(16))) T xj[kRbfTJ][DPAD];
+  __shared__ T sqj[kRbfTJ];
+  __shared__ T vj[PB][kRbfTJ];
+  const int tid = threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * 256 + tid;
+  const int64_t b0 = (int64_t)blockIdx.y * PB;
+  const int64_t ic = i < n ? i : n - 1;
+  T xi[DPAD];
+#pragma unroll
+  for (int c = 0; c < DPAD; ++c) xi[c] = xs[ic * DPAD + c];
+  const T sqi = sq[ic];
+  T acc[PB];
+#pragma unroll
+  for (int q = 0; q < PB; ++q) acc[q] = T(0);
+  for (int64_t j0 = 0; j0 < n; j0 += kRbfTJ) {
+    for (int t = tid; t < kRbfTJ * DPAD; t += 256) {
+      const int64_t g = j0 * DPAD + t;
+      (&xj[0][0])[t] = g < n * DPAD ? xs[g] : T(0);
+    }
+    if (tid < kRbfTJ) sqj[tid] = (j0 + tid < n) ? sq[j0 + tid] : T(0);
+    for (int t = tid; t < PB * kRbfTJ; t += 256) {
+      const int q = t / kRbfTJ, jj = t % kRbfTJ;
+      vj[q][jj] = (b0 + q < p && j0 + jj < n) ? x[(b0 + q) * ldx + j0 + jj] : T(0);
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int jj = 0; jj < kRbfTJ; ++jj) {
+      T dot = T(0);
+#pragma unroll
+      for (int c = 0; c < DPAD; ++c) dot += xi[c] * xj[jj][c];
+      T dist = sqi + sqj[jj] - T(2) * dot;
+      dist = dist > T(0) ? dist : T(0);
+      const T kv = exp_neg_half(dist);
+#pragma unroll
+      for (int q = 0; q < PB; ++q) acc[q] += kv * vj[q][jj];
+    }
+    __syncthreads();
+  }
+  if (i < n) {
+    const T s = outputscale[0], nz = noise[0];
+#pragma unroll
+    for (int q = 0; q < PB; ++q)
+      if (b0 + q < p) y[(b0 + q) * ldy + i] = s * acc[q] + nz * x[(b0 + q) * ldx + i];
+  }
+}
+
+// Parameter-gradient sweep (generic VALU path): workgroup = 256 rows i, walks all j in tiles of 16,
+// S_ij = sum_bt L[bt][i] R[bt][j] accumulated in registers, then W = S o K and the per-parameter
+// reductions.  Per-workgroup partials (double) -> k_rbf_grad_final (deterministic).
+constexpr int kGradTJ = 16;
+constexpr int kGradBC = 32;
+
+template <typename T, int DPAD>
+__global__ __launch_bounds__(256) void k_rbf_grad(const T* __restrict__ xs, const T* __restrict__ sq, int64_t n,
+                                                  int ard, const T* __restrict__ L, int64_t ldl,
+                                                  const T* __restrict__ R, int64_t ldr, int64_t batch,
+                                                  double* __restrict__ partial /* (nblocks, DPAD + 2) */) {
+  __shared__ __attribute__((aligned(16))) T xj[kGradTJ][DPAD];
+  __shared__ T sqj[kGradTJ];
+  __shared__ T rj[kGradBC][kGradTJ];
+  __shared__ double red[4][DPAD + 2];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 256 + tid;
+  const bool live = i < n;
+  const int64_t ic = live ? i : n - 1;
+  T xi[DPAD];
+#pragma unroll
+  for (int c = 0; c < DPAD; ++c) xi[c] = xs[ic * DPAD + c];
+  const T sqi = sq[ic];
+  double g[DPAD + 2];  // [0..DPAD): lengthscale dims (ARD) or [0] scalar; [DPAD]: outputscale; [DPAD+1]: noise
+#pragma unroll
+  for (int c = 0; c < DPAD + 2; ++c) g[c] = 0.0;
+  for (int64_t j0 = 0; j0 < n; j0 += kGradTJ) {
+    T S[kGradTJ];
+#pragma unroll
+    for (int jj = 0; jj < kGradTJ; ++jj) S[jj] = T(0);
+    for (int64_t bt0 = 0; bt0 < batch; bt0 += kGradBC) {
+      __syncthreads();
+      for (int t = tid; t < kGradBC * kGradTJ; t += 256) {
+        const int q = t / kGradTJ, jj = t % kGradTJ;
+        rj[q][jj] = (bt0 + q < batch && j0 + jj < n) ? R[(bt0 + q) * ldr + j0 + jj] : T(0);
+      }
+      __syncthreads();
+      const int qmax = (int)((batch - bt0) < kGradBC ? (batch - bt0) : kGradBC);
+      for (int q = 0; q < qmax; ++q) {
+        const T l = live ? L[(bt0 + q) * ldl + i] : T(0);
+#pragma unroll
+        for (int jj = 0; jj < kGradTJ; ++jj) S[jj] += l * rj[q][jj];
+      }
+    }
+    __syncthreads();
+    for (int t = tid; t < kGradTJ * DPAD; t += 256) {
+      const int64_t gi = j0 * DPAD + t;
+      (&xj[0][0])[t] = gi < n * DPAD ? xs[gi] : T(0);
+    }
+    if (tid < kGradTJ) sqj[tid] = (j0 + tid < n) ? sq[j0 + tid] : T(0);
+    __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < kGradTJ; ++jj) {
+      if (j0 + jj >= n) continue;
+      T dot = T(0);
+#pragma unroll
+      for (int c = 0; c < DPAD; ++c) dot += xi[c] * xj[jj][c];
+      T dist = sqi + sqj[jj] - T(2) * dot;
+      dist = dist > T(0) ? dist : T(0);
+      const T w = S[jj] * exp_neg_half(dist);
+      g[DPAD] += (double)w;
+      if (ard) {
+#pragma unroll
+        for (int c = 0; c < DPAD; ++c) {
+          const T df = xi[c] - xj[jj][c];
+          g[c] += (double)(w * df * df);
+        }
+      } else {
+        g[0] += (double)(w * dist);
+      }
+      if (j0 + jj == i) g[DPAD + 1] += (double)S[jj];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < DPAD + 2; ++c) {
+    const double v = wave_sum(live ? g[c] : 0.0);
+    if (lane == 0) red[wid][c] = v;
+  }
+  __syncthreads();
+  if (tid < DPAD + 2) partial[(int64_t)blockIdx.x * (DPAD + 2) + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
+// grads += factors * sum_blocks partial  (chain to the constrained parameters l, s, noise)
+template <typename T>
+__global__ void k_rbf_grad_final(const double* __restrict__ partial, int64_t nblocks, int dpad, int d, int ard,
+                                 const T* __restrict__ ls, const T* __restrict__ outputscale, T* __restrict__ g_ls,
+                                 T* __restrict__ g_s, T* __restrict__ g_noise) {
+  const int c = threadIdx.x;
+  if (c >= dpad + 2) return;
+  double acc = 0.0;
+  for (int64_t q = 0; q < nblocks; ++q) acc += partial[q * (dpad + 2) + c];
+  const double s = (double)outputscale[0];
+  if (c < dpad) {
+    if (ard ? (c < d) : (c == 0)) {
+      if (g_ls) g_ls[c] += (T)(s * acc / (double)ls[ard ? c : 0]);
+    }
+  } else if (c == dpad) {
+    if (g_s) g_s[0] += (T)acc;
+  } else {
+    if (g_noise) g_noise[0] += (T)acc;
+  }
+}
+
+static int rbf_dpad(int d) { return d <= 4 ? 4 : d <= 8 ? 8 : d <= 12 ? 12 : d <= 16 ? 16 : d <= 32 ? 32 : -1; }
+
+struct RbfWs {
+  void *xs, *sq;
+  double* partial;
+};
+
+static int64_t rbf_carve(const mfx_operator* op, void* ws, int64_t ws_bytes, RbfWs* out) {
+  const size_t es = dtype_size(op->dtype);
+  const int dpad = rbf_dpad(op->d);
+  Carver cv(ws, ws_bytes);
+  RbfWs r;
+  r.xs = cv.take(op->n * (dpad > 0 ? dpad : 1) * es);
+  r.sq = cv.take(op->n * es);
+  r.partial = static_cast<double*>(cv.take(((op->n + 255) / 256) * 64 * sizeof(double)));
+  if (out) *out = r;
+  return cv.off;
+}
+
+// MFMA path (mfx_rbf_mfma.hip)
+bool rbf_mfma_supported(const mfx_operator* op, int64_t p);
+int rbf_mfma_apply(const mfx_operator* op, const float* xs, const float* sq, int dpad, const float* x, int64_t ldx,
+                   float* y, int64_t ldy, int64_t p, hipStream_t stream);
+bool rbf_mfma_grad_supported(const mfx_operator* op, int64_t batch);
+int rbf_mfma_grad(const mfx_operator* op, const float* xs, const float* sq, int dpad, const float* L, int64_t ldl,
+                  const float* R, int64_t ldr, int64_t batch, double* partial, int64_t* nblocks_out,
+                  hipStream_t stream);
+
+template <typename T>
+static int rbf_prep(const mfx_operator* op, const RbfWs& w, int dpad, hipStream_t stream) {
+  k_rbf_prep<T><<<(unsigned)((op->n + 255) / 256), 256, 0, stream>>>(
+      (const T*)op->x, op->n, op->d, dpad, (const T*)op->lengthscale, op->ard, (T*)w.xs, (T*)w.sq);
+  MFX_CHECK_LAUNCH();
+  return MFX_OK;
+}
+
+template <typename T, int DPAD>
+static int rbf_apply_d(const mfx_operator* op, const RbfWs& w, const T* x, int64_t ldx, T* y, int64_t ldy, int64_t p,
+                       hipStream_t stream) {
+  const unsigned gx = (unsigned)((op->n + 255) / 256);
+#define MFX_RBF_LAUNCH(PB)                                                                           \
+  k_rbf_apply<T, DPAD, PB><<<dim3(gx, (unsigned)((p + PB - 1) / PB)), 256, 0, stream>>>(               \
+      (const T*)w.xs, (const T*)w.sq, op->n, (const T*)op->outputscale, (const T*)op->noise, x, ldx, y, ldy, p)
+  if (p == 1) {
+    MFX_RBF_LAUNCH(1);
+  } else if (p == 2) {
+    MFX_RBF_LAUNCH(2);
+  } else if (p <= 4) {
+    MFX_RBF_LAUNCH(4);
+  } else {
+    MFX_RBF_LAUNCH(8);
+  }
+#undef MFX_RBF_LAUNCH
+  MFX_CHECK_LAUNCH();
+  return MFX_OK;
+}
+
+template <typename T>
+static int rbf_apply(const mfx_operator* op, const T* x, int64_t ldx, T* y, int64_t ldy, int64_t p, void* ws,
+                     int64_t ws_bytes, hipStream_t stream) {
+  const int dpad = rbf_dpad(op->d);
+  MFX_REQUIRE(dpad > 0, MFX_ERR_UNSUPPORTED, "RBF operator supports d <= 32 (got %d)", op->d);
+  RbfWs w;
+  MFX_REQUIRE(rbf_carve(op, ws, ws_bytes, &w) <= ws_bytes && ws, MFX_ERR_WORKSPACE, "RBF workspace too small");
+  MFX_TRY(rbf_prep<T>(op, w, dpad, stream));
+  if constexpr (sizeof(T) == 4) {
+    if (rbf_mfma_supported(op, p))
+      return rbf_mfma_apply(op, (const float*)w.xs, (const float*)w.sq, dpad, x, ldx, y, ldy, p, stream);
+  }
+  switch (dpad) {
+    case 4: return rbf_apply_d<T, 4>(op, w, x, ldx, y, ldy, p, stream);
+    case 8: return rbf_apply_d<T, 8>(op, w, x, ldx, y, ldy, p, stream);
+    case 12: return rbf_apply_d<T, 12>(op, w, x, ldx, y, ldy, p, stream);
+    case 16: return rbf_apply_d<T, 16>(op, w, x, ldx, y, ldy, p, stream);
+    default: return rbf_apply_d<T, 32>(op, w, x, ldx, y, ldy, p, stream);
+  }
+}
+
+template <typename T>
+static int rbf_grad(const mfx_operator* op, const T* L, int64_t ldl, const T* R, int64_t ldr, int64_t batch,
+                    const mfx_op_grads* grads, void* ws, int64_t ws_bytes, hipStream_t stream) {
+  const int dpad = rbf_dpad(op->d);
+  MFX_REQUIRE(dpad > 0, MFX_ERR_UNSUPPORTED, "RBF operator supports d <= 32 (got %d)", op->d);
+  RbfWs w;
+  MFX_REQUIRE(rbf_carve(op, ws, ws_bytes, &w) <= ws_bytes && ws, MFX_ERR_WORKSPACE, "RBF workspace too small");
+  MFX_TRY(rbf_prep<T>(op, w, dpad, stream));
+  int64_t nblocks = (op->n + 255) / 256;
+  bool done = false;
+  if constexpr (sizeof(T) == 4) {
+    if (rbf_mfma_grad_supported(op, batch)) {
+      MFX_TRY(rbf_mfma_grad(op, (const float*)w.xs, (const float*)w.sq, dpad, L, ldl, R, ldr, batch, w.partial,
+                            &nblocks, stream));
+      done = true;
+    }
+  }
+  if (!done) {
+#define MFX_RBF_GRAD(D)                                                                                    \
+  k_rbf_grad<T, D><<<(unsigned)nblocks, 256, 0, stream>>>((const T*)w.xs, (const T*)w.sq, op->n, op->ard, L, ldl, R, \
+                                                           ldr, batch, w.partial)
+    switch (dpad) {
+      case 4: MFX_RBF_GRAD(4); break;
+      case 8: MFX_RBF_GRAD(8); break;
+      case 12: MFX_RBF_GRAD(12); break;
+      case 16: MFX_RBF_GRAD(16); break;
+      default: MFX_RBF_GRAD(32); break;
+    }
+#undef MFX_RBF_GRAD
+    MFX_CHECK_LAUNCH();
+  }
+  k_rbf_grad_final<T><<<1, 64, 0, stream>>>(w.partial, nblocks, dpad, op->d, op->ard, (const T*)op->lengthscale,
+                                            (const T*)op->outputscale, (T*)grads->lengthscale,
+                                            (T*)grads->outputscale, (T*)grads->noise);
+  MFX_CHECK_LAUNCH();
+  return MFX_OK;
+}
+
+// ================================================================================================
+// dispatch
+// ================================================================================================
+int64_t op_workspace_bytes(const mfx_operator* op, int64_t /*p*/) {
+  if (op->kind == MFX_OP_RBF) return rbf_carve(op, nullptr, 0, nullptr);
+  return 256;
+}
+
+template <typename T>
+static int op_apply_t(const mfx_operator* op, const T* x, int64_t ldx, T* y, int64_t ldy, int64_t p, int transpose,
+                      void* ws, int64_t ws_bytes, hipStream_t stream) {
+  const int64_t n = op->n;
+  switch (op->kind) {
+    case MFX_OP_DENSE: {
+      MFX_REQUIRE(op->dense_a, MFX_ERR_INVALID, "dense operator without matrix");
+      constexpr int PB = 4;
+      if (!transpose) {
+        k_dense_apply<T, PB><<<dim3((unsigned)((n + 3) / 4), (unsigned)((p + PB - 1) / PB)), 256, 0, stream>>>(
+            (const T*)op->dense_a, op->lda, n, x, ldx, y, ldy, p);
+      } else {
+        k_dense_apply_t<T, PB><<<dim3((unsigned)((n + 63) / 64), (unsigned)((p + PB - 1) / PB)), 256, 0, stream>>>(
+            (const T*)op->dense_a, op->lda, n, x, ldx, y, ldy, p);
+      }
+      MFX_CHECK_LAUNCH();
+      return MFX_OK;
+    }
+    case MFX_OP_CSR: {
+      MFX_REQUIRE(op->crow && op->col && op->val, MFX_ERR_INVALID, "CSR operator without structure");
+      const dim3 grid((unsigned)((n + 31) / 32), (unsigned)p);
+      if (!transpose) {
+        k_csr_apply<T><<<grid, 256, 0, stream>>>(op->crow, op->col, nullptr, (const T*)op->val, n, x, ldx, y, ldy);
+      } else {
+        MFX_REQUIRE(op->t_crow && op->t_col && op->t_perm, MFX_ERR_INVALID,
+                    "CSR transpose structure required for the Arnoldi adjoint");
+        k_csr_apply<T><<<grid, 256, 0, stream>>>(op->t_crow, op->t_col, op->t_perm, (const T*)op->val, n, x, ldx, y, ldy);
+      }
+      MFX_CHECK_LAUNCH();
+      return MFX_OK;
+    }
+    case MFX_OP_RBF:
+      MFX_REQUIRE(op->x && op->lengthscale && op->outputscale && op->noise, MFX_ERR_INVALID,
+                  "RBF operator with null pointers");
+      return rbf_apply<T>(op, x, ldx, y, ldy, p, ws, ws_bytes, stream);  // symmetric: transpose ignored
+    default:
+      set_error("unknown operator kind %d", op->kind);
+      return MFX_ERR_UNSUPPORTED;
+  }
+}
+
+int op_apply(const mfx_operator* op, const void* x, int64_t ldx, void* y, int64_t ldy, int64_t p, int transpose,
+             void* ws, int64_t ws_bytes, hipStream_t stream) {
+  MFX_REQUIRE(p <= 65535, MFX_ERR_UNSUPPORTED, "p too large");
+  if (op->dtype == MFX_F32) return op_apply_t<float>(op, (const float*)x, ldx, (float*)y, ldy, p, transpose, ws, ws_bytes, stream);
+  if (op->dtype == MFX_F64) return op_apply_t<double>(op, (const double*)x, ldx, (double*)y, ldy, p, transpose, ws, ws_bytes, stream);
+  set_error("unsupported dtype %d", op->dtype);
+  return MFX_ERR_UNSUPPORTED;
+}
+
+int op_apply_cb(const mfx_operator* op, int mode, const void* x, int64_t ldx, const void* aux, int64_t ldaux, void* y,
+                int64_t ldy, int64_t p, hipStream_t stream) {
+  MFX_REQUIRE(op->callback, MFX_ERR_INVALID, "callback operator without function pointer");
+  const int rc = op->callback(op->ctx, mode, x, ldx, aux, ldaux, y, ldy, p, op->n, stream);
+  MFX_REQUIRE(rc == 0, MFX_ERR_CALLBACK, "operator callback failed with code %d", rc);
+  return MFX_OK;
+}
+
+template <typename T>
+static int op_vjp_params_t(const mfx_operator* op, const T* L, int64_t ldl, const T* R, int64_t ldr, int64_t batch,
+                           const mfx_op_grads* grads, void* ws, int64_t ws_bytes, hipStream_t stream) {
+  const int64_t n = op->n;
+  switch (op->kind) {
+    case MFX_OP_DENSE:
+      if (!grads->dense_a) return MFX_OK;
+      k_dense_grad<T><<<dim3((unsigned)((n + 15) / 16), (unsigned)((n + 15) / 16)), 256, 0, stream>>>(
+          L, ldl, R, ldr, batch, n, (T*)grads->dense_a);
+      MFX_CHECK_LAUNCH();
+      return MFX_OK;
+    case MFX_OP_CSR:
+      if (!grads->val) return MFX_OK;
+      MFX_REQUIRE(op->row && op->col, MFX_ERR_INVALID, "CSR gradient needs the COO row index");
+      k_csr_grad<T><<<(unsigned)((op->nnz + 255) / 256), 256, 0, stream>>>(op->row, op->col, op->nnz, L, ldl, R, ldr,
+                                                                         batch, (T*)grads->val);
+      MFX_CHECK_LAUNCH();
+      return MFX_OK;
+    case MFX_OP_RBF:
+      if (!grads->lengthscale && !grads->outputscale && !grads->noise) return MFX_OK;
+      return rbf_grad<T>(op, L, ldl, R, ldr, batch, grads, ws, ws_bytes, stream);
+    default:
+      set_error("unknown operator kind %d", op->kind);
+      return MFX_ERR_UNSUPPORTED;
+  }
+}
+
+int op_vjp_params(const mfx_operator* op, const void* L, int64_t ldl, const void* R, int64_t ldr, int64_t batch,
+                  const mfx_op_grads* grads, void* ws, int64_t ws_bytes, hipStream_t stream) {
+  if (op->dtype == MFX_F32)
+    return op_vjp_params_t<float>(op, (const float*)L, ldl, (const float*)R, ldr, batch, grads, ws, ws_bytes, stream);
+  if (op->dtype == MFX_F64)
+    return op_vjp_params_t<double>(op, (const double*)L, ldl, (const double*)R, ldr, batch, grads, ws, ws_bytes, stream);
+  set_error("unsupported dtype %d", op->dtype);
+  return MFX_ERR_UNSUPPORTED;
+}
+
+}  // namespace mfx

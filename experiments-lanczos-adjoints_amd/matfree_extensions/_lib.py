@@ -1,0 +1,198 @@
+"""ctypes binding of libmfx.so (the C-ABI declared in include/mfx.h).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every hot-path operation goes
+through the hand-written HIP kernels behind ``mfx_*``.  There is deliberately NO CPU or eager
+fallback: if the library is missing, or a tensor is not on a ROCm device, calls raise.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmfx.so")
+
+MFX_F32, MFX_F64 = 0, 1
+OP_DENSE, OP_CSR, OP_RBF, OP_CALLBACK = 0, 1, 2, 3
+REORTHO_NONE, REORTHO_FULL = 0, 1
+
+CALLBACK_T = C.CFUNCTYPE(
+    C.c_int,  # return
+    C.c_void_p,  # ctx
+    C.c_int,  # mode
+    C.c_void_p,  # x
+    C.c_int64,  # ldx
+    C.c_void_p,  # aux
+    C.c_int64,  # ldaux
+    C.c_void_p,  # y
+    C.c_int64,  # ldy
+    C.c_int64,  # p
+    C.c_int64,  # n
+    C.c_void_p,  # stream
+)
+
+
+class Operator(C.Structure):
+    """mirror of ``struct mfx_operator`` (include/mfx.h)."""
+
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("dtype", C.c_int32),
+        ("n", C.c_int64),
+        ("dense_a", C.c_void_p),
+        ("lda", C.c_int64),
+        ("crow", C.c_void_p),
+        ("col", C.c_void_p),
+        ("row", C.c_void_p),
+        ("val", C.c_void_p),
+        ("nnz", C.c_int64),
+        ("t_crow", C.c_void_p),
+        ("t_col", C.c_void_p),
+        ("t_perm", C.c_void_p),
+        ("x", C.c_void_p),
+        ("d", C.c_int32),
+        ("ard", C.c_int32),
+        ("lengthscale", C.c_void_p),
+        ("outputscale", C.c_void_p),
+        ("noise", C.c_void_p),
+        ("callback", CALLBACK_T),
+        ("ctx", C.c_void_p),
+    ]
+
+
+class OpGrads(C.Structure):
+    """mirror of ``struct mfx_op_grads``."""
+
+    _fields_ = [
+        ("dense_a", C.c_void_p),
+        ("val", C.c_void_p),
+        ("lengthscale", C.c_void_p),
+        ("outputscale", C.c_void_p),
+        ("noise", C.c_void_p),
+    ]
+
+
+# every symbol include/mfx.h declares: (name, restype, argtypes)
+_P, _I64, _I = C.c_void_p, C.c_int64, C.c_int
+_OPP, _GRP = C.POINTER(Operator), C.POINTER(OpGrads)
+SYMBOLS = {
+    "mfx_last_error": (C.c_char_p, []),
+    "mfx_version": (_I, []),
+    "mfx_workspace_bytes": (_I64, [_OPP, _I64, _I64, _I64]),
+    "mfx_op_apply": (_I, [_OPP, _P, _I64, _P, _I64, _I64, _I, _P, _I64, _P]),
+    "mfx_op_vjp_params": (_I, [_OPP, _P, _I64, _P, _I64, _I64, _GRP, _P, _I64, _P]),
+    "mfx_arnoldi_forward": (_I, [_OPP, _P, _I64, _I64, _I64, _I, _P, _P, _P, _P, _P, _I64, _P]),
+    "mfx_arnoldi_adjoint": (
+        _I,
+        [_OPP, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _GRP, _P, _I64, _P],
+    ),
+    "mfx_lanczos_forward": (_I, [_OPP, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _I64, _P]),
+    "mfx_lanczos_adjoint": (
+        _I,
+        [_OPP, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _GRP, _P, _I64, _P],
+    ),
+    "mfx_tridiag_eigh": (_I, [_P, _P, _I64, _I64, _I64, _I, _P, _P, _P]),
+    "mfx_slq_quadform_bwd": (_I, [_P, _P, _P, _P, _P, _I64, _I64, _I, _P, _P, _I64, _P]),
+    "mfx_rademacher": (_I, [C.c_uint64, _I64, _I64, _I64, _I, _P, _P]),
+    "mfx_timing_enable": (_I, [_I]),
+    "mfx_timing_reset": (_I, []),
+    "mfx_timing_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class MfxError(RuntimeError):
+    pass
+
+
+def get():
+    """Load libmfx.so once; raise loudly when it is absent (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise MfxError(
+                    f"libmfx.so not found at {LIB_PATH}: build it with "
+                    "`python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(or `make -C experiments-lanczos-adjoints_amd/csrc`). There is no CPU fallback."
+                )
+            lib = C.CDLL(LIB_PATH)
+            for name, (res, args) in SYMBOLS.items():
+                fn = getattr(lib, name)  # AttributeError if the library does not export it
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def check(rc: int):
+    if rc != 0:
+        msg = get().mfx_last_error().decode()
+        if rc == -1:
+            raise ValueError(msg)  # MFX_ERR_INVALID mirrors the reference's ValueError conventions
+        raise MfxError(f"libmfx error {rc}: {msg}")
+
+
+def dtype_code(dtype: torch.dtype) -> int:
+    if dtype == torch.float32:
+        return MFX_F32
+    if dtype == torch.float64:
+        return MFX_F64
+    raise TypeError(f"libmfx supports float32/float64 (got {dtype}); complex Arnoldi is out of scope")
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise MfxError(
+                "matfree_extensions (MI355X build): tensors must live on a ROCm device "
+                f"(got device={t.device}); there is no CPU fallback path."
+            )
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+_ws_cache = {}
+
+
+def workspace(desc: Operator, n: int, k: int, p: int, device) -> torch.Tensor:
+    """Caller-owned scratch, cached per (device, size bucket) so repeated calls do not re-allocate."""
+    need = int(get().mfx_workspace_bytes(C.byref(desc), n, k, p))
+    if need < 0:
+        raise MfxError("mfx_workspace_bytes failed")
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(int(need * 1.0) + 256, dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def timing_enable(flag: bool):
+    check(get().mfx_timing_enable(int(flag)))
+
+
+def timing_reset():
+    check(get().mfx_timing_reset())
+
+
+def timing_read(cls: int):
+    tot, cnt = C.c_double(0.0), C.c_int64(0)
+    check(get().mfx_timing_read(cls, C.byref(tot), C.byref(cnt)))
+    return tot.value, cnt.value

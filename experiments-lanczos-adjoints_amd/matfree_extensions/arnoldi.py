@@ -1,0 +1,145 @@
+"""Arnoldi (Hessenberg) factorisation with its custom adjoint -- MI355X build.
+
+Same functional surface as the reference's ``matfree_extensions/arnoldi.py``:
+
+    hessenberg(matvec, krylov_depth, /, *, reortho, custom_vjp=True, reortho_vjp="match")
+        -> estimate(v, *params) -> (Q (n, k), H (k, k), r (n,), c ())
+
+but on ``torch`` tensors that live on a ROCm device, with the forward loop (arnoldi.py:57-101) and the
+adjoint scan (arnoldi.py:104-220) executed by libmfx's HIP kernels (``mfx_arnoldi_forward`` /
+``mfx_arnoldi_adjoint``).  ``v`` may also be a batch (p, n): outputs gain a leading probe axis (this
+replaces ``jax.vmap`` over probes, hutchinson.py:14).
+
+Differences from the reference, all deliberate:
+  * parameters must be explicit tensors (no closure conversion, arnoldi.py:22): pass a native
+    operator (``operators.DenseOp`` ...) or any callable ``matvec(v, *params)``;
+  * real float32/float64 only (complex Arnoldi forward, test_hessenberg_forward.py, is out of scope);
+  * ``custom_vjp=False`` returns non-differentiable outputs (there is no autodiff through HIP loops).
+Reference quirk Q1 is reproduced: the forward pass re-orthogonalises unless ``reortho_vjp="none"``
+(arnoldi.py:26,91), whatever ``reortho`` says; ``reortho`` only selects the adjoint's re-projection.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .operators import CallbackOp, _PtrRegistry, as_operator
+
+
+def hessenberg(
+    matvec,
+    krylov_depth,
+    /,
+    *,
+    reortho: str,
+    custom_vjp: bool = True,
+    reortho_vjp: str = "match",
+):
+    reortho_expected = ["none", "full"]
+    if reortho not in reortho_expected or not isinstance(reortho, str):
+        msg = f"Unexpected input for {reortho}: either of {reortho_expected} expected."
+        raise TypeError(msg)
+    op, bound = as_operator(matvec)
+
+    def estimate(v, *params):
+        if bound is not None:
+            params = tuple(bound) + tuple(params)
+        batched = v.dim() == 2
+        V = v if batched else v[None]
+        n = V.shape[-1]
+        if krylov_depth < 1 or krylov_depth > n:
+            msg = f"Parameter depth {krylov_depth} is outside the expected range"
+            raise ValueError(msg)
+        # Q1 (arnoldi.py:26): the forward always sees `reortho_vjp`
+        reortho_fwd = reortho_vjp if reortho_vjp != "match" else reortho_vjp
+        second_pass = reortho_fwd != "none"
+        cparams = op.constrain(*params)
+        Qkn, H, r, c = _ArnoldiFn.apply(op, int(krylov_depth), second_pass, reortho, custom_vjp, V, *cparams)
+        Q = Qkn.transpose(-1, -2)  # reference layout (n, k); storage stays (k, n)
+        if not batched:
+            return Q[0], H[0], r[0], c[0]
+        return Q, H, r, c
+
+    return estimate
+
+
+class _ArnoldiFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, op, k, second_pass, reortho_bwd, differentiable, V, *cparams):
+        tensors = [q for q in cparams if torch.is_tensor(q)]
+        _lib.require_device(V, *tensors)
+        lib = _lib.get()
+        V = V.contiguous()
+        p, n = V.shape
+        dt, dev = V.dtype, V.device
+        Q = torch.empty((p, k, n), dtype=dt, device=dev)
+        H = torch.empty((p, k, k), dtype=dt, device=dev)
+        r = torch.empty((p, n), dtype=dt, device=dev)
+        c = torch.empty((p,), dtype=dt, device=dev)
+        keep = None
+        if isinstance(op, CallbackOp):
+            reg = _PtrRegistry()
+            desc, keep, _ = op.make(cparams, dt, n, reg, want_grads=False)
+        else:
+            desc = op.descriptor(cparams, dt, n)
+        ws = _lib.workspace(desc, n, k, p, dev)
+        if keep is not None:
+            for t in (V, Q, r):
+                reg.add(t)
+            reg.add_bytes(ws, dt)
+        rc = lib.mfx_arnoldi_forward(C.byref(desc), _lib.ptr(V), n, k, p, int(second_pass), _lib.ptr(Q),
+                                     _lib.ptr(H), _lib.ptr(r), _lib.ptr(c), _lib.ptr(ws), ws.numel(),
+                                     _lib.stream_ptr(dev))
+        if keep is not None and keep[1]:
+            raise keep[1][0]
+        _lib.check(rc)
+        ctx.op, ctx.k, ctx.reortho, ctx.differentiable = op, k, reortho_bwd, differentiable
+        ctx.nparams = len(cparams)
+        ctx.nontensor = [None if torch.is_tensor(q) else q for q in cparams]
+        ctx.save_for_backward(Q, H, r, c, *tensors)
+        ctx.set_materialize_grads(False)
+        return Q, H, r, c
+
+    @staticmethod
+    def backward(ctx, dQ, dH, dr, dc):
+        if not ctx.differentiable:
+            raise RuntimeError("hessenberg(custom_vjp=False) is not differentiable in the MI355X build; "
+                               "use custom_vjp=True (the adjoint system).")
+        Q, H, r, c, *tensors = ctx.saved_tensors
+        it = iter(tensors)
+        cparams = tuple(next(it) if q is None else q for q in ctx.nontensor)
+        op, k, lib = ctx.op, ctx.k, _lib.get()
+        p, _, n = Q.shape
+        dt, dev = Q.dtype, Q.device
+        dQ = None if dQ is None else dQ.contiguous()
+        dr = None if dr is None else dr.contiguous()
+        dc = None if dc is None else dc.contiguous()
+        dH = torch.zeros_like(H) if dH is None else dH.contiguous()
+        dv = torch.empty((p, n), dtype=dt, device=dev)
+        Lam = torch.empty((p, k, n), dtype=dt, device=dev)
+        keep = None
+        if isinstance(op, CallbackOp):
+            reg = _PtrRegistry()
+            desc, keep, grads = op.make(cparams, dt, n, reg, want_grads=True)
+            gptr = None
+        else:
+            desc = op.descriptor(cparams, dt, n)
+            gstruct, grads = op.new_grads(*cparams)
+            gptr = C.byref(gstruct)
+        ws = _lib.workspace(desc, n, k, p, dev)
+        if keep is not None:
+            for t in (Q, r, Lam, dv, dQ, dr):
+                reg.add(t)
+            reg.add_bytes(ws, dt)
+        rc = lib.mfx_arnoldi_adjoint(C.byref(desc), n, k, p, _lib.ptr(Q), _lib.ptr(H), _lib.ptr(r), _lib.ptr(c),
+                                     _lib.ptr(dQ), _lib.ptr(dH), _lib.ptr(dr), _lib.ptr(dc),
+                                     _lib.REORTHO_FULL if ctx.reortho == "full" else _lib.REORTHO_NONE,
+                                     _lib.ptr(dv), _lib.ptr(Lam), gptr, _lib.ptr(ws), ws.numel(),
+                                     _lib.stream_ptr(dev))
+        if keep is not None and keep[1]:
+            raise keep[1][0]
+        _lib.check(rc)
+        return (None, None, None, None, None, dv, *grads)

@@ -1,0 +1,187 @@
+/*
+ * mfx.h -- C-ABI of the MI355X-native Lanczos/Arnoldi-with-adjoint engine (libmfx.so).
+ *
+ * This is the drop-in boundary for the hot path of pnkraemer/experiments-lanczos-adjoints.  The
+ * reference is pure-Python JAX and has no FFI; the entry points below are what a binding of its
+ * functional API would call, and each one cites the reference function it replaces
+ * (paths relative to /root/reference/src/matfree_extensions).
+ *
+ * Conventions
+ *   - plain pointers + sizes only; all array pointers are DEVICE pointers unless stated otherwise;
+ *   - every buffer is owned by the caller (outputs and workspace are pre-allocated; the library keeps
+ *     no device allocations between calls);
+ *   - every entry point is asynchronous on the given hipStream_t (passed as void*) and re-entrant
+ *     across streams; no host synchronisation inside (except callback operators, see below);
+ *   - return value 0 = ok, <0 = error (MFX_ERR_*); mfx_last_error() gives a thread-local message;
+ *   - batched layout: a batch of p vectors of length n is row-major (p, n); the Krylov basis is
+ *     (p, k, n) -- the layout lanczos.tridiag returns per probe (lanczos.py:165, `Q.T`), batched over
+ *     probes in place of jax.vmap (hutchinson.py:14,53).
+ */
+#ifndef MFX_H
+#define MFX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFX_VERSION 100
+
+enum { MFX_F32 = 0, MFX_F64 = 1 };
+enum { MFX_OP_DENSE = 0, MFX_OP_CSR = 1, MFX_OP_RBF = 2, MFX_OP_CALLBACK = 3 };
+enum { MFX_REORTHO_NONE = 0, MFX_REORTHO_FULL = 1 };
+enum {
+  MFX_OK = 0,
+  MFX_ERR_INVALID = -1,     /* bad argument (shape, null pointer, depth out of range) */
+  MFX_ERR_UNSUPPORTED = -2, /* dtype / operator kind / size not supported by this build */
+  MFX_ERR_HIP = -3,         /* a HIP runtime call failed */
+  MFX_ERR_WORKSPACE = -4,   /* workspace too small */
+  MFX_ERR_CALLBACK = -5     /* a callback operator returned non-zero */
+};
+
+/* Callback operator (generic Python `matvec(v, *params)` of the reference, e.g. lanczos.py:28-33).
+ * x, y are device pointers to p vectors of length n with leading dimensions ldx, ldy (elements).
+ * The callee must enqueue its work on `stream` (or synchronise it itself).
+ *   mode 0: y = A x                                            (arnoldi.py:84, lanczos.py:254)
+ *   mode 1: y = A^T x, and accumulate d/dtheta [x^T A(theta) aux]   (arnoldi.py:207-209; aux = q_idx)
+ *   mode 2: y = A x,   and accumulate d/dtheta [aux^T A(theta) x]   (lanczos.py:328-329; aux = x_j)
+ * Parameter-gradient accumulation lives on the callee's side (it owns theta). */
+typedef int (*mfx_callback_fn)(void* ctx, int mode, const void* x, int64_t ldx, const void* aux,
+                               int64_t ldaux, void* y, int64_t ldy, int64_t p, int64_t n,
+                               void* stream);
+
+/* Operator descriptor: a POD of borrowed pointers, valid for the duration of one call.
+ * Replaces the reference's `matvec(v, *params)` closures:
+ *   DENSE    p @ x                          tests/test_lanczos/test_tridiag_forward.py:18
+ *   CSR      BCOO((vals, idx)) @ x          experiments/benchmarks/.../suite_sparse/benchmark.py:64-68
+ *   RBF      (K(X,X) + noise I) x           util/gp_util.py:160-176,225-226,525-549
+ *   CALLBACK any Python callable                                                              */
+typedef struct mfx_operator {
+  int32_t kind;  /* MFX_OP_* */
+  int32_t dtype; /* MFX_F32 / MFX_F64: element type of vectors, matrix values and X */
+  int64_t n;     /* operator is n x n */
+
+  /* DENSE: row-major (n, n), leading dimension lda */
+  const void* dense_a;
+  int64_t lda;
+
+  /* CSR (int32 indices).  `row` = COO row index per stored value (for the SDDMM gradient).  The
+   * transpose structure (CSR of A^T: t_crow, t_col, and t_perm[e] = position of that value in `val`)
+   * may be NULL for operators that are only applied forward. */
+  const int32_t* crow;
+  const int32_t* col;
+  const int32_t* row;
+  const void* val;
+  int64_t nnz;
+  const int32_t* t_crow;
+  const int32_t* t_col;
+  const int32_t* t_perm;
+
+  /* RBF Gram: X row-major (n, d); constrained hyper-parameters live on the device so that no host
+   * synchronisation is needed: lengthscale (d values if ard else 1), outputscale (1), noise (1). */
+  const void* x;
+  int32_t d;
+  int32_t ard;
+  const void* lengthscale;
+  const void* outputscale;
+  const void* noise;
+
+  /* CALLBACK */
+  mfx_callback_fn callback;
+  void* ctx;
+} mfx_operator;
+
+/* Parameter-gradient outputs (device pointers, ACCUMULATED into, caller zero-fills).  NULL = skip.
+ *   dense_a (n, n) row-major, leading dimension = n;  val (nnz);
+ *   lengthscale (d if ard else 1), outputscale (1), noise (1).
+ * d/dtheta of  sum_b L_b^T A(theta) R_b   (arnoldi.py:207-209, lanczos.py:328-329). */
+typedef struct mfx_op_grads {
+  void* dense_a;
+  void* val;
+  void* lengthscale;
+  void* outputscale;
+  void* noise;
+} mfx_op_grads;
+
+const char* mfx_last_error(void);
+int mfx_version(void);
+
+/* Workspace (bytes) needed by the drivers below for an (n, k, p) problem on this operator. */
+int64_t mfx_workspace_bytes(const mfx_operator* op, int64_t n, int64_t k, int64_t p);
+
+/* y_b = A x_b (transpose = 0) or A^T x_b (transpose = 1) for b < p.
+ * Replaces one call of the user matvec, vmapped over probes (hutchinson.py:14). */
+int mfx_op_apply(const mfx_operator* op, const void* x, int64_t ldx, void* y, int64_t ldy,
+                 int64_t p, int transpose, void* ws, int64_t ws_bytes, void* stream);
+
+/* grads += d/dtheta sum_{b<batch} L_b^T A(theta) R_b, with L_b = L + b*ldl, R_b = R + b*ldr.
+ * Replaces the parameter half of jax.vjp(matvec) (arnoldi.py:207-209, lanczos.py:328-329), deferred
+ * to ONE sweep over all (probe, step) pairs.  Not available for CALLBACK operators. */
+int mfx_op_vjp_params(const mfx_operator* op, const void* L, int64_t ldl, const void* R,
+                      int64_t ldr, int64_t batch, const mfx_op_grads* grads, void* ws,
+                      int64_t ws_bytes, void* stream);
+
+/* arnoldi._forward (arnoldi.py:57-101), batched over p start vectors, live columns only.
+ *   v0 (p, n) -> Q (p, k, n) [= reference Q^T], H (p, k, k) row-major, r (p, n) un-normalised,
+ *   c (p) = 1/|v0|.  second_pass != 0 runs the re-orthogonalisation pass (reference quirk Q1:
+ *   the reference forward always does unless reortho_vjp="none", arnoldi.py:26,91). */
+int mfx_arnoldi_forward(const mfx_operator* op, const void* v0, int64_t n, int64_t k, int64_t p,
+                        int second_pass, void* Q, void* H, void* r, void* c, void* ws,
+                        int64_t ws_bytes, void* stream);
+
+/* arnoldi._adjoint (arnoldi.py:104-220).  Cotangents: dQ (p, k, n) or NULL (= 0), dH (p, k, k),
+ * dr (p, n) or NULL, dc (p) or NULL.  Outputs dv (p, n); parameter gradients accumulated into
+ * `grads` (native operators: one deferred sweep; CALLBACK: inside the callback, per step).
+ * reortho = MFX_REORTHO_FULL re-projects lambda every step (arnoldi.py:200-204).
+ * Lambda (p, k, n) is caller-provided scratch that holds the adjoint states on return. */
+int mfx_arnoldi_adjoint(const mfx_operator* op, int64_t n, int64_t k, int64_t p, const void* Q,
+                        const void* H, const void* r, const void* c, const void* dQ,
+                        const void* dH, const void* dr, const void* dc, int reortho, void* dv,
+                        void* Lambda, const mfx_op_grads* grads, void* ws, int64_t ws_bytes,
+                        void* stream);
+
+/* lanczos._forward (lanczos.py:215-285): three-term recurrence, no re-orthogonalisation.
+ *   v0 (p, n) -> xs (p, k+1, n), alpha (p, k), beta (p, k), vnorm (p) = |v0|. */
+int mfx_lanczos_forward(const mfx_operator* op, const void* v0, int64_t n, int64_t k, int64_t p,
+                        void* xs, void* alpha, void* beta, void* vnorm, void* ws,
+                        int64_t ws_bytes, void* stream);
+
+/* lanczos._adjoint (lanczos.py:288-335).  dxs (p, k+1, n) or NULL, dalpha (p, k), dbeta (p, k).
+ * Outputs dv (p, n); Lambda (p, k, n) scratch (adjoint states).  Applies A (not A^T) as the
+ * reference does (quirk Q4, lanczos.py:328). */
+int mfx_lanczos_adjoint(const mfx_operator* op, int64_t n, int64_t k, int64_t p, const void* xs,
+                        const void* alpha, const void* beta, const void* vnorm, const void* dxs,
+                        const void* dalpha, const void* dbeta, void* dv, void* Lambda,
+                        const mfx_op_grads* grads, void* ws, int64_t ws_bytes, void* stream);
+
+/* jnp.linalg.eigh of the k x k tridiagonal (lanczos.py:48-53), batched: alpha (p, k),
+ * beta (p, k-1 values, leading dimension ldbeta) -> evals (p, k) (unordered), evecs (p, k, k) with
+ * evecs[b][i][a] = component i of eigenvector a.  fp64 arithmetic inside, k <= 120. */
+int mfx_tridiag_eigh(const void* alpha, const void* beta, int64_t ldbeta, int64_t p, int64_t k,
+                     int dtype, void* evals, void* evecs, void* stream);
+
+/* VJP of  value_b = sum_a evecs[b][0][a]^2 f(evals[b][a])  w.r.t. (alpha, beta) -- what autodiff
+ * through eigh + vmap(matfun) + dot yields in lanczos.py:53-59, in divided-difference form.
+ * fvals = f(evals), dfvals = f'(evals) (p, k); gout (p) upstream cotangent. */
+int mfx_slq_quadform_bwd(const void* evals, const void* evecs, const void* fvals,
+                         const void* dfvals, const void* gout, int64_t p, int64_t k, int dtype,
+                         void* dalpha, void* dbeta, int64_t lddbeta, void* stream);
+
+/* +-1 probes (matfree.hutchinson.sampler_rademacher call sites: util/gp_util.py:557,
+ * optim_logml_adjoints_adaptive.py:109).  Counter-based: element (b, i) depends only on
+ * (seed, first_probe + b, i), so probe shards on different GPUs form one global probe matrix. */
+int mfx_rademacher(uint64_t seed, int64_t first_probe, int64_t p, int64_t n, int dtype, void* out,
+                   void* stream);
+
+/* Per-kernel-class device timing with hipEvents recorded on the caller's stream (no host syncs
+ * while enabled; events are read back in mfx_timing_read, which synchronises the events).
+ * classes: 0 = operator apply, 1 = operator parameter-gradient sweep, 2 = Krylov vector kernels. */
+int mfx_timing_enable(int enable);
+int mfx_timing_reset(void);
+int mfx_timing_read(int cls, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFX_H */

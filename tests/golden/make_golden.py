@@ -1,0 +1,148 @@
+"""Generate the committed golden fixtures from the CPU oracle (fp64).
+
+    python tests/golden/make_golden.py
+
+The reference stores no golden vectors for this path and cannot be executed here
+(JAX / matfree absent), so the fixtures are produced by ``oracle/slq_oracle.py`` -- which is pinned
+against the reference's own property tests in tests/test_oracle_pinning.py -- and every fixture is
+re-validated against those identities by tests/test_golden_fixtures.py.  Fixtures are DATA only
+(inputs + expected outputs).  The one external input, SuiteSparse ``1138_bus`` (a data file of the
+reference: data/matrices/1138_bus/1138_bus.mtx, read as util/exp_util.py:35-42 does), is embedded as
+COO triplets because /root/reference does not exist on the GPU box.
+"""
+
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import slq_oracle as orc  # noqa: E402
+
+
+def save(name, **arrays):
+    np.savez_compressed(os.path.join(HERE, name), **arrays)
+    print("wrote", name, {k: np.shape(v) for k, v in arrays.items()})
+
+
+def tridiag_forward():
+    A = orc.symmetric_matrix_from_eigenvalues(np.arange(1.0, 2.0, 1.0 / 12), seed=1)
+    v = np.flip(np.arange(1.0, 13.0)).copy()
+    out = {"A": A, "v": v}
+    for reortho in ("full", "none"):
+        for k in (1, 5, 11, 12):
+            (Q, (d, e)), (q, b) = orc.tridiag(orc.DenseOp(), k, v, A, reortho=reortho)
+            out.update({f"{reortho}_{k}_Q": Q, f"{reortho}_{k}_d": d, f"{reortho}_{k}_e": e,
+                        f"{reortho}_{k}_q": q, f"{reortho}_{k}_b": b})
+    save("tridiag_forward_n12.npz", **out)
+
+
+def arnoldi_adjoint():
+    rng = np.random.default_rng(3)
+    out = {}
+    for tag, n, k, which in (("rand3", 3, 2, "random"), ("rand10", 10, 4, "random"), ("hilbert15", 15, 10, "hilbert")):
+        v = rng.standard_normal(n)
+        if which == "random":
+            A = rng.standard_normal((n, n))
+        else:
+            Hm = np.tril(orc.hilbert(n))
+            P = Hm - 0.5 * np.diag(np.diag(Hm))
+            A = P + P.T
+        out.update({f"{tag}_A": A, f"{tag}_v": v})
+        for reortho in ("full", "none"):
+            if which == "hilbert" and reortho == "none":
+                continue
+            Q, H, r, c = orc.arnoldi_forward(orc.DenseOp(), k, v, A, reortho=reortho)
+            dQ, dH, dr, dc = (rng.standard_normal(np.shape(x)) for x in (Q, H, r, c))
+            dv, (dA,) = orc.arnoldi_adjoint(orc.DenseOp(), (A,), Q=Q, H=H, r=r, c=c, dQ=dQ, dH=dH, dr=dr, dc=dc,
+                                            reortho=reortho)
+            pre = f"{tag}_{reortho}_"
+            out.update({pre + "Q": Q, pre + "H": H, pre + "r": r, pre + "c": c, pre + "dQ": dQ, pre + "dH": dH,
+                        pre + "dr": dr, pre + "dc": dc, pre + "dv": dv, pre + "dA": dA})
+    save("arnoldi_adjoint.npz", **out)
+
+
+def tridiag_adjoint():
+    n, k = 10, 4
+    rng = np.random.default_rng(2)
+    A = orc.symmetric_matrix_from_eigenvalues(rng.uniform(size=n) + 1.0, seed=2)
+    v = rng.standard_normal(n)
+    out = {"A": A, "v": v}
+    for reortho in ("full", "none"):
+        (Q, (d, e)), (q, b) = orc.tridiag(orc.DenseOp(), k, v, A, reortho=reortho)
+        cot = ((rng.standard_normal(Q.shape), (rng.standard_normal(d.shape), rng.standard_normal(e.shape))),
+               (rng.standard_normal(q.shape), rng.standard_normal()))
+        vjp = orc.tridiag_full_vjp if reortho == "full" else orc.tridiag_none_vjp
+        dv, (dA,) = vjp(orc.DenseOp(), k, v, (A,), cot)
+        pre = reortho + "_"
+        out.update({pre + "dQ": cot[0][0], pre + "dd": cot[0][1][0], pre + "de": cot[0][1][1], pre + "dq": cot[1][0],
+                    pre + "db": cot[1][1], pre + "dv": dv, pre + "dA": dA})
+    save("tridiag_adjoint_n10.npz", **out)
+
+
+def slq_dense():
+    n, k = 11, 6
+    A = orc.symmetric_matrix_from_eigenvalues(np.arange(1.0, 1.0 + n), seed=5)
+    v0 = orc.rademacher(2, 1, n)[0]
+    out = {"A": A, "v0": v0}
+    for reortho in ("full", "none"):
+        val, dv0, (dA,) = orc.integrand_spd_value_and_grad(orc.DenseOp(), k, v0, (A,), reortho=reortho)
+        out.update({f"{reortho}_value": val, f"{reortho}_dv0": dv0, f"{reortho}_dA": dA})
+    val, _, _ = orc.integrand_spd_value_and_grad(orc.DenseOp(), n, v0, (A,))
+    out["full_depth_value"] = val
+    # config C1 of BASELINE.json: 512 x 512 SPD (diag + rank 4), 20 steps, 1 probe
+    A1 = orc.spd_diag_plus_lowrank(512, 4, seed=0)
+    p1 = orc.rademacher(1, 1, 512)[0]
+    val1, _, (dA1,) = orc.integrand_spd_value_and_grad(orc.DenseOp(), 20, p1, (A1,))
+    out.update({"c1_value": val1, "c1_dA_diag": np.diag(dA1).copy(), "c1_dA_row0": dA1[0].copy()})
+    save("slq_dense.npz", **out)
+
+
+def slq_rbf():
+    rng = np.random.default_rng(4)
+    n, d, k, p = 96, 3, 8, 4
+    X = rng.standard_normal((n, d))
+    probes = orc.rademacher(5, p, n)
+    out = {"X": X, "probes": probes}
+    for tag, raw_l in (("ard", np.array([0.5, -0.3, 1.2])), ("iso", np.array(0.4))):
+        raw = (raw_l, np.array(0.2), np.array(-1.0))
+        op = orc.RbfGramOp(X, noise_minval=1e-4)
+        val, grads, vals = orc.hutchinson_value_and_grad(op, k, probes, raw)
+        out.update({f"{tag}_raw_l": raw_l, f"{tag}_value": val, f"{tag}_values": vals, f"{tag}_g_l": grads[0],
+                    f"{tag}_g_s": grads[1], f"{tag}_g_n": grads[2]})
+    out.update({"raw_s": np.array(0.2), "raw_n": np.array(-1.0), "noise_minval": np.array(1e-4)})
+    save("slq_rbf_n96.npz", **out)
+
+
+def csr_1138_bus():
+    path = "/root/reference/data/matrices/1138_bus/1138_bus.mtx"
+    import scipy.io
+
+    M = scipy.io.mmread(path)  # symmetric expansion, as util/exp_util.py:36
+    row, col, vals, n = M.row.astype(np.int64), M.col.astype(np.int64), M.data.astype(np.float64), M.shape[0]
+    rng = np.random.default_rng(1)
+    v = rng.standard_normal(n)
+    k = 12
+    op = orc.CooOp(row, col, n)
+    out = {"row": row, "col": col, "vals": vals, "v": v, "k": np.array(k)}
+    for reortho in ("full", "none"):
+        (Q, (d, e)), (q, b) = orc.tridiag(op, k, v, vals, reortho=reortho)
+        cot = ((rng.standard_normal(Q.shape), (rng.standard_normal(d.shape), rng.standard_normal(e.shape))),
+               (rng.standard_normal(q.shape), rng.standard_normal()))
+        vjp = orc.tridiag_full_vjp if reortho == "full" else orc.tridiag_none_vjp
+        dv, (dvals,) = vjp(op, k, v, (vals,), cot)
+        pre = reortho + "_"
+        out.update({pre + "d": d, pre + "e": e, pre + "b": b, pre + "dQ": cot[0][0], pre + "dd": cot[0][1][0],
+                    pre + "de": cot[0][1][1], pre + "dq": cot[1][0], pre + "db": cot[1][1], pre + "dv": dv,
+                    pre + "dvals": dvals})
+    save("csr_1138_bus.npz", **out)
+
+
+if __name__ == "__main__":
+    tridiag_forward()
+    arnoldi_adjoint()
+    tridiag_adjoint()
+    slq_dense()
+    slq_rbf()
+    csr_1138_bus()

@@ -1,0 +1,421 @@
+"""GPU parity: the HIP path (through the C-ABI of libmfx.so) against the CPU oracle and the committed
+golden fixtures.  Tolerances: fp64 build vs fp64 oracle rtol 1e-9 (forward) / 1e-7 (gradients);
+fp32 build vs fp64 oracle value rtol 1e-4, gradients rtol 2e-3 of the gradient's max-norm
+(the reference's own fp32 tolerance is sqrt(eps) ~ 3.5e-4, test_integrand_spd_value_and_grad.py:36-38).
+"""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import slq_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from matfree_extensions import _lib, arnoldi, hutchinson, lanczos
+    from matfree_extensions.operators import CsrOp, DenseOp, RbfGramOp
+    from matfree_extensions.util import gp_util
+
+DEV = torch.device("cuda:0")
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def T(x, dtype=torch.float64, grad=False):
+    t = torch.tensor(np.asarray(x), dtype=dtype, device=DEV)
+    return t.requires_grad_(True) if grad else t
+
+
+def N(t):
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+def close(a, b, rtol, atol_rel=None):
+    a, b = N(a) if torch.is_tensor(a) else np.asarray(a), np.asarray(b)
+    atol = (atol_rel if atol_rel is not None else rtol) * max(np.abs(b).max(), 1e-300)
+    ok = np.allclose(a, b, rtol=rtol, atol=atol)
+    if not ok:
+        print("max abs err", np.abs(a - b).max(), "scale", np.abs(b).max())
+    return ok
+
+
+# ------------------------------------------------------------------------------------------------
+# operators: apply / transpose / parameter sweep
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-12), (torch.float32, 2e-5)])
+@pytest.mark.parametrize("p", [1, 3, 9])
+def test_dense_op(dtype, tol, p):
+    rng = np.random.default_rng(0)
+    n = 77
+    A, V, Cc = rng.standard_normal((n, n)), rng.standard_normal((p, n)), rng.standard_normal((p, n))
+    At, Vt = T(A, dtype, True), T(V, dtype, True)
+    y = DenseOp()(Vt, At)
+    assert close(y, V @ A.T, tol)
+    gV, gA = torch.autograd.grad(y, (Vt, At), T(Cc, dtype))
+    assert close(gV, Cc @ A, tol)
+    assert close(gA, Cc.T @ V, tol)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-12), (torch.float32, 2e-5)])
+def test_csr_op(dtype, tol):
+    r, c, vals, n = orc.laplacian_2d_plus_identity(13)
+    rng = np.random.default_rng(1)
+    vals = vals + 0.1 * rng.standard_normal(vals.shape)  # non-symmetric values: exercises A^T
+    op, v_dev, order = CsrOp.from_coo(r, c, vals, n, DEV)
+    o = orc.CooOp(r, c, n)
+    V, Cc = rng.standard_normal((3, n)), rng.standard_normal((3, n))
+    vt, Vt = v_dev.to(dtype).requires_grad_(True), T(V, dtype, True)
+    y = op(Vt, vt)
+    assert close(y, np.stack([o.apply(v, vals) for v in V]), tol)
+    gV, gvals = torch.autograd.grad(y, (Vt, vt), T(Cc, dtype))
+    assert close(gV, np.stack([o.apply_t(cc, vals) for cc in Cc]), tol)
+    ref = sum(o.param_vjp(v, cc, vals)[0] for v, cc in zip(V, Cc))
+    assert close(gvals, ref[order.numpy()], tol)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-11), (torch.float32, 5e-5)])
+@pytest.mark.parametrize("ard", [False, True])
+@pytest.mark.parametrize("n,d,p", [(300, 3, 1), (515, 8, 5), (700, 9, 8), (640, 8, 64), (333, 5, 17), (1000, 8, 40)])
+def test_rbf_op_apply_and_param_sweep(dtype, tol, ard, n, d, p):
+    """p >= 16 in fp32 takes the MFMA kernel, everything else the VALU kernel."""
+    rng = np.random.default_rng(2)
+    X = rng.standard_normal((n, d))
+    raw = (rng.standard_normal(d) * 0.3 + 0.5 if ard else np.array(0.7), np.array(0.4), np.array(-1.0))
+    V, Cc = rng.standard_normal((p, n)), rng.standard_normal((p, n))
+    o = orc.RbfGramOp(X, noise_minval=1e-4)
+    op = RbfGramOp(T(X, dtype), noise_minval=1e-4)
+    params = [T(r, dtype, True) for r in raw]
+    Vt = T(V, dtype, True)
+    y = op(Vt, *params)
+    assert close(y, o.apply(V, *raw), tol)
+    grads = torch.autograd.grad(y, (Vt, *params), T(Cc, dtype))
+    assert close(grads[0], o.apply(Cc, *raw), tol)
+    ref = o.param_vjp(V, Cc, *raw)
+    gtol = tol * (50 if dtype == torch.float32 else 10)
+    for g, rr in zip(grads[1:], ref):
+        assert close(g.reshape(np.shape(rr)), rr, gtol, atol_rel=gtol * np.sqrt(n))
+
+
+# ------------------------------------------------------------------------------------------------
+# small dense pieces
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-11), (torch.float32, 3e-5)])
+@pytest.mark.parametrize("k", [1, 2, 7, 40, 90])
+def test_tridiag_eigh_and_quadform_backward(dtype, tol, k):
+    rng = np.random.default_rng(k)
+    p = 5
+    d = rng.uniform(1.0, 3.0, size=(p, k))
+    e = rng.uniform(0.1, 0.5, size=(p, max(k - 1, 0)))
+    dt, et = T(d, dtype, True), T(e, dtype, True)
+    val, evals, evecs = lanczos._QuadformFn.apply(torch.log, dt, et)
+    gd, ge = torch.autograd.grad(val.sum(), (dt, et), allow_unused=True)
+    for b in range(p):
+        ref, (rd, re), (lam, U) = orc.quadform_from_tridiag(d[b], e[b], "log")
+        assert close(val[b], ref, tol)
+        assert close(np.sort(N(evals[b])), lam, tol)
+        Tm = orc.dense_tridiag(d[b], e[b])
+        Ub = N(evecs[b])
+        assert np.allclose(Ub.T @ Ub, np.eye(k), atol=tol * 10)
+        assert np.allclose(Tm @ Ub, Ub * N(evals[b])[None, :], atol=tol * 30)
+        assert close(gd[b], rd, tol * 20, atol_rel=tol * 20)
+        if k > 1:
+            assert close(ge[b], re, tol * 20, atol_rel=tol * 20)
+
+
+def test_rademacher_bit_exact_and_shardable():
+    x_like = torch.empty(1000, dtype=torch.float32, device=DEV)
+    full = hutchinson.sampler_rademacher(x_like, num=6)(11)
+    assert np.array_equal(N(full), orc.rademacher(11, 6, 1000))
+    part = hutchinson.sampler_rademacher(x_like, num=2)((11, 4))
+    assert np.array_equal(N(part), orc.rademacher(11, 2, 1000, first_probe=4))
+    explicit = torch.ones(3, 1000, device=DEV)
+    assert hutchinson.sampler_rademacher(x_like, num=3)(explicit) is explicit
+
+
+# ------------------------------------------------------------------------------------------------
+# Arnoldi forward / adjoint (reference: tests/test_arnoldi/*)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-10), (torch.float32, 1e-4)])
+@pytest.mark.parametrize("k", [1, 5, 10])
+@pytest.mark.parametrize("reortho", ["none", "full"])
+def test_hessenberg_forward_identities_and_oracle(dtype, tol, k, reortho):
+    n = 10
+    rng = np.random.default_rng(1)
+    A, v = rng.standard_normal((n, n)), rng.standard_normal(n)
+    Q, H, r, c = arnoldi.hessenberg(DenseOp(), k, reortho=reortho)(T(v, dtype), T(A, dtype))
+    assert Q.shape == (n, k) and H.shape == (k, k) and r.shape == (n,) and c.shape == ()
+    Qn, Hn, rn, cn = N(Q), N(H), N(r), N(c)
+    eK = np.eye(k)[-1]
+    assert np.allclose(A @ Qn - Qn @ Hn - np.outer(rn, eK), 0.0, atol=tol * 10)
+    assert np.allclose(Qn.T @ Qn, np.eye(k), atol=tol * 10)
+    assert np.allclose(Qn[:, 0], cn * v, atol=tol)
+    Qo, Ho, ro, co = orc.arnoldi_forward(orc.DenseOp(), k, v, A, reortho=reortho)
+    assert close(Q, Qo, tol * 10) and close(H, Ho, tol * 10) and close(r, ro, tol * 100, atol_rel=tol * 100)
+    assert close(c, co, tol)
+
+
+def test_hessenberg_batched_callable_and_errors():
+    n, k = 12, 4
+    rng = np.random.default_rng(5)
+    A, V = rng.standard_normal((n, n)), rng.standard_normal((3, n))
+    At = T(A)
+    Qb, Hb, rb, cb = arnoldi.hessenberg(DenseOp(), k, reortho="full")(T(V), At)
+    Qc, Hc, rc, cc = arnoldi.hessenberg(lambda s, p: p @ s, k, reortho="full")(T(V), At)  # Python callable path
+    assert Qb.shape == (3, n, k) and Hb.shape == (3, k, k) and rb.shape == (3, n) and cb.shape == (3,)
+    assert close(Qc, N(Qb), 1e-12) and close(Hc, N(Hb), 1e-12) and close(rc, N(rb), 1e-10, atol_rel=1e-10)
+    for b in range(3):
+        Qo, Ho, ro, co = orc.arnoldi_forward(orc.DenseOp(), k, V[b], A, reortho="full")
+        assert close(Qb[b], Qo, 1e-10) and close(Hb[b], Ho, 1e-10)
+    # single pass only when reortho_vjp="none" (quirk Q1; experiments/benchmarks/loss_of_orthogonality/measure.py:47-49)
+    Q1, H1, _, _ = arnoldi.hessenberg(DenseOp(), k, reortho="none", reortho_vjp="none")(T(V[0]), At)
+    Qo, Ho, _, _ = orc.arnoldi_forward(orc.DenseOp(), k, V[0], A, reortho="none", reortho_vjp="none")
+    assert close(H1, Ho, 1e-10)
+    for bad in (0, n + 1):
+        with pytest.raises(ValueError, match="depth"):
+            arnoldi.hessenberg(DenseOp(), bad, reortho="full")(T(V[0]), At)
+    for bad in (True, "full_with_sparsity", "None"):
+        with pytest.raises(TypeError, match="Unexpected input"):
+            arnoldi.hessenberg(lambda s: s, 1, reortho=bad)
+    with pytest.raises(ValueError, match="unsupported"):
+        lanczos.tridiag(DenseOp(), 1, reortho="half")
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("tag,reortho", [("rand3", "full"), ("rand3", "none"), ("rand10", "full"), ("rand10", "none"),
+                                         ("hilbert15", "full")])
+@pytest.mark.parametrize("kind", ["native", "callable"])
+def test_arnoldi_adjoint_golden(dtype, tag, reortho, kind):
+    """tests/test_arnoldi/test_hessenberg_adjoint.py: dense random cotangents over (Q, H, r, c)."""
+    g = np.load(os.path.join(GOLD, "arnoldi_adjoint.npz"))
+    pre = f"{tag}_{reortho}_"
+    A, v = T(g[tag + "_A"], dtype, True), T(g[tag + "_v"], dtype, True)
+    k = g[pre + "H"].shape[0]
+    mv = DenseOp() if kind == "native" else (lambda s, p: p @ s)
+    Q, H, r, c = arnoldi.hessenberg(mv, k, reortho=reortho)(v, A)
+    ftol = 1e-9 if dtype == torch.float64 else 2e-4
+    if tag != "hilbert15":
+        assert close(Q, g[pre + "Q"], ftol) and close(H, g[pre + "H"], ftol)
+    cot = [T(g[pre + s], dtype) for s in ("dQ", "dH", "dr", "dc")]
+    dv, dA = torch.autograd.grad((Q, H, r, c), (v, A), cot)
+    if dtype == torch.float64:
+        gtol = 1e-7
+    else:
+        gtol = 5e-3 if tag != "hilbert15" else None  # fp32 on cond ~1e17 is meaningless (reference runs it in x64 only)
+    if gtol is not None:
+        assert close(dv, g[pre + "dv"], gtol, atol_rel=gtol)
+        assert close(dA, g[pre + "dA"], gtol, atol_rel=gtol)
+
+
+# ------------------------------------------------------------------------------------------------
+# Lanczos tridiag forward / adjoint (reference: tests/test_lanczos/*)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-9), (torch.float32, 1e-4)])
+@pytest.mark.parametrize("reortho", ["full", "none"])
+@pytest.mark.parametrize("k", [1, 5, 11, 12])
+def test_tridiag_forward_golden(dtype, tol, reortho, k):
+    g = np.load(os.path.join(GOLD, "tridiag_forward_n12.npz"))
+    A, v = g["A"], g["v"]
+    (Q, (d, e)), (q, b) = lanczos.tridiag(DenseOp(), k, reortho=reortho)(T(v, dtype), T(A, dtype))
+    Qn, Tm = N(Q), orc.dense_tridiag(N(d), N(e))
+    if k == 12:
+        rt = 1e-5 if reortho == "full" else 1e-1
+        assert np.allclose(Qn.T @ Tm @ Qn, A, atol=rt, rtol=rt)
+        assert np.allclose(Qn @ Qn.T, np.eye(12), atol=rt, rtol=rt)
+    else:
+        eK = np.eye(k)[-1]
+        assert np.allclose(A @ Qn.T, Qn.T @ Tm + np.outer(eK, N(q) * N(b)).T, atol=1e-5, rtol=1e-5)
+        pre = f"{reortho}_{k}_"
+        loose = tol * (1 if reortho == "full" else 30)
+        assert close(d, g[pre + "d"], loose) and close(e, g[pre + "e"], loose, atol_rel=loose) if k > 1 else True
+        assert close(Q, g[pre + "Q"], loose * 10, atol_rel=loose * 10)
+        assert close(b, g[pre + "b"], loose * 10)
+
+
+@pytest.mark.parametrize("dtype,gtol", [(torch.float64, 1e-8), (torch.float32, 2e-3)])
+@pytest.mark.parametrize("reortho", ["full", "none"])
+@pytest.mark.parametrize("kind", ["native", "callable"])
+def test_tridiag_adjoint_golden(dtype, gtol, reortho, kind):
+    """tests/test_lanczos/test_tridiag_adjoint.py:12-50: random cotangents over ALL outputs."""
+    g = np.load(os.path.join(GOLD, "tridiag_adjoint_n10.npz"))
+    A, v = T(g["A"], dtype, True), T(g["v"], dtype, True)
+    mv = DenseOp() if kind == "native" else (lambda s, p: p @ s)
+    (Q, (d, e)), (q, b) = lanczos.tridiag(mv, 4, reortho=reortho)(v, A)
+    pre = reortho + "_"
+    cot = [T(g[pre + s], dtype) for s in ("dQ", "dd", "de", "dq", "db")]
+    dv, dA = torch.autograd.grad((Q, d, e, q, b), (v, A), cot)
+    assert close(dv, g[pre + "dv"], gtol, atol_rel=gtol)
+    # Q4: the no-reortho adjoint returns sum x lambda^T, exact only on the symmetric subspace
+    ref = g[pre + "dA"]
+    if reortho == "none":
+        dA, ref = 0.5 * (dA + dA.T), 0.5 * (ref + ref.T)
+    assert close(dA, ref, gtol, atol_rel=gtol)
+
+
+@pytest.mark.parametrize("dtype,gtol", [(torch.float64, 1e-8), (torch.float32, 5e-3)])
+@pytest.mark.parametrize("reortho", ["full", "none"])
+def test_csr_1138_bus_tridiag_and_adjoint(dtype, gtol, reortho):
+    """BASELINE config 3 parity case: SuiteSparse 1138_bus, gradient w.r.t. ALL stored values
+    (experiments/benchmarks/wall_times_vjp_through_lanczos_arnoldi/suite_sparse/benchmark.py:57-121)."""
+    g = np.load(os.path.join(GOLD, "csr_1138_bus.npz"))
+    n, k = g["v"].shape[0], int(g["k"])
+    op, vals, order = CsrOp.from_coo(g["row"], g["col"], g["vals"], n, DEV)
+    vals = vals.to(dtype).requires_grad_(True)
+    v = T(g["v"], dtype, True)
+    (Q, (d, e)), (q, b) = lanczos.tridiag(op, k, reortho=reortho)(v, vals)
+    pre = reortho + "_"
+    ftol = 1e-8 if dtype == torch.float64 else 5e-3
+    if reortho == "full" or dtype == torch.float64:
+        assert close(d, g[pre + "d"], ftol) and close(e, g[pre + "e"], ftol, atol_rel=ftol)
+    cot = [T(g[pre + s], dtype) for s in ("dQ", "dd", "de", "dq", "db")]
+    dv, dvals = torch.autograd.grad((Q, d, e, q, b), (v, vals), cot)
+    if dtype == torch.float64:
+        assert close(dv, g[pre + "dv"], gtol, atol_rel=gtol)
+        ref = g[pre + "dvals"][order.numpy()]
+        assert close(dvals, ref, gtol, atol_rel=gtol)
+    else:  # fp32 on cond(1138_bus) ~ 1e7: finite and the right size (the reference benchmark only times fp32)
+        assert torch.isfinite(dv).all() and torch.isfinite(dvals).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# SLQ integrand + Hutchinson (reference: tests/test_lanczos/test_integrand_spd_value_and_grad.py)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype,vtol,gtol", [(torch.float64, 1e-10, 1e-7), (torch.float32, 1e-4, 2e-3)])
+@pytest.mark.parametrize("reortho", ["full", "none"])
+def test_integrand_spd_dense_golden(dtype, vtol, gtol, reortho):
+    g = np.load(os.path.join(GOLD, "slq_dense.npz"))
+    A, v0 = T(g["A"], dtype, True), T(g["v0"], dtype, True)
+    integrand = lanczos.integrand_spd(torch.log, 6, DenseOp(), reortho=reortho)
+    val = integrand(v0, A)
+    dv0, dA = torch.autograd.grad(val, (v0, A))
+    assert close(val, g[f"{reortho}_value"], vtol)
+    ref = g[f"{reortho}_dA"]
+    if reortho == "none":
+        dA, ref = 0.5 * (dA + dA.T), 0.5 * (ref + ref.T)
+    assert close(dA, ref, gtol, atol_rel=gtol)
+    assert close(dv0, g[f"{reortho}_dv0"], gtol, atol_rel=gtol)
+    if reortho == "full":  # k = n: the quadrature is exact, v^T log(A) v
+        full = lanczos.integrand_spd(torch.log, 11, DenseOp())(v0, A)
+        assert close(full, g["full_depth_value"], vtol * 10)
+
+
+def test_integrand_symmetric_parametrisation_callable_matches_oracle():
+    """test_integrand_spd_value_and_grad.py:10-38 with matvec (p + p^T) @ x as a Python callable."""
+    n, k = 10, 6
+    A = orc.symmetric_matrix_from_eigenvalues(np.arange(0.0, 1.0 + n) + 1.0, seed=5)
+    P = np.triu(A) - 0.5 * np.diag(np.diag(A))
+    v0 = orc.rademacher(2, 1, n + 1)[0]
+    for use_adjoints in (True,):
+        integrand = lanczos.integrand_spd(torch.log, k, lambda x, p: (p + p.T) @ x, use_adjoints_for_tridiag=use_adjoints)
+        Pt = T(P, grad=True)
+        x_like = torch.ones(n + 1, dtype=torch.float64, device=DEV)
+        estimate = hutchinson.hutchinson(integrand, hutchinson.sampler_rademacher(x_like, num=1))
+        val = estimate(2, Pt)
+        (gP,) = torch.autograd.grad(val, Pt)
+        rv, _, (rP,) = orc.integrand_spd_value_and_grad(orc.DenseSymOp(), k, v0, (P,))
+        small = np.sqrt(np.finfo(np.float32).eps)
+        assert close(val, rv, small) and close(gP, rP, small, atol_rel=1e-9)
+
+
+def test_c1_config_dense_512():
+    """BASELINE config 1: 512 x 512 SPD (diag + rank-4), 20 Lanczos steps, 1 probe."""
+    g = np.load(os.path.join(GOLD, "slq_dense.npz"))
+    A = orc.spd_diag_plus_lowrank(512, 4, seed=0)
+    probe = orc.rademacher(1, 1, 512)[0]
+    for dtype, vtol, gtol in ((torch.float64, 1e-10, 1e-7), (torch.float32, 1e-4, 2e-3)):
+        At = T(A, dtype, True)
+        val = lanczos.integrand_spd(torch.log, 20, DenseOp())(T(probe, dtype), At)
+        (dA,) = torch.autograd.grad(val, At)
+        assert close(val, g["c1_value"], vtol)
+        assert close(torch.diagonal(dA), g["c1_dA_diag"], gtol, atol_rel=gtol)
+        assert close(dA[0], g["c1_dA_row0"], gtol, atol_rel=gtol)
+
+
+@pytest.mark.parametrize("dtype,vtol,gtol", [(torch.float64, 1e-9, 1e-6), (torch.float32, 1e-4, 2e-3)])
+@pytest.mark.parametrize("tag", ["ard", "iso"])
+def test_slq_rbf_golden(dtype, vtol, gtol, tag):
+    g = np.load(os.path.join(GOLD, "slq_rbf_n96.npz"))
+    op = gp_util.gram_operator(T(g["X"], dtype), noise_minval=float(g["noise_minval"]))
+    params = [T(g[f"{tag}_raw_l"], dtype, True), T(g["raw_s"], dtype, True), T(g["raw_n"], dtype, True)]
+    integrand = lanczos.integrand_spd(torch.log, 8, op)
+    probes = T(g["probes"], dtype)
+    vals = integrand(probes, *params)
+    assert close(vals, g[f"{tag}_values"], vtol)
+    value = hutchinson.hutchinson(integrand, lambda key: key)(probes, *params)
+    grads = torch.autograd.grad(value, params)
+    assert close(value, g[f"{tag}_value"], vtol)
+    for gr, name in zip(grads, ("g_l", "g_s", "g_n")):
+        assert close(gr.reshape(g[f"{tag}_{name}"].shape), g[f"{tag}_{name}"], gtol, atol_rel=gtol)
+
+
+@pytest.mark.parametrize("n,d,k,p", [(2048, 8, 16, 64), (1500, 9, 12, 24)])
+def test_slq_rbf_mfma_path_downsized_c4_c2(n, d, k, p):
+    """Down-sized BASELINE configs 4 (d=8, 64 probes) and 2 (d=9): fp32 MFMA Gram matvec inside the full
+    SLQ value-and-gradient, against the fp64 oracle on identical explicit probes."""
+    rng = np.random.default_rng(4)
+    X = rng.standard_normal((n, d))
+    ls = 2.0
+    raw = (np.array(np.log(np.expm1(ls))), np.array(np.log(np.expm1(1.0))), np.array(np.log(np.expm1(0.1))))
+    probes = orc.rademacher(5, p, n)
+    ref_val, ref_g, ref_vals = orc.hutchinson_value_and_grad(orc.RbfGramOp(X), k, probes, raw)
+    op = gp_util.gram_operator(T(X, torch.float32))
+    params = [T(r, torch.float32, True) for r in raw]
+    integrand = lanczos.integrand_spd(torch.log, k, op)
+    vals = integrand(T(probes, torch.float32), *params)
+    grads = torch.autograd.grad(vals.mean(), params)
+    assert close(vals, ref_vals, 1e-4)
+    for gr, rr in zip(grads, ref_g):
+        assert close(gr.reshape(np.shape(rr)), rr, 2e-3, atol_rel=2e-3)
+
+
+def test_reuse_integrand_and_logdet_helpers():
+    n, k = 64, 10
+    rng = np.random.default_rng(6)
+    A = orc.spd_diag_plus_lowrank(n, 3, seed=1)
+    At = T(A, grad=True)
+    probes = T(orc.rademacher(3, 8, n))
+    exact = lanczos.integrand_spd(torch.log, k, DenseOp())
+    reuse = lanczos.integrand_spd_custom_vjp_reuse(torch.log, k, DenseOp())
+    v1, v2 = exact(probes, At), reuse(probes, At)
+    assert close(v2, N(v1), 1e-12)
+    with pytest.warns(UserWarning):
+        (g2,) = torch.autograd.grad(v2.sum(), At)
+    for b in range(2):
+        _, _, (rg,) = orc.integrand_spd_reuse_value_and_grad(orc.DenseOp(), k, N(probes[b]), (A,))
+        (gb,) = torch.autograd.grad(reuse(probes[b], At), At)
+        assert close(gb, rg, 1e-8, atol_rel=1e-8)
+    # krylov_logdet_slq (util/gp_util.py:552-576): info dict keys and value
+    sample = hutchinson.sampler_rademacher(torch.empty(n, dtype=torch.float64, device=DEV), num=16)
+    value, info = gp_util.krylov_logdet_slq(k, sample=sample, num_batches=1, checkpoint=False)(DenseOp().bind(At), 3)
+    assert set(info) == {"std", "std_rel"} and abs(value.item() - np.linalg.slogdet(A)[1]) < 0.05 * abs(np.linalg.slogdet(A)[1]) + 1.0
+    value2, info2 = gp_util.krylov_logdet_slq(k, sample=sample, num_batches=3, checkpoint=True)(DenseOp().bind(At), 3)
+    assert set(info2) == {"std_abs", "std_rel"}
+    (gA,) = torch.autograd.grad(value2, At)
+    assert close(gA.diagonal().sum(), np.trace(np.linalg.inv(A)), 0.2)
+
+
+def test_hutchinson_variants():
+    """tests/test_hutchinson.py:9-37: custom-vjp forward == plain forward, backward differs but agrees statistically."""
+    n, k = 24, 6
+    A = orc.spd_diag_plus_lowrank(n, 2, seed=2)
+    At = T(A, grad=True)
+    integrand = lanczos.integrand_spd(torch.log, k, DenseOp())
+    sample = hutchinson.sampler_rademacher(torch.empty(n, dtype=torch.float64, device=DEV), num=512)
+    plain = hutchinson.hutchinson(integrand, sample)
+    nograd = hutchinson.hutchinson_nograd(integrand, sample)
+    custom = hutchinson.hutchinson_custom_vjp(integrand, sample)
+    v0, v1, v2 = plain(1, At), nograd(1, At), custom(1, At)
+    assert v0.item() == v1.item() == v2.item()
+    (g0,) = torch.autograd.grad(v0, At)
+    (g2,) = torch.autograd.grad(v2, At)
+    assert not torch.equal(g0, g2)
+    assert close(g2, N(g0), 0.25, atol_rel=0.25)
+    batch = hutchinson.hutchinson_batch(plain, num=4)(1, At)
+    keys = hutchinson.split(1, 4)
+    assert close(batch, np.mean([plain(kk, At).item() for kk in keys]), 1e-12)
+
+
+def test_no_cpu_fallback():
+    with pytest.raises(_lib.MfxError, match="no CPU fallback"):
+        arnoldi.hessenberg(DenseOp(), 2, reortho="full")(torch.ones(4), torch.eye(4))

@@ -1,0 +1,116 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol of include/mfx.h,
+the host wrappers raise the reference's errors before any launch, and nothing silently falls back."""
+
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from matfree_extensions import _lib, arnoldi, hutchinson, lanczos
+from matfree_extensions.distributed import shard_probes
+from matfree_extensions.operators import CsrOp, DenseOp, RbfGramOp, as_operator
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _lib.get()
+    header = open(os.path.join(ROOT, "include", "mfx.h")).read()
+    declared = set(re.findall(r"\b(mfx_[a-z_0-9]+)\s*\(", header)) - {"mfx_callback_fn"}
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.mfx_version() == 100
+    assert lib.mfx_last_error() is not None
+
+
+def test_struct_layout_matches_header_field_order():
+    header = open(os.path.join(ROOT, "include", "mfx.h")).read()
+    body = header[header.index("typedef struct mfx_operator {") : header.index("} mfx_operator;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"\b(\w+);", body)
+    assert fields == [f[0] for f in _lib.Operator._fields_]
+    gbody = header[header.index("typedef struct mfx_op_grads {") : header.index("} mfx_op_grads;")]
+    assert re.findall(r"\b(\w+);", gbody) == [f[0] for f in _lib.OpGrads._fields_]
+    # sizes/offsets as the C compiler lays the header out
+    import subprocess
+    import tempfile
+
+    prog = '#include <stdio.h>\n#include <stddef.h>\n#include "mfx.h"\nint main(void){printf("%zu %zu %zu %zu %zu\\n",' \
+           'sizeof(mfx_operator), sizeof(mfx_op_grads), offsetof(mfx_operator, x), offsetof(mfx_operator, lengthscale),' \
+           'offsetof(mfx_operator, callback));return 0;}'
+    with tempfile.TemporaryDirectory() as td:
+        src, exe = os.path.join(td, "s.c"), os.path.join(td, "s")
+        open(src, "w").write(prog)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe], check=True)
+        sizes = [int(t) for t in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
+    O = _lib.Operator
+    assert sizes == [ctypes.sizeof(O), ctypes.sizeof(_lib.OpGrads), O.x.offset, O.lengthscale.offset, O.callback.offset]
+
+
+def test_argument_errors_are_raised_before_any_launch():
+    # arnoldi.py:16-19,58-60 ; lanczos.py:148-149 (tests/test_arnoldi/test_hessenberg_forward.py:69-84)
+    for bad in (True, "full_with_sparsity", "None"):
+        with pytest.raises(TypeError, match="Unexpected input"):
+            arnoldi.hessenberg(lambda s: s, 1, reortho=bad)
+    for k in (0, 5):
+        with pytest.raises(ValueError, match="depth"):
+            arnoldi.hessenberg(DenseOp(), k, reortho="full")(torch.ones(4), torch.eye(4))
+        with pytest.raises(ValueError, match="depth"):
+            lanczos.tridiag(DenseOp(), k, reortho="none")(torch.ones(4), torch.eye(4))
+    with pytest.raises(ValueError, match="unsupported"):
+        lanczos.tridiag(DenseOp(), 1, reortho="half")
+
+
+def test_product_path_has_no_cpu_fallback():
+    with pytest.raises(_lib.MfxError, match="no CPU fallback"):
+        arnoldi.hessenberg(DenseOp(), 2, reortho="full")(torch.ones(4), torch.eye(4))
+    with pytest.raises(_lib.MfxError, match="no CPU fallback"):
+        lanczos.integrand_spd(torch.log, 2, DenseOp())(torch.ones(4), torch.eye(4))
+    with pytest.raises(_lib.MfxError, match="no CPU fallback"):
+        hutchinson.sampler_rademacher(torch.ones(4), num=2)(0)
+    src = ""
+    pkg = os.path.join(ROOT, "experiments-lanczos-adjoints_amd", "matfree_extensions")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src += open(os.path.join(dirpath, f)).read()
+    assert "oracle" not in src.replace("the oracle", "").lower() or "import oracle" not in src
+    assert "from oracle" not in src and "import oracle" not in src
+
+
+def test_operator_plumbing_on_cpu():
+    op, bound = as_operator(DenseOp().bind(torch.eye(3)))
+    assert isinstance(op, DenseOp) and len(bound) == 1
+    op2, bound2 = as_operator(lambda v, p: p @ v)
+    assert bound2 is None and op2(torch.ones(3), torch.eye(3)).shape == (3,)
+    with pytest.raises(TypeError):
+        as_operator(3)
+    crow = torch.tensor([0, 2, 3, 5])
+    col = torch.tensor([0, 2, 1, 0, 2])
+    csr = CsrOp(crow, col, 3)
+    assert csr.row.tolist() == [0, 0, 1, 2, 2]
+    assert csr.t_crow.tolist() == [0, 2, 3, 5] and csr.t_col.tolist() == [0, 2, 1, 0, 2]
+    assert csr.t_perm.tolist() == [0, 3, 2, 1, 4]
+    rbf = RbfGramOp(torch.zeros(5, 2), noise_minval=1e-4)
+    ls, s, nz = rbf.constrain(torch.zeros(2), torch.zeros(()), torch.zeros(()))
+    assert torch.allclose(ls, torch.full((2,), 0.6931472)) and abs(nz.item() - (1e-4 + 0.6931472)) < 1e-6
+    with pytest.raises(ValueError):
+        rbf.constrain(torch.zeros(3), torch.zeros(()), torch.zeros(()))
+
+
+def test_key_splitting_and_probe_sharding():
+    ks = hutchinson.split(7, 3)
+    assert len(set(ks)) == 3 and ks == hutchinson.split(7, 3)
+    probes = torch.arange(24.0).reshape(6, 4)
+    parts = hutchinson.split(probes, 3)
+    assert len(parts) == 3 and torch.equal(torch.cat(parts), probes)
+    assert hutchinson.sampler_rademacher(torch.ones(4), num=6)(probes) is probes
+    covered = []
+    for r in range(8):
+        first, count = shard_probes(64, r, 8)
+        covered += list(range(first, first + count))
+    assert covered == list(range(64))
+    assert [shard_probes(10, r, 4) for r in range(4)] == [(0, 3), (3, 3), (6, 2), (8, 2)]
