@@ -39,7 +39,8 @@ class DenseOp:
         return A.T @ lam
 
     def param_vjp(self, v, cot, A):
-        return (np.outer(cot, v),)
+        # v, cot of shape (n,) or a stacked batch (b, n): sum_b cot_b v_b^T
+        return (np.atleast_2d(cot).T @ np.atleast_2d(v),)
 
 
 class DenseSymOp:
@@ -52,7 +53,7 @@ class DenseSymOp:
         return (P + P.T) @ lam
 
     def param_vjp(self, v, cot, P):
-        o = np.outer(cot, v)
+        o = np.atleast_2d(cot).T @ np.atleast_2d(v)
         return (o + o.T,)
 
 
@@ -78,7 +79,7 @@ class CooOp:
         return out
 
     def param_vjp(self, v, cot, vals):
-        return (cot[self.row] * v[self.col],)
+        return ((np.atleast_2d(cot)[:, self.row] * np.atleast_2d(v)[:, self.col]).sum(0),)
 
 
 def softplus(x, beta=1.0, threshold=20.0):
@@ -113,17 +114,30 @@ class RbfGramOp:
     Row-chunked so that n up to a few 1e4 stays in memory.
     """
 
-    def __init__(self, X, noise_minval=0.0, chunk=2048):
+    def __init__(self, X, noise_minval=0.0, chunk=2048, cache_limit=4096):
         self.X = np.asarray(X)
         self.n, self.d = self.X.shape
         self.noise_minval = noise_minval
         self.chunk = chunk
+        self.cache_limit = cache_limit  # n up to which the dense K is kept between calls (test speed only)
+        self._cache = (None, None)
+
+    def _dense_k(self, ls, s):
+        if self.n > self.cache_limit:
+            return None
+        key = (np.asarray(ls).tobytes(), np.asarray(s).tobytes())
+        if self._cache[0] != key:
+            self._cache = (key, rbf_kernel_matrix(self.X, self.X, ls, s))
+        return self._cache[1]
 
     def constrained(self, raw_l, raw_s, raw_noise):
         return softplus(raw_l), softplus(raw_s), self.noise_minval + softplus(raw_noise)
 
     def apply(self, v, raw_l, raw_s, raw_noise):
         ls, s, noise = self.constrained(raw_l, raw_s, raw_noise)
+        Kd = self._dense_k(ls, s)
+        if Kd is not None:
+            return v @ Kd.T + noise * v
         out = np.empty(v.shape, dtype=np.result_type(v, self.X))
         for a in range(0, self.n, self.chunk):
             b = min(self.n, a + self.chunk)
@@ -142,9 +156,10 @@ class RbfGramOp:
         ard = np.ndim(raw_l) > 0
         g_l = np.zeros(self.d if ard else (), dtype=np.float64)
         g_s = 0.0
+        Kd = self._dense_k(ls, s)
         for a in range(0, self.n, self.chunk):
             b = min(self.n, a + self.chunk)
-            K = rbf_kernel_matrix(self.X[a:b], self.X, ls, s)
+            K = Kd[a:b] if Kd is not None else rbf_kernel_matrix(self.X[a:b], self.X, ls, s)
             S = C[:, a:b].T @ V  # (chunk, n): sum_b cot_b[i] v_b[j]
             W = S * K
             g_s += W.sum() / s
@@ -153,7 +168,8 @@ class RbfGramOp:
                     diff2 = (self.X[a:b, c][:, None] - self.X[None, :, c]) ** 2
                     g_l[c] += (W * diff2).sum() / ls[c] ** 3
             else:
-                diff2 = ((self.X[a:b, None, :] - self.X[None, :, :]) ** 2).sum(-1)
+                sqn = (self.X * self.X).sum(-1)
+                diff2 = np.maximum(0.0, sqn[a:b, None] + sqn[None, :] - 2.0 * self.X[a:b] @ self.X.T)
                 g_l += (W * diff2).sum() / ls**3
         g_noise = float((C * V).sum())
         return (
@@ -228,7 +244,7 @@ def arnoldi_adjoint(op, params, *, Q, H, r, c, dQ, dH, dr, dc, reortho="full"):
     beta_plus = H - np.diag(np.diag(H)) - np.diag(np.diag(H, -1), -1)  # arnoldi.py:139
 
     P = Q.T.copy()
-    dparams = None
+    pairs_v, pairs_cot = [], []
     for idx in range(k - 1, -1, -1):
         if reortho == "full":  # arnoldi.py:200-204 (cumulative row masking of P)
             P = ps_mask[idx][:, None] * P
@@ -236,12 +252,13 @@ def arnoldi_adjoint(op, params, *, Q, H, r, c, dQ, dH, dr, dc, reortho="full"):
             lam = lam - P.T @ (P @ lam) + P.T @ pvec
         q = Q[:, idx]
         z = op.apply_t(lam, *params)  # arnoldi.py:207-208: one vjp gives A^T lam and d/dtheta
-        inc = op.param_vjp(q, lam, *params)
-        dparams = inc if dparams is None else tuple(a + b for a, b in zip(dparams, inc))
+        pairs_v.append(q)  # d/dtheta [lam^T A(theta) q], summed over idx (arnoldi.py:209) in one sweep below
+        pairs_cot.append(lam)
         Gam[idx, :] = lower_mask[idx] * (Pi_gamma[idx] - z @ Q)  # arnoldi.py:212-213
         Lam[:, idx] = lam  # arnoldi.py:216
         xi = Pi_xi[idx] + (Gam + Gam.T)[idx, :] @ Q.T  # arnoldi.py:217
         lam = (xi - (alpha[idx] * lam - z) - beta_plus[idx] @ Lam.T) / beta_minus[idx]
+    dparams = op.param_vjp(np.stack(pairs_v), np.stack(pairs_cot), *params)
     return lam * c, dparams
 
 
@@ -305,7 +322,7 @@ def tridiag_none_vjp(op, k, v, params, cot):
     db = np.concatenate([db_, [db_last]])
     xi = -dxs[-1]
     lam_plus = np.zeros_like(xi)
-    dparams = None
+    pairs_v, pairs_cot = [], []
     for j in range(k - 1, -1, -1):
         xplus, x = xs[j + 1], xs[j]
         xi = xi / b[j]
@@ -314,12 +331,13 @@ def tridiag_none_vjp(op, k, v, params, cot):
         lam = -xi + mu * xplus + nu * x
         # Q4 (lanczos.py:328): A lam (not A^T lam), parameter-gradient of x^T A(theta) lam
         Alam = op.apply(lam, *params)
-        inc = op.param_vjp(lam, x, *params)
-        dparams = inc if dparams is None else tuple(p + q for p, q in zip(dparams, inc))
+        pairs_v.append(lam)
+        pairs_cot.append(x)
         xi = -dxs[j] - Alam + a[j] * lam + b[j] * lam_plus - b[j] * nu * xplus
         lam_plus = lam
     # Q3 (lanczos.py:305,311): the "lambda_1" used for the initial-vector gradient is the final xi
     dvec = ((xi @ xs[0]) * xs[0] - xi) / np.linalg.norm(v)
+    dparams = op.param_vjp(np.stack(pairs_v), np.stack(pairs_cot), *params)  # lanczos.py:310 (sum over steps)
     return dvec, dparams
 
 

@@ -152,7 +152,8 @@ def test_hessenberg_forward_identities_and_oracle(dtype, tol, k, reortho):
     assert np.allclose(Qn.T @ Qn, np.eye(k), atol=tol * 10)
     assert np.allclose(Qn[:, 0], cn * v, atol=tol)
     Qo, Ho, ro, co = orc.arnoldi_forward(orc.DenseOp(), k, v, A, reortho=reortho)
-    assert close(Q, Qo, tol * 10) and close(H, Ho, tol * 10) and close(r, ro, tol * 100, atol_rel=tol * 100)
+    assert close(Q, Qo, tol * 10) and close(H, Ho, tol * 10)
+    assert np.allclose(rn, ro, atol=tol * 100)  # at k = n the remainder is round-off only
     assert close(c, co, tol)
 
 
@@ -349,7 +350,7 @@ def test_slq_rbf_golden(dtype, vtol, gtol, tag):
         assert close(gr.reshape(g[f"{tag}_{name}"].shape), g[f"{tag}_{name}"], gtol, atol_rel=gtol)
 
 
-@pytest.mark.parametrize("n,d,k,p", [(2048, 8, 16, 64), (1500, 9, 12, 24)])
+@pytest.mark.parametrize("n,d,k,p", [(1536, 8, 12, 64), (1000, 9, 10, 24)])
 def test_slq_rbf_mfma_path_downsized_c4_c2(n, d, k, p):
     """Down-sized BASELINE configs 4 (d=8, 64 probes) and 2 (d=9): fp32 MFMA Gram matvec inside the full
     SLQ value-and-gradient, against the fp64 oracle on identical explicit probes."""
