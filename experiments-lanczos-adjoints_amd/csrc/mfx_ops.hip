@@ -312,7 +312,8 @@ static int64_t rbf_carve(const mfx_operator* op, void* ws, int64_t ws_bytes, Rbf
   RbfWs r;
   r.xs = cv.take(op->n * (dpad > 0 ? dpad : 1) * es);
   r.sq = cv.take(op->n * es);
-  r.partial = static_cast<double*>(cv.take(((op->n + 255) / 256) * 64 * sizeof(double)));
+  // per-workgroup gradient partials: VALU sweep n/256 rows, MFMA sweep 8 * n/128 rows, <= 34 doubles each
+  r.partial = static_cast<double*>(cv.take(((op->n + 127) / 128) * 8 * 34 * sizeof(double)));
   if (out) *out = r;
   return cv.off;
 }

@@ -188,12 +188,273 @@ int rbf_mfma_apply(const mfx_operator* op, const float* xs, const float* sq, int
   }
 }
 
-bool rbf_mfma_grad_supported(const mfx_operator* /*op*/, int64_t /*batch*/) { return false; }
+// ================================================================================================
+// Parameter-gradient sweep on the matrix cores.
+//
+//   d/dtheta sum_bt L_bt^T K(theta) R_bt = sum_ij S_ij dK_ij/dtheta,   S = L^T R  (n x n, rank <= batch)
+//
+// GEMM view: M = n (i), N = n (j), K = batch (all (probe, Lanczos-step) pairs of the adjoint at once:
+// 2560 for BASELINE config 4).  Both operands are K-major in HBM ((batch, n) rows, n contiguous), which
+// is exactly the A[i][k] / B[k][j] lane layout of v_mfma_f32_32x32x2_f32 -- LDS tiles are straight row
+// copies (ds_write_b128), fragments are conflict-free ds_read_b32.  S never leaves the accumulators:
+// the epilogue evaluates K_ij (distance from LDS-broadcast x_i and register x_j, v_exp_f32), multiplies
+// and reduces to (d + 2) numbers per workgroup.  128 x 128 tile per workgroup (4 waves, 64 x 64 each),
+// BK = 32 batch rows per stage, register-prefetched double buffering.
+// grid = (8 column ranges, n/128 row tiles): blockIdx.x is the XCD label (round-robin dispatch), so the
+// 64 resident workgroups of one XCD walk the SAME R panel (1.3 MB, L2-resident) while their L panels
+// come from the Infinity Cache.
+// ================================================================================================
+constexpr int kGM = 128, kGN = 128, kGK = 32, kGSplit = 8;
 
-int rbf_mfma_grad(const mfx_operator*, const float*, const float*, int, const float*, int64_t, const float*, int64_t,
-                  int64_t, double*, int64_t*, hipStream_t) {
-  set_error("RBF MFMA gradient sweep not built");
-  return MFX_ERR_UNSUPPORTED;
+constexpr int kGLd = kGM + 4;  // padded row of the transposed S tile: conflict-free ds_write_b128
+
+template <int DPAD>
+struct GradSmem {
+  union {
+    struct {
+      float a[2][kGK][kGM];
+      float b[2][kGK][kGN];
+    } st;
+    float s_t[kGN][kGLd];  // S^T tile (column j major) for the epilogue
+  } u;
+  float xi[kGM][DPAD];
+  float sqi[kGM];
+  float xj[kGN][DPAD];
+  float sqj[kGN];
+  double red[4][DPAD + 2];
+};
+
+template <int DPAD, bool VEC4>
+__device__ __forceinline__ void grad_load_stage(float4 (&ra)[4], float4 (&rb)[4], const float* __restrict__ L,
+                                                int64_t ldl, const float* __restrict__ R, int64_t ldr,
+                                                int64_t batch, int64_t n, int64_t bt0, int64_t i0, int64_t j0,
+                                                int tid) {
+  // 32 rows x 128 floats = 1024 float4 per operand; thread t takes float4 (row = f / 32, col4 = f % 32)
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int f = tid + 256 * u;
+    const int row = f >> 5, c4 = (f & 31) * 4;
+    const int64_t bt = bt0 + row;
+    float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+    if (bt < batch) {
+      const float* pa = L + bt * ldl + i0 + c4;
+      const float* pb = R + bt * ldr + j0 + c4;
+      if (VEC4 && i0 + c4 + 3 < n) {
+        va = *reinterpret_cast<const float4*>(pa);
+      } else {
+        if (i0 + c4 + 0 < n) va.x = pa[0];
+        if (i0 + c4 + 1 < n) va.y = pa[1];
+        if (i0 + c4 + 2 < n) va.z = pa[2];
+        if (i0 + c4 + 3 < n) va.w = pa[3];
+      }
+      if (VEC4 && j0 + c4 + 3 < n) {
+        vb = *reinterpret_cast<const float4*>(pb);
+      } else {
+        if (j0 + c4 + 0 < n) vb.x = pb[0];
+        if (j0 + c4 + 1 < n) vb.y = pb[1];
+        if (j0 + c4 + 2 < n) vb.z = pb[2];
+        if (j0 + c4 + 3 < n) vb.w = pb[3];
+      }
+    }
+    ra[u] = va;
+    rb[u] = vb;
+  }
+}
+
+template <int DPAD, bool VEC4>
+__global__ __launch_bounds__(256, 2) void k_rbf_mfma_grad(const float* __restrict__ xs, const float* __restrict__ sq,
+                                                          int64_t n, int ard, const float* __restrict__ L,
+                                                          int64_t ldl, const float* __restrict__ R, int64_t ldr,
+                                                          int64_t batch, int tiles_per_block,
+                                                          double* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  GradSmem<DPAD>& sm = *reinterpret_cast<GradSmem<DPAD>*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int wm = wid >> 1, wn = wid & 1;  // wave -> 64 x 64 quadrant of the 128 x 128 tile
+  const int64_t i0 = (int64_t)blockIdx.y * kGM;
+  const int64_t ntj = (n + kGN - 1) / kGN;
+  const int64_t tj_begin = (int64_t)blockIdx.x * tiles_per_block;
+  int64_t tj_end = tj_begin + tiles_per_block;
+  if (tj_end > ntj) tj_end = ntj;
+
+  // x_i, |x_i|^2 of this row tile (fixed for the workgroup)
+  for (int t = tid; t < kGM * DPAD; t += 256) {
+    const int64_t g = i0 * DPAD + t;
+    (&sm.xi[0][0])[t] = g < n * DPAD ? xs[g] : 0.f;
+  }
+  if (tid < kGM) sm.sqi[tid] = (i0 + tid < n) ? sq[i0 + tid] : 0.f;
+
+  double gsum[DPAD + 2];
+#pragma unroll
+  for (int c = 0; c < DPAD + 2; ++c) gsum[c] = 0.0;
+
+  const int64_t nstage = (batch + kGK - 1) / kGK;
+  for (int64_t tj = tj_begin; tj < tj_end; ++tj) {
+    const int64_t j0 = tj * kGN;
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    float4 ra[4], rb[4];
+    grad_load_stage<DPAD, VEC4>(ra, rb, L, ldl, R, ldr, batch, n, 0, i0, j0, tid);
+    __syncthreads();  // previous tile's epilogue / LDS reads are done
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int f = tid + 256 * u;
+      *reinterpret_cast<float4*>(&sm.u.st.a[0][f >> 5][(f & 31) * 4]) = ra[u];
+      *reinterpret_cast<float4*>(&sm.u.st.b[0][f >> 5][(f & 31) * 4]) = rb[u];
+    }
+    __syncthreads();
+    for (int64_t st = 0; st < nstage; ++st) {
+      const int cur = (int)(st & 1);
+      if (st + 1 < nstage) grad_load_stage<DPAD, VEC4>(ra, rb, L, ldl, R, ldr, batch, n, (st + 1) * kGK, i0, j0, tid);
+#pragma unroll
+      for (int kk = 0; kk < kGK; kk += 2) {
+        float av[2], bv[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) av[a] = sm.u.st.a[cur][kk + lhi][wm * 64 + a * 32 + l31];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) bv[b] = sm.u.st.b[cur][kk + lhi][wn * 64 + b * 32 + l31];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+      }
+      if (st + 1 < nstage) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int f = tid + 256 * u;
+          *reinterpret_cast<float4*>(&sm.u.st.a[cur ^ 1][f >> 5][(f & 31) * 4]) = ra[u];
+          *reinterpret_cast<float4*>(&sm.u.st.b[cur ^ 1][f >> 5][(f & 31) * 4]) = rb[u];
+        }
+      }
+      __syncthreads();
+    }
+    // ---- epilogue: S^T tile -> LDS (overlays the staging buffers; the K-loop's last barrier has
+    //      passed), then thread = row i walks 64 columns j: W_ij = S_ij exp(-dist_ij / 2) ------------
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float4 q;
+          q.x = acc[a][b][4 * g + 0]; q.y = acc[a][b][4 * g + 1]; q.z = acc[a][b][4 * g + 2]; q.w = acc[a][b][4 * g + 3];
+          *reinterpret_cast<float4*>(&sm.u.s_t[wn * 64 + b * 32 + l31][wm * 64 + a * 32 + 8 * g + 4 * lhi]) = q;
+        }
+    for (int t = tid; t < kGN * DPAD; t += 256) {
+      const int64_t g = j0 * DPAD + t;
+      (&sm.xj[0][0])[t] = g < n * DPAD ? xs[g] : 0.f;
+    }
+    if (tid < kGN) sm.sqj[tid] = (j0 + tid < n) ? sq[j0 + tid] : 0.f;
+    __syncthreads();
+    {
+      const int il = tid & (kGM - 1), jh = (tid >> 7) * 64;
+      const int64_t i = i0 + il;
+      float xiv[DPAD];
+#pragma unroll
+      for (int c = 0; c < DPAD; c += 4) {
+        const float4 q = *reinterpret_cast<const float4*>(&sm.xi[il][c]);
+        xiv[c] = q.x; xiv[c + 1] = q.y; xiv[c + 2] = q.z; xiv[c + 3] = q.w;
+      }
+      const float si = sm.sqi[il];
+      float gt[DPAD + 2];
+#pragma unroll
+      for (int c = 0; c < DPAD + 2; ++c) gt[c] = 0.f;
+#pragma unroll 2
+      for (int jj = 0; jj < 64; ++jj) {
+        const int jl = jh + jj;
+        const int64_t j = j0 + jl;
+        float xjv[DPAD];
+#pragma unroll
+        for (int c = 0; c < DPAD; c += 4) {
+          const float4 q = *reinterpret_cast<const float4*>(&sm.xj[jl][c]);
+          xjv[c] = q.x; xjv[c + 1] = q.y; xjv[c + 2] = q.z; xjv[c + 3] = q.w;
+        }
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < DPAD; ++c) dot = fmaf(xiv[c], xjv[c], dot);
+        float dist = fmaf(-2.f, dot, si + sm.sqj[jl]);
+        dist = fmaxf(dist, 0.f);
+        const bool live = (i < n) && (j < n);
+        const float s_ij = live ? sm.u.s_t[jl][il] : 0.f;
+        const float w = s_ij * __builtin_amdgcn_exp2f(-0.72134752044448170368f * dist);
+        gt[DPAD] += w;
+        if (ard) {
+#pragma unroll
+          for (int c = 0; c < DPAD; ++c) {
+            const float df = xiv[c] - xjv[c];
+            gt[c] = fmaf(w * df, df, gt[c]);
+          }
+        } else {
+          gt[0] = fmaf(w, dist, gt[0]);
+        }
+        if (i == j) gt[DPAD + 1] += s_ij;
+      }
+#pragma unroll
+      for (int c = 0; c < DPAD + 2; ++c) gsum[c] += (double)gt[c];
+    }
+  }
+  // ---- workgroup reduction -> one partial row per workgroup ------------------------------------
+#pragma unroll
+  for (int c = 0; c < DPAD + 2; ++c) {
+    const double v = wave_sum(gsum[c]);
+    if (lane == 0) sm.red[wid][c] = v;
+  }
+  __syncthreads();
+  if (tid < DPAD + 2) {
+    const int64_t blk = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+    partial[blk * (DPAD + 2) + tid] = sm.red[0][tid] + sm.red[1][tid] + sm.red[2][tid] + sm.red[3][tid];
+  }
+}
+
+bool rbf_mfma_grad_supported(const mfx_operator* op, int64_t batch) {
+  return op->dtype == MFX_F32 && batch >= 16 && op->d <= 16 && op->n >= 256;
+}
+
+int64_t rbf_mfma_grad_partial_rows(int64_t n) { return ((n + kGM - 1) / kGM) * kGSplit; }
+
+template <int DPAD>
+static int launch_grad(const mfx_operator* op, const float* xs, const float* sq, const float* L, int64_t ldl,
+                       const float* R, int64_t ldr, int64_t batch, double* partial, int64_t* nblocks_out,
+                       hipStream_t stream) {
+  const int64_t n = op->n;
+  const int64_t nti = (n + kGM - 1) / kGM, ntj = (n + kGN - 1) / kGN;
+  const int tiles_per_block = (int)((ntj + kGSplit - 1) / kGSplit);
+  const dim3 grid(kGSplit, (unsigned)nti);
+  const size_t sh = sizeof(GradSmem<DPAD>);
+  const bool vec4 = (n % 4 == 0) && (ldl % 4 == 0) && (ldr % 4 == 0) && (reinterpret_cast<uintptr_t>(L) % 16 == 0) &&
+                    (reinterpret_cast<uintptr_t>(R) % 16 == 0);
+  if (vec4) {
+    MFX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rbf_mfma_grad<DPAD, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    k_rbf_mfma_grad<DPAD, true><<<grid, 256, sh, stream>>>(xs, sq, n, op->ard, L, ldl, R, ldr, batch, tiles_per_block, partial);
+  } else {
+    MFX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rbf_mfma_grad<DPAD, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    k_rbf_mfma_grad<DPAD, false><<<grid, 256, sh, stream>>>(xs, sq, n, op->ard, L, ldl, R, ldr, batch, tiles_per_block, partial);
+  }
+  MFX_CHECK_LAUNCH();
+  *nblocks_out = nti * kGSplit;
+  return MFX_OK;
+}
+
+int rbf_mfma_grad(const mfx_operator* op, const float* xs, const float* sq, int dpad, const float* L, int64_t ldl,
+                  const float* R, int64_t ldr, int64_t batch, double* partial, int64_t* nblocks_out,
+                  hipStream_t stream) {
+  switch (dpad) {
+    case 4: return launch_grad<4>(op, xs, sq, L, ldl, R, ldr, batch, partial, nblocks_out, stream);
+    case 8: return launch_grad<8>(op, xs, sq, L, ldl, R, ldr, batch, partial, nblocks_out, stream);
+    case 12: return launch_grad<12>(op, xs, sq, L, ldl, R, ldr, batch, partial, nblocks_out, stream);
+    case 16: return launch_grad<16>(op, xs, sq, L, ldl, R, ldr, batch, partial, nblocks_out, stream);
+    default: set_error("RBF MFMA path supports d <= 16"); return MFX_ERR_UNSUPPORTED;
+  }
 }
 
 }  // namespace mfx
