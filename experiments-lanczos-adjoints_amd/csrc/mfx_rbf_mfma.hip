@@ -6,9 +6,10 @@
 // The Gram matrix is never materialised (the reference materialises (n/num x n) tiles,
 // util/gp_util.py:496-509).  GEMM view: M = n rows i, N = probes, K = n columns j.
 //   * v_mfma_f32_32x32x2_f32: A = K-tile (32 i x 2 j), B = V-tile (2 j x 32 probes), D = 32 i x 32 probes.
-//   * A-operand layout is lane -> (i = lane & 31, j = lane >> 5): every lane EVALUATES its own kernel
-//     entries (distance from its register-resident x_i and an LDS-broadcast x_j, v_exp_f32) straight
-//     into the MFMA A register -- no shuffle, no LDS round trip for K.
+//   * The squared distances are themselves a small MFMA product (inner dimension d + 2, augmented
+//     vectors), computed TRANSPOSED so that its accumulator registers, after v_min + v_exp in place,
+//     are exactly the A operand of the contraction MFMA (lane = row i, register = column j) -- no
+//     shuffle, no LDS round trip for K, ~2 VALU instructions per kernel entry.
 //   * B comes from an LDS image Vt[j][probe] (probe-contiguous, conflict-free ds_read_b32), filled
 //     from the (p, n) probe-major global layout with 256-B coalesced segments and a transposing store
 //     (row pad 1 -> at most 2-way ds_write conflicts, which are free on gfx950).
@@ -20,38 +21,54 @@ namespace mfx {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-constexpr int kTJ = 64;   // columns j per LDS tile
+constexpr int kTJ = 64;   // columns j per LDS tile (two 32-column MFMA blocks)
 constexpr int kMI = 2;    // 32-row sub-tiles per wave
+
+// -log2(e)/2: exp(-dist/2) = exp2(kNegHalfLog2e * dist)
+constexpr float kNegHalfLog2e = -0.72134752044448170368f;
 
 template <int DPAD, int NB>
 struct RbfTile {
-  static constexpr int LDV = NB * 32 + 1;
-  float xj[kTJ][DPAD];
-  float sqj[kTJ];
-  float vt[kTJ][LDV];
+  static constexpr int KD = DPAD + 2;        // augmented inner dimension of the distance product
+  static constexpr int LDV = NB * 32 + 1;    // padded probe row
+  float aj[KD][kTJ];   // A operand of the distance MFMA, k-major: c * [-2 x_j, |x_j|^2, 1]
+  float vt[kTJ][LDV];  // V^T tile [j][probe]
 };
 
+// One workgroup = 4 waves x 64 rows; grid.y = chunks of NB*32 probes.  Per 64-column tile and per
+// (32-row, 32-column) block the wave runs
+//   (1) KD/2 distance MFMAs  D^T[j][i] = sum_k A_j[k] B_i[k] = c (|x_i|^2 + |x_j|^2 - 2 x_i.x_j)   (c = -log2(e)/2)
+//       A_j from LDS (k-major, conflict-free), B_i = [x_i, 1, |x_i|^2] resident in registers;
+//   (2) 16 x { v_min(., 0), v_exp }  in place: the accumulator registers ARE the A operand of step (3):
+//       register r of lane (i = lane & 31, h = lane >> 5) holds column j_r(h) = (r & 3) + 8 (r >> 2) + 4 h;
+//   (3) 16 x NB contraction MFMAs  W[i][probe] += K[i][j_r(h)] V[j_r(h)][probe]  with B = Vt rows j_r(h).
+// K never exists outside VGPRs.  Global -> LDS staging is register-prefetched and double-buffered: one
+// barrier per tile.
 template <int DPAD, int NB, bool VEC4>
 __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply(const float* __restrict__ xs, const float* __restrict__ sq,
                                                            int64_t n, const float* __restrict__ outputscale,
                                                            const float* __restrict__ noise,
                                                            const float* __restrict__ x, int64_t ldx,
                                                            float* __restrict__ y, int64_t ldy, int64_t p) {
-  __shared__ __attribute__((aligned(16))) RbfTile<DPAD, NB> tile;
-  constexpr int LDV = RbfTile<DPAD, NB>::LDV;
+  using Tile = RbfTile<DPAD, NB>;
+  constexpr int KD = Tile::KD, KS = KD / 2;
+  __shared__ __attribute__((aligned(16))) Tile tile[2];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
   const int64_t i_wave = (int64_t)blockIdx.x * (4 * kMI * 32) + (int64_t)wid * (kMI * 32);
   const int64_t b0 = (int64_t)blockIdx.y * (NB * 32);
 
-  float xi[kMI][DPAD], sqi[kMI];
+  // B operand of the distance product: B_i[k], k = 2 s + lhi
+  float bi[kMI][KS];
 #pragma unroll
   for (int mi = 0; mi < kMI; ++mi) {
     int64_t i = i_wave + mi * 32 + l31;
     if (i >= n) i = n - 1;
 #pragma unroll
-    for (int c = 0; c < DPAD; ++c) xi[mi][c] = xs[i * DPAD + c];
-    sqi[mi] = sq[i];
+    for (int s = 0; s < KS; ++s) {
+      const int k = 2 * s + lhi;
+      bi[mi][s] = (k < DPAD) ? xs[i * DPAD + k] : (k == DPAD ? 1.f : sq[i]);
+    }
   }
   floatx16 acc[kMI][NB];
 #pragma unroll
@@ -61,63 +78,95 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply(const float* __restri
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][nb][r] = 0.f;
 
-  for (int64_t j0 = 0; j0 < n; j0 += kTJ) {
-    __syncthreads();
-    // ---- stage x_j, |x_j|^2 -------------------------------------------------------------------
-    for (int t = tid; t < kTJ * DPAD; t += 256) {
-      const int64_t g = j0 * DPAD + t;
-      (&tile.xj[0][0])[t] = g < n * DPAD ? xs[g] : 0.f;
-    }
-    if (tid < kTJ) tile.sqj[tid] = (j0 + tid < n) ? sq[j0 + tid] : 0.f;
-    // ---- stage V^T: global (probe, j) 256-B segments -> LDS [j][probe] -------------------------
-    constexpr int kF4 = NB * 32 * (kTJ / 4);  // float4 chunks in the tile
-    for (int f = tid; f < kF4; f += 256) {
+  // ---- staging: registers <- global, LDS <- registers -----------------------------------------
+  constexpr int kF4 = NB * 32 * (kTJ / 4);   // float4 chunks of the V tile
+  constexpr int kVPT = (kF4 + 255) / 256;    // per thread
+  constexpr int kXPT = (kTJ * DPAD + 255) / 256;
+  float4 rv[kVPT];
+  float rx[kXPT], rsq = 0.f;
+
+  auto load_tile = [&](int64_t j0) {
+#pragma unroll
+    for (int u = 0; u < kVPT; ++u) {
+      const int f = tid + 256 * u;
       const int bq = f / (kTJ / 4), j4 = (f % (kTJ / 4)) * 4;
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
-      if (b0 + bq < p) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (f < kF4 && b0 + bq < p) {
         const float* src = x + (b0 + bq) * ldx + j0 + j4;
         if (VEC4 && j0 + j4 + 3 < n) {
-          const float4 q = *reinterpret_cast<const float4*>(src);
-          v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+          v = *reinterpret_cast<const float4*>(src);
         } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (j0 + j4 + e < n) v[e] = src[e];
+          if (j0 + j4 + 0 < n) v.x = src[0];
+          if (j0 + j4 + 1 < n) v.y = src[1];
+          if (j0 + j4 + 2 < n) v.z = src[2];
+          if (j0 + j4 + 3 < n) v.w = src[3];
         }
       }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) tile.vt[j4 + e][bq] = v[e];
+      rv[u] = v;
     }
-    __syncthreads();
-    // ---- 32 K-steps of 2 columns ----------------------------------------------------------------
-#pragma unroll 4
-    for (int ks = 0; ks < kTJ / 2; ++ks) {
-      const int jj = 2 * ks + lhi;
-      float xjv[DPAD];
 #pragma unroll
-      for (int c = 0; c < DPAD; c += 4) {
-        const float4 q = *reinterpret_cast<const float4*>(&tile.xj[jj][c]);
-        xjv[c] = q.x; xjv[c + 1] = q.y; xjv[c + 2] = q.z; xjv[c + 3] = q.w;
+    for (int u = 0; u < kXPT; ++u) {
+      const int t = tid + 256 * u;
+      const int64_t g = j0 * DPAD + t;
+      rx[u] = (t < kTJ * DPAD && g < n * DPAD) ? xs[g] : 0.f;
+    }
+    if (tid < kTJ) rsq = (j0 + tid < n) ? sq[j0 + tid] : 0.f;
+  };
+  auto store_tile = [&](Tile& tl) {
+#pragma unroll
+    for (int u = 0; u < kVPT; ++u) {
+      const int f = tid + 256 * u;
+      if (f < kF4) {
+        const int bq = f / (kTJ / 4), j4 = (f % (kTJ / 4)) * 4;
+        tl.vt[j4 + 0][bq] = rv[u].x;
+        tl.vt[j4 + 1][bq] = rv[u].y;
+        tl.vt[j4 + 2][bq] = rv[u].z;
+        tl.vt[j4 + 3][bq] = rv[u].w;
       }
-      const float sj = tile.sqj[jj];
-      float a[kMI];
+    }
+#pragma unroll
+    for (int u = 0; u < kXPT; ++u) {
+      const int t = tid + 256 * u;
+      if (t < kTJ * DPAD) tl.aj[t % DPAD][t / DPAD] = -2.f * kNegHalfLog2e * rx[u];
+    }
+    if (tid < kTJ) {
+      tl.aj[DPAD][tid] = kNegHalfLog2e * rsq;
+      tl.aj[DPAD + 1][tid] = kNegHalfLog2e;
+    }
+  };
+
+  load_tile(0);
+  store_tile(tile[0]);
+  __syncthreads();
+  const int64_t ntile = (n + kTJ - 1) / kTJ;
+  for (int64_t t = 0; t < ntile; ++t) {
+    const Tile& tl = tile[t & 1];
+    if (t + 1 < ntile) load_tile((t + 1) * kTJ);
+#pragma unroll
+    for (int jb = 0; jb < kTJ / 32; ++jb) {
+      float aj[KS];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) aj[s] = tl.aj[2 * s + lhi][jb * 32 + l31];
 #pragma unroll
       for (int mi = 0; mi < kMI; ++mi) {
-        float dot = 0.f;
+        floatx16 kd;
 #pragma unroll
-        for (int c = 0; c < DPAD; ++c) dot = fmaf(xi[mi][c], xjv[c], dot);
-        const float dist = fmaf(-2.f, dot, sqi[mi] + sj);
-        // exp(-max(0, dist) / 2) = exp2(min(0, -log2(e)/2 * dist))
-        a[mi] = __builtin_amdgcn_exp2f(fminf(-0.72134752044448170368f * dist, 0.f));
-      }
+        for (int r = 0; r < 16; ++r) kd[r] = 0.f;
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const float bv = tile.vt[jj][nb * 32 + l31];
+        for (int s = 0; s < KS; ++s) kd = __builtin_amdgcn_mfma_f32_32x32x2f32(aj[s], bi[mi][s], kd, 0, 0, 0);
 #pragma unroll
-        for (int mi = 0; mi < kMI; ++mi)
-          acc[mi][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], bv, acc[mi][nb], 0, 0, 0);
+        for (int r = 0; r < 16; ++r) kd[r] = __builtin_amdgcn_exp2f(fminf(kd[r], 0.f));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int jr = jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[mi][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(kd[r], tl.vt[jr][nb * 32 + l31], acc[mi][nb], 0, 0, 0);
+        }
       }
     }
+    if (t + 1 < ntile) store_tile(tile[(t + 1) & 1]);
+    __syncthreads();
   }
   // ---- epilogue: y[b][i] = s * acc + noise * x[b][i];  D layout: col = lane & 31 (probe),
   //      row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)  -> 4 consecutive rows per register quad
