@@ -15,19 +15,30 @@
 //     (row pad 1 -> at most 2-way ds_write conflicts, which are free on gfx950).
 //   * one wave owns MI x 32 rows and all NB x 32 probes of its chunk: MI*NB*16 accumulator registers.
 // Bound: fp32 MFMA (2 n^2 p flop per matvec) -- the exp/distance VALU work co-issues underneath.
+#include <stdlib.h>
+
 #include "mfx_internal.h"
 
 namespace mfx {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-constexpr int kTJ = 64;   // columns j per LDS tile (two 32-column MFMA blocks)
-constexpr int kMI = 2;    // 32-row sub-tiles per wave
 
 // -log2(e)/2: exp(-dist/2) = exp2(kNegHalfLog2e * dist)
 constexpr float kNegHalfLog2e = -0.72134752044448170368f;
 
-template <int DPAD, int NB>
+// exp2(min(x, 0)) in ONE VALU instruction: v_exp_f32 with the clamp output modifier ([0, 1]); exp2 is
+// monotone, so clamping the result equals clamping the argument (the reference clamps the squared
+// distance at 0, util/gp_util.py:173).  fp32 MFMA shares the FP32 lanes with the VALU on gfx950
+// (measured: removing the min/exp shortens the kernel by exactly their issue cycles), so every VALU
+// instruction per kernel entry is paid in full.  s_nop 1 = the VALU-write -> MFMA-operand wait states.
+__device__ __forceinline__ float exp2_clamped(float x) {
+  float r;
+  asm("v_exp_f32_e64 %0, %1 clamp\n\ts_nop 1" : "=v"(r) : "v"(x));
+  return r;
+}
+
+template <int DPAD, int NB, int kTJ>
 struct RbfTile {
   static constexpr int KD = DPAD + 2;        // augmented inner dimension of the distance product
   static constexpr int LDV = NB * 32 + 1;    // padded probe row
@@ -44,13 +55,13 @@ struct RbfTile {
 //   (3) 16 x NB contraction MFMAs  W[i][probe] += K[i][j_r(h)] V[j_r(h)][probe]  with B = Vt rows j_r(h).
 // K never exists outside VGPRs.  Global -> LDS staging is register-prefetched and double-buffered: one
 // barrier per tile.
-template <int DPAD, int NB, bool VEC4>
+template <int DPAD, int NB, bool VEC4, int kMI, int kTJ>
 __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply(const float* __restrict__ xs, const float* __restrict__ sq,
                                                            int64_t n, const float* __restrict__ outputscale,
                                                            const float* __restrict__ noise,
                                                            const float* __restrict__ x, int64_t ldx,
                                                            float* __restrict__ y, int64_t ldy, int64_t p) {
-  using Tile = RbfTile<DPAD, NB>;
+  using Tile = RbfTile<DPAD, NB, kTJ>;
   constexpr int KD = Tile::KD, KS = KD / 2;
   __shared__ __attribute__((aligned(16))) Tile tile[2];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -155,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply(const float* __restri
 #pragma unroll
         for (int s = 0; s < KS; ++s) kd = __builtin_amdgcn_mfma_f32_32x32x2f32(aj[s], bi[mi][s], kd, 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) kd[r] = __builtin_amdgcn_exp2f(fminf(kd[r], 0.f));
+        for (int r = 0; r < 16; ++r) kd[r] = exp2_clamped(kd[r]);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int jr = jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
@@ -201,22 +212,34 @@ bool rbf_mfma_supported(const mfx_operator* op, int64_t p) {
   return op->dtype == MFX_F32 && p >= 16 && op->d <= 16;
 }
 
-template <int DPAD, int NB>
-static int launch_apply(const mfx_operator* op, const float* xs, const float* sq, const float* x, int64_t ldx,
-                        float* y, int64_t ldy, int64_t p, hipStream_t stream) {
+template <int DPAD, int NB, int MI, int TJ>
+static int launch_apply_mi(const mfx_operator* op, const float* xs, const float* sq, const float* x, int64_t ldx,
+                           float* y, int64_t ldy, int64_t p, hipStream_t stream) {
   const int64_t n = op->n;
-  const dim3 grid((unsigned)((n + 4 * kMI * 32 - 1) / (4 * kMI * 32)), (unsigned)((p + NB * 32 - 1) / (NB * 32)));
+  const dim3 grid((unsigned)((n + 4 * MI * 32 - 1) / (4 * MI * 32)), (unsigned)((p + NB * 32 - 1) / (NB * 32)));
   const bool vec4 = (n % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) &&
                     (reinterpret_cast<uintptr_t>(y) % 16 == 0);
   if (vec4) {
-    k_rbf_mfma_apply<DPAD, NB, true><<<grid, 256, 0, stream>>>(xs, sq, n, (const float*)op->outputscale,
-                                                               (const float*)op->noise, x, ldx, y, ldy, p);
+    k_rbf_mfma_apply<DPAD, NB, true, MI, TJ><<<grid, 256, 0, stream>>>(xs, sq, n, (const float*)op->outputscale,
+                                                                   (const float*)op->noise, x, ldx, y, ldy, p);
   } else {
-    k_rbf_mfma_apply<DPAD, NB, false><<<grid, 256, 0, stream>>>(xs, sq, n, (const float*)op->outputscale,
-                                                                (const float*)op->noise, x, ldx, y, ldy, p);
+    k_rbf_mfma_apply<DPAD, NB, false, MI, TJ><<<grid, 256, 0, stream>>>(xs, sq, n, (const float*)op->outputscale,
+                                                                    (const float*)op->noise, x, ldx, y, ldy, p);
   }
   MFX_CHECK_LAUNCH();
   return MFX_OK;
+}
+
+template <int DPAD, int NB>
+static int launch_apply(const mfx_operator* op, const float* xs, const float* sq, const float* x, int64_t ldx,
+                        float* y, int64_t ldy, int64_t p, hipStream_t stream) {
+  static const int mi_env = [] { const char* e = getenv("MFX_RBF_MI"); return e ? atoi(e) : 0; }();
+  // 64 rows per wave (2 workgroups per CU at n = 131072) unless the problem is too small to fill the chip
+  const bool small = (op->n + 255) / 256 < 512;
+  static const int tj_env = [] { const char* e = getenv("MFX_RBF_TJ"); return e ? atoi(e) : 0; }();
+  if (mi_env == 1 || (mi_env == 0 && small)) return launch_apply_mi<DPAD, NB, 1, 64>(op, xs, sq, x, ldx, y, ldy, p, stream);
+  if (tj_env == 128) return launch_apply_mi<DPAD, NB, 2, 128>(op, xs, sq, x, ldx, y, ldy, p, stream);
+  return launch_apply_mi<DPAD, NB, 2, 64>(op, xs, sq, x, ldx, y, ldy, p, stream);
 }
 
 template <int DPAD>
