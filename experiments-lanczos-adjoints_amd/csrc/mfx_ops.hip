@@ -303,6 +303,7 @@ static int rbf_dpad(int d) { return d <= 4 ? 4 : d <= 8 ? 8 : d <= 12 ? 12 : d <
 struct RbfWs {
   void *xs, *sq;
   double* partial;
+  float* vscale;  // (rows, 2) power-of-two scales of the f16-split path
 };
 
 static int64_t rbf_carve(const mfx_operator* op, void* ws, int64_t ws_bytes, RbfWs* out) {
@@ -314,6 +315,7 @@ static int64_t rbf_carve(const mfx_operator* op, void* ws, int64_t ws_bytes, Rbf
   r.sq = cv.take(op->n * es);
   // per-workgroup gradient partials: VALU sweep n/256 rows, MFMA sweep 8 * n/128 rows, <= 34 doubles each
   r.partial = static_cast<double*>(cv.take(((op->n + 127) / 128) * 8 * 34 * sizeof(double)));
+  r.vscale = static_cast<float*>(cv.take(65536 * 2 * sizeof(float)));
   if (out) *out = r;
   return cv.off;
 }
@@ -322,6 +324,9 @@ static int64_t rbf_carve(const mfx_operator* op, void* ws, int64_t ws_bytes, Rbf
 bool rbf_mfma_supported(const mfx_operator* op, int64_t p);
 int rbf_mfma_apply(const mfx_operator* op, const float* xs, const float* sq, int dpad, const float* x, int64_t ldx,
                    float* y, int64_t ldy, int64_t p, hipStream_t stream);
+int rbf_mfma_apply_h(const mfx_operator* op, const float* xs, const float* sq, int dpad, const float* x, int64_t ldx,
+                     float* y, int64_t ldy, int64_t p, float* vscale, hipStream_t stream);
+bool rbf_split_f16_enabled();
 bool rbf_mfma_grad_supported(const mfx_operator* op, int64_t batch);
 int rbf_mfma_grad(const mfx_operator* op, const float* xs, const float* sq, int dpad, const float* L, int64_t ldl,
                   const float* R, int64_t ldr, int64_t batch, double* partial, int64_t* nblocks_out,
@@ -365,8 +370,11 @@ static int rbf_apply(const mfx_operator* op, const T* x, int64_t ldx, T* y, int6
   MFX_REQUIRE(rbf_carve(op, ws, ws_bytes, &w) <= ws_bytes && ws, MFX_ERR_WORKSPACE, "RBF workspace too small");
   MFX_TRY(rbf_prep<T>(op, w, dpad, stream));
   if constexpr (sizeof(T) == 4) {
-    if (rbf_mfma_supported(op, p))
+    if (rbf_mfma_supported(op, p)) {
+      if (rbf_split_f16_enabled())
+        return rbf_mfma_apply_h(op, (const float*)w.xs, (const float*)w.sq, dpad, x, ldx, y, ldy, p, w.vscale, stream);
       return rbf_mfma_apply(op, (const float*)w.xs, (const float*)w.sq, dpad, x, ldx, y, ldy, p, stream);
+    }
   }
   switch (dpad) {
     case 4: return rbf_apply_d<T, 4>(op, w, x, ldx, y, ldy, p, stream);
