@@ -326,7 +326,9 @@ int rbf_mfma_apply(const mfx_operator* op, const float* xs, const float* sq, int
                    float* y, int64_t ldy, int64_t p, hipStream_t stream);
 int rbf_mfma_apply_h(const mfx_operator* op, const float* xs, const float* sq, int dpad, const float* x, int64_t ldx,
                      float* y, int64_t ldy, int64_t p, float* vscale, hipStream_t stream);
-bool rbf_split_f16_enabled();
+int rbf_mfma_apply_h3(const mfx_operator* op, const float* xs, const float* sq, int dpad, const float* x, int64_t ldx,
+                      float* y, int64_t ldy, int64_t p, float* vscale, hipStream_t stream);
+int rbf_split_f16_mode();
 bool rbf_mfma_grad_supported(const mfx_operator* op, int64_t batch);
 int rbf_mfma_grad(const mfx_operator* op, const float* xs, const float* sq, int dpad, const float* L, int64_t ldl,
                   const float* R, int64_t ldr, int64_t batch, double* partial, int64_t* nblocks_out,
@@ -371,7 +373,9 @@ static int rbf_apply(const mfx_operator* op, const T* x, int64_t ldx, T* y, int6
   MFX_TRY(rbf_prep<T>(op, w, dpad, stream));
   if constexpr (sizeof(T) == 4) {
     if (rbf_mfma_supported(op, p)) {
-      if (rbf_split_f16_enabled())
+      if (rbf_split_f16_mode() == 2)
+        return rbf_mfma_apply_h3(op, (const float*)w.xs, (const float*)w.sq, dpad, x, ldx, y, ldy, p, w.vscale, stream);
+      if (rbf_split_f16_mode() == 1)
         return rbf_mfma_apply_h(op, (const float*)w.xs, (const float*)w.sq, dpad, x, ldx, y, ldy, p, w.vscale, stream);
       return rbf_mfma_apply(op, (const float*)w.xs, (const float*)w.sq, dpad, x, ldx, y, ldy, p, stream);
     }

@@ -490,9 +490,282 @@ int rbf_mfma_apply_h(const mfx_operator* op, const float* xs, const float* sq, i
 #undef MFX_H_CASE
 }
 
-bool rbf_split_f16_enabled() {
+// ================================================================================================
+// Pipelined 3 x f16 kernel ("h3"): the production fp32 RBF Gram matvec.
+//
+// Measured on gfx950 (ablations): in the un-pipelined split kernel the fp32 distance MFMAs,
+// the exp/split VALU work and the f16 contraction MFMAs simply ADD UP -- the two waves of a SIMD run the
+// same program between the same barriers and fall into lock-step, and the fp32 MFMA shares the FP32 lanes
+// with the VALU.  So the overlap is built into ONE wave's instruction stream, pinned with sched_barrier:
+//   phase 1:  the 5 fp32 distance MFMAs of block b+1 (FP32 lanes)  ||  the first half of block b's f16
+//             contraction MFMAs (matrix pipe)
+//   phase 2:  the exp / hi-lo split of block b+1 (VALU, FP32 lanes)  ||  the second half of block b's MFMAs
+// The distances stay on the fp32 MFMA on purpose: it is a round-to-nearest fmaf chain, whereas the f16 MFMA
+// truncates its internal sum (tools/mfma_f16_rounding.hip: up to -1.75 ulp, biased), which is harmless in
+// the sign-mixed contraction but showed up as a 5x larger gradient error when used for the exponent.
+// ================================================================================================
+template <int DPAD, int NB, bool VEC4>
+__global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __restrict__ xs, const float* __restrict__ sq,
+                                                              int64_t n, const float* __restrict__ outputscale,
+                                                              const float* __restrict__ noise,
+                                                              const float* __restrict__ vscale,
+                                                              const float* __restrict__ x, int64_t ldx,
+                                                              float* __restrict__ y, int64_t ldy, int64_t p) {
+  constexpr int kMI = 2, kTJ = 64;
+  using Tile = RbfTileH<DPAD, NB, kTJ>;
+  constexpr int KD = Tile::KD, KS = KD / 2;
+  __shared__ __attribute__((aligned(16))) Tile tile[2];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int64_t i_wave = (int64_t)blockIdx.x * (4 * kMI * 32) + (int64_t)wid * (kMI * 32);
+  const int64_t b0 = (int64_t)blockIdx.y * (NB * 32);
+
+  float bi[kMI][KS];
+#pragma unroll
+  for (int mi = 0; mi < kMI; ++mi) {
+    int64_t i = i_wave + mi * 32 + l31;
+    if (i >= n) i = n - 1;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int k = 2 * s + lhi;
+      bi[mi][s] = (k < DPAD) ? xs[i * DPAD + k] : (k == DPAD ? 1.f : sq[i]);
+    }
+  }
+  floatx16 acc[kMI][NB];
+#pragma unroll
+  for (int mi = 0; mi < kMI; ++mi)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][nb][r] = 0.f;
+
+  constexpr int kF4 = NB * 32 * (kTJ / 4);
+  constexpr int kVPT = (kF4 + 255) / 256;
+  constexpr int kXPT = (kTJ * DPAD + 255) / 256;
+  float4 rv[kVPT];
+  float rx[kXPT], rsq = 0.f;
+  float vs[kVPT];
+#pragma unroll
+  for (int u = 0; u < kVPT; ++u) {
+    const int f = tid + 256 * u;
+    const int64_t b = b0 + f / (kTJ / 4);
+    vs[u] = (f < kF4 && b < p) ? vscale[2 * b] : 0.f;
+  }
+
+  auto load_tile = [&](int64_t j0) {
+#pragma unroll
+    for (int u = 0; u < kVPT; ++u) {
+      const int f = tid + 256 * u;
+      const int bq = f / (kTJ / 4), j4 = (f % (kTJ / 4)) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (f < kF4 && b0 + bq < p) {
+        const float* src = x + (b0 + bq) * ldx + j0 + j4;
+        if (VEC4 && j0 + j4 + 3 < n) {
+          v = *reinterpret_cast<const float4*>(src);
+        } else {
+          if (j0 + j4 + 0 < n) v.x = src[0];
+          if (j0 + j4 + 1 < n) v.y = src[1];
+          if (j0 + j4 + 2 < n) v.z = src[2];
+          if (j0 + j4 + 3 < n) v.w = src[3];
+        }
+      }
+      rv[u] = v;
+    }
+#pragma unroll
+    for (int u = 0; u < kXPT; ++u) {
+      const int t = tid + 256 * u;
+      const int64_t g = j0 * DPAD + t;
+      rx[u] = (t < kTJ * DPAD && g < n * DPAD) ? xs[g] : 0.f;
+    }
+    if (tid < kTJ) rsq = (j0 + tid < n) ? sq[j0 + tid] : 0.f;
+  };
+  auto store_tile = [&](Tile& tl) {
+#pragma unroll
+    for (int u = 0; u < kVPT; ++u) {
+      const int f = tid + 256 * u;
+      if (f < kF4) {
+        const int bq = f / (kTJ / 4), j4 = (f % (kTJ / 4)) * 4;
+        const int row = ((j4 >> 5) * 2 + ((j4 >> 4) & 1)) * 2 + ((j4 >> 2) & 1);
+        const int col = bq * 8 + 4 * ((j4 >> 3) & 1);
+        float h0, h1, h2, h3, l0, l1, l2, l3;
+        split_hi_lo(rv[u].x * vs[u], h0, l0);
+        split_hi_lo(rv[u].y * vs[u], h1, l1);
+        split_hi_lo(rv[u].z * vs[u], h2, l2);
+        split_hi_lo(rv[u].w * vs[u], h3, l3);
+        half4 hh = {(_Float16)h0, (_Float16)h1, (_Float16)h2, (_Float16)h3};
+        half4 ll = {(_Float16)l0, (_Float16)l1, (_Float16)l2, (_Float16)l3};
+        *reinterpret_cast<half4*>(&tl.vhi[row][col]) = hh;
+        *reinterpret_cast<half4*>(&tl.vlo[row][col]) = ll;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kXPT; ++u) {
+      const int t = tid + 256 * u;
+      if (t < kTJ * DPAD) tl.aj[t % DPAD][t / DPAD] = -2.f * kNegHalfLog2e * rx[u];
+    }
+    if (tid < kTJ) {
+      tl.aj[DPAD][tid] = kNegHalfLog2e * rsq + kKShift;  // K' = 2^15 K: lo(K') stays a NORMAL f16 for K >= 4e-6
+      tl.aj[DPAD + 1][tid] = kNegHalfLog2e;
+    }
+  };
+  // entries (2 pr, 2 pr + 1): K' = exp2(min(arg, 15)) and its hi/lo f16 pieces.  min as ONE compiler-visible
+  // v_med3_f32 (fminf adds a canonicalising v_max; inline asm would hide the MFMA-result hazard from hipcc).
+  auto exp_split_pair = [&](const floatx16& kd, int pr, half8 (&ah)[2], half8 (&al)[2]) {
+    const int s = pr >> 2, q = (pr & 3) * 2;
+    const float k0 = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(kd[8 * s + q], -3.0e38f, kKShift));
+    const float k1 = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(kd[8 * s + q + 1], -3.0e38f, kKShift));
+    const half2v h = {(_Float16)k0, (_Float16)k1};
+    const half2v l = {(_Float16)(k0 - (float)h[0]), (_Float16)(k1 - (float)h[1])};
+    ah[s][q] = h[0]; ah[s][q + 1] = h[1];
+    al[s][q] = l[0]; al[s][q + 1] = l[1];
+  };
+
+  load_tile(0);
+  store_tile(tile[0]);
+  __syncthreads();
+  const int64_t ntile = (n + kTJ - 1) / kTJ;
+  for (int64_t t = 0; t < ntile; ++t) {
+    const Tile& tl = tile[t & 1];
+    if (t + 1 < ntile) load_tile((t + 1) * kTJ);
+    half8 ah[2], al[2];
+    {  // pipeline prologue: fragments of block 0 of this tile
+      floatx16 kd;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) kd[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) kd = __builtin_amdgcn_mfma_f32_32x32x2f32(tl.aj[2 * s + lhi][l31], bi[0][s], kd, 0, 0, 0);
+#pragma unroll
+      for (int pr = 0; pr < 8; ++pr) exp_split_pair(kd, pr, ah, al);
+    }
+#pragma unroll
+    for (int blk = 0; blk < 2 * kMI; ++blk) {
+      const int jb = blk / kMI, mi = blk % kMI;
+      constexpr int NM = 6 * NB;       // contraction MFMAs of this block
+      constexpr int NM1 = NM / 2;      // issued in phase 1, next to the distance MFMAs
+      const bool has_next = blk + 1 < 2 * kMI;
+      const int jbn = (blk + 1) / kMI, min_ = (blk + 1) % kMI;
+      half8 bh[2][NB], bl[2][NB];
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const int row = (jb * 2 + s) * 2 + lhi;
+          bh[s][nb] = *reinterpret_cast<const half8*>(&tl.vhi[row][(nb * 32 + l31) * 8]);
+          bl[s][nb] = *reinterpret_cast<const half8*>(&tl.vlo[row][(nb * 32 + l31) * 8]);
+        }
+      float ajn[KS];
+      if (has_next) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) ajn[s] = tl.aj[2 * s + lhi][jbn * 32 + l31];
+      }
+      floatx16 kdn;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) kdn[r] = 0.f;
+      half8 ahn[2], aln[2];
+      auto contraction = [&](int m) {
+        const int s = m / (3 * NB), nb = (m / 3) % NB, w = m % 3;
+        acc[mi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w == 2 ? al[s] : ah[s], w == 1 ? bl[s][nb] : bh[s][nb],
+                                                             acc[mi][nb], 0, 0, 0);
+      };
+      // ---- phase 1: distance MFMAs of the next block between the first NM1 contraction MFMAs ----
+#pragma unroll
+      for (int m = 0; m < NM1; ++m) {
+        __builtin_amdgcn_sched_barrier(0);
+        contraction(m);
+        if (has_next) {
+#pragma unroll
+          for (int s = 0; s < KS; ++s)
+            if (s >= KS * m / NM1 && s < KS * (m + 1) / NM1)
+              kdn = __builtin_amdgcn_mfma_f32_32x32x2f32(ajn[s], bi[min_][s], kdn, 0, 0, 0);
+        }
+      }
+      // ---- phase 2: exp / split of the next block between the remaining contraction MFMAs -------
+#pragma unroll
+      for (int m = NM1; m < NM; ++m) {
+        __builtin_amdgcn_sched_barrier(0);
+        contraction(m);
+        if (has_next) {
+#pragma unroll
+          for (int pr = 0; pr < 8; ++pr)
+            if (pr >= 8 * (m - NM1) / (NM - NM1) && pr < 8 * (m - NM1 + 1) / (NM - NM1)) exp_split_pair(kdn, pr, ahn, aln);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (has_next) {
+        ah[0] = ahn[0]; ah[1] = ahn[1];
+        al[0] = aln[0]; al[1] = aln[1];
+      }
+    }
+    if (t + 1 < ntile) store_tile(tile[(t + 1) & 1]);
+    __syncthreads();
+  }
+  const float s = outputscale[0], nz = noise[0];
+#pragma unroll
+  for (int mi = 0; mi < kMI; ++mi)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int64_t b = b0 + nb * 32 + l31;
+      if (b >= p) continue;
+      const float sb = s * vscale[2 * b + 1] * (1.f / 32768.f);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int64_t i = i_wave + mi * 32 + 8 * g + 4 * lhi;
+        if (VEC4 && i + 3 < n) {
+          const float4 xv = *reinterpret_cast<const float4*>(x + b * ldx + i);
+          float4 o;
+          o.x = fmaf(sb, acc[mi][nb][4 * g + 0], nz * xv.x);
+          o.y = fmaf(sb, acc[mi][nb][4 * g + 1], nz * xv.y);
+          o.z = fmaf(sb, acc[mi][nb][4 * g + 2], nz * xv.z);
+          o.w = fmaf(sb, acc[mi][nb][4 * g + 3], nz * xv.w);
+          *reinterpret_cast<float4*>(y + b * ldy + i) = o;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (i + e < n) y[b * ldy + i + e] = fmaf(sb, acc[mi][nb][4 * g + e], nz * x[b * ldx + i + e]);
+        }
+      }
+    }
+}
+
+template <int DPAD, int NB>
+static int launch_apply_h3(const mfx_operator* op, const float* xs, const float* sq, const float* x, int64_t ldx,
+                           float* y, int64_t ldy, int64_t p, float* vscale, hipStream_t stream) {
+  const int64_t n = op->n;
+  k_row_scale<<<(unsigned)p, 256, 0, stream>>>(x, ldx, n, vscale);
+  MFX_CHECK_LAUNCH();
+  const dim3 grid((unsigned)((n + 255) / 256), (unsigned)((p + NB * 32 - 1) / (NB * 32)));
+  const bool vec4 = (n % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) &&
+                    (reinterpret_cast<uintptr_t>(y) % 16 == 0);
+  if (vec4) {
+    k_rbf_mfma_apply_h3<DPAD, NB, true><<<grid, 256, 0, stream>>>(xs, sq, n, (const float*)op->outputscale,
+                                                                  (const float*)op->noise, vscale, x, ldx, y, ldy, p);
+  } else {
+    k_rbf_mfma_apply_h3<DPAD, NB, false><<<grid, 256, 0, stream>>>(xs, sq, n, (const float*)op->outputscale,
+                                                                   (const float*)op->noise, vscale, x, ldx, y, ldy, p);
+  }
+  MFX_CHECK_LAUNCH();
+  return MFX_OK;
+}
+
+int rbf_mfma_apply_h3(const mfx_operator* op, const float* xs, const float* sq, int dpad, const float* x, int64_t ldx,
+                      float* y, int64_t ldy, int64_t p, float* vscale, hipStream_t stream) {
+#define MFX_H3_CASE(D)                                                                             \
+  case D:                                                                                          \
+    return p <= 32 ? launch_apply_h3<D, 1>(op, xs, sq, x, ldx, y, ldy, p, vscale, stream)          \
+                   : launch_apply_h3<D, 2>(op, xs, sq, x, ldx, y, ldy, p, vscale, stream)
+  switch (dpad) {
+    MFX_H3_CASE(4);
+    MFX_H3_CASE(8);
+    MFX_H3_CASE(12);
+    MFX_H3_CASE(16);
+    default: set_error("RBF MFMA path supports d <= 16"); return MFX_ERR_UNSUPPORTED;
+  }
+#undef MFX_H3_CASE
+}
+
+int rbf_split_f16_mode() {
   static const int mode = [] { const char* e = getenv("MFX_RBF_SPLIT_F16"); return e ? atoi(e) : 0; }();
-  return mode != 0;
+  return mode;  // 0: exact fp32 MFMA, 1: 3 x f16 contraction (un-pipelined), 2: pipelined 3 x f16 kernel (h3)
 }
 
 bool rbf_mfma_supported(const mfx_operator* op, int64_t p) {
