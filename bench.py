@@ -30,6 +30,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
+MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense
 
 
 def parse():
@@ -43,6 +44,8 @@ def parse():
     ap.add_argument("--probes-per-gpu", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-n", type=int, default=3072)
+    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "fp32", "f16x3+grad"],
+                    help="arithmetic of the fp32 Gram matvec: 3 x f16 split on the f16 matrix pipe (default) or exact fp32 MFMA")
     return ap.parse_args()
 
 
@@ -102,7 +105,7 @@ def main():
     X = torch.randn((n, d), generator=gen, dtype=torch.float32).to(dev)
     params = [torch.tensor(v, dtype=torch.float32, device=dev, requires_grad=True)
               for v in (inv_softplus(2.0), inv_softplus(1.0), inv_softplus(0.1))]
-    op = gp_util.gram_operator(X)
+    op = gp_util.gram_operator(X, precision=args.precision)
     integrand = lanczos.integrand_spd(torch.log, k, op)
     first, count = shard_probes(p_total, rank, world)
     sampler = hutchinson.sampler_rademacher(X[:, 0], num=count)
@@ -142,15 +145,20 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = p_total * args.steps / elapsed
-        # dominant kernel: the RBF Gram matvec (fp32 MFMA).  Algorithmic flops per launch: the
-        # contraction 2 n^2 p only (what the matrix cores execute); distance + exp ride on the VALU.
+        # dominant kernel: the RBF Gram matvec.  Algorithmic flops per launch: the contraction 2 n^2 p
+        # (what the matrix cores must deliver); distance + exp are extra work priced in DESIGN.md.
         flops_launch = 2.0 * n * n * p
         avg_ms = apply_ms / max(apply_cnt, 1)
         achieved = flops_launch / (avg_ms * 1e-3) / 1e12 if apply_cnt else 0.0
+        split = args.precision.startswith("f16x3")
+        peak = MFMA_F16_PEAK_TFLOPS if split else MFMA_F32_PEAK_TFLOPS
+        kernel = ("k_rbf_mfma_apply_h3 (Gram matvec, fp32 emulated by 3 f16 MFMA products + fp32-MFMA distances)"
+                  if split else "k_rbf_mfma_apply (Gram matvec, exact fp32 MFMA)")
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
-            traffic = json.load(open(tfile)).get("k_rbf_mfma_apply_hbm_bytes_per_launch")
+            traffic = json.load(open(tfile)).get("k_rbf_mfma_apply_h3_hbm_bytes_per_launch" if split
+                                                 else "k_rbf_mfma_apply_hbm_bytes_per_launch")
         mean, std, grads = out
         line = {
             "metric": "slq_logdet_value_and_grad_throughput",
@@ -163,24 +171,29 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if not split else "f32 (Gram contraction emulated with 3 f16 MFMA products, fp32 accumulate)",
             "data": "synthetic",
             "config": {
                 "workload": f"matrix-free RBF GP kernel N={n} d={d}, SLQ log-det value+grad, {k} Lanczos steps "
                             f"(full reortho) x {p} probes per GPU, fp32 (BASELINE config 4)",
                 "N": n, "d": d, "krylov_depth": k, "probes_per_gpu": p, "probes_total": p_total,
                 "parallelism": f"probe-sharded x{world}, operator replicated, one all-reduce per step",
+                "gram_precision": args.precision,
             },
             "roofline": {
-                "kernel": "k_rbf_mfma_apply (Gram matvec, 2*k launches per step)",
+                "kernel": kernel + f", {apply_cnt // max(args.steps, 1)} launches per step",
                 "bound": "mfma",
                 "achieved": achieved,
-                "peak": MFMA_F32_PEAK_TFLOPS,
+                "peak": peak,
                 "unit": "TFLOP/s",
-                "frac": achieved / MFMA_F32_PEAK_TFLOPS,
+                "frac": achieved / peak,
                 "traffic": traffic,
                 "avg_launch_ms": avg_ms,
                 "launches": apply_cnt,
+                "algorithmic_flops_per_launch": flops_launch,
+                # the 3-product emulation executes 3x the algorithmic MFMA flops: its ceiling is peak / 3
+                "executed_mfma_flops_factor": 3.0 if split else 1.0,
+                "frac_of_fp32_mfma_peak": achieved / MFMA_F32_PEAK_TFLOPS,
             },
             "breakdown_ms_per_step": {
                 "gram_matvec": apply_ms / args.steps,

@@ -281,11 +281,12 @@ __global__ __launch_bounds__(256) void k_rbf_grad(const T* __restrict__ xs, cons
 template <typename T>
 __global__ void k_rbf_grad_final(const double* __restrict__ partial, int64_t nblocks, int dpad, int d, int ard,
                                  const T* __restrict__ ls, const T* __restrict__ outputscale, T* __restrict__ g_ls,
-                                 T* __restrict__ g_s, T* __restrict__ g_noise) {
+                                 T* __restrict__ g_s, T* __restrict__ g_noise, const float* __restrict__ scales) {
   const int c = threadIdx.x;
   if (c >= dpad + 2) return;
   double acc = 0.0;
   for (int64_t q = 0; q < nblocks; ++q) acc += partial[q * (dpad + 2) + c];
+  if (scales) acc *= (double)scales[1] * (double)scales[3];  // undo the power-of-two operand scales of the split GEMM
   const double s = (double)outputscale[0];
   if (c < dpad) {
     if (ard ? (c < d) : (c == 0)) {
@@ -304,9 +305,14 @@ struct RbfWs {
   void *xs, *sq;
   double* partial;
   float* vscale;  // (rows, 2) power-of-two scales of the f16-split path
+  void* hws;      // f16 hi/lo packs of the split gradient sweep (sized for `batch_hint` rows)
+  int64_t hws_bytes;
 };
 
-static int64_t rbf_carve(const mfx_operator* op, void* ws, int64_t ws_bytes, RbfWs* out) {
+int64_t rbf_grad_h_ws_bytes(int64_t n, int64_t batch);
+int rbf_mode(const mfx_operator* op);
+
+static int64_t rbf_carve(const mfx_operator* op, void* ws, int64_t ws_bytes, RbfWs* out, int64_t batch_hint = 0) {
   const size_t es = dtype_size(op->dtype);
   const int dpad = rbf_dpad(op->d);
   Carver cv(ws, ws_bytes);
@@ -316,6 +322,8 @@ static int64_t rbf_carve(const mfx_operator* op, void* ws, int64_t ws_bytes, Rbf
   // per-workgroup gradient partials: VALU sweep n/256 rows, MFMA sweep 8 * n/128 rows, <= 34 doubles each
   r.partial = static_cast<double*>(cv.take(((op->n + 127) / 128) * 8 * 34 * sizeof(double)));
   r.vscale = static_cast<float*>(cv.take(65536 * 2 * sizeof(float)));
+  r.hws_bytes = (op->dtype == MFX_F32 && rbf_mode(op) == MFX_RBF_F16X3_GRAD && batch_hint > 0) ? rbf_grad_h_ws_bytes(op->n, batch_hint) : 0;
+  r.hws = r.hws_bytes ? cv.take(r.hws_bytes) : nullptr;
   if (out) *out = r;
   return cv.off;
 }
@@ -328,7 +336,9 @@ int rbf_mfma_apply_h(const mfx_operator* op, const float* xs, const float* sq, i
                      float* y, int64_t ldy, int64_t p, float* vscale, hipStream_t stream);
 int rbf_mfma_apply_h3(const mfx_operator* op, const float* xs, const float* sq, int dpad, const float* x, int64_t ldx,
                       float* y, int64_t ldy, int64_t p, float* vscale, hipStream_t stream);
-int rbf_split_f16_mode();
+int rbf_mfma_grad_h(const mfx_operator* op, const float* xs, const float* sq, int dpad, const float* L, int64_t ldl,
+                    const float* R, int64_t ldr, int64_t batch, double* partial, int64_t* nblocks_out, void* hws,
+                    const float** scales_out, hipStream_t stream);
 bool rbf_mfma_grad_supported(const mfx_operator* op, int64_t batch);
 int rbf_mfma_grad(const mfx_operator* op, const float* xs, const float* sq, int dpad, const float* L, int64_t ldl,
                   const float* R, int64_t ldr, int64_t batch, double* partial, int64_t* nblocks_out,
@@ -373,9 +383,9 @@ static int rbf_apply(const mfx_operator* op, const T* x, int64_t ldx, T* y, int6
   MFX_TRY(rbf_prep<T>(op, w, dpad, stream));
   if constexpr (sizeof(T) == 4) {
     if (rbf_mfma_supported(op, p)) {
-      if (rbf_split_f16_mode() == 2)
+      if (rbf_mode(op) >= MFX_RBF_F16X3)
         return rbf_mfma_apply_h3(op, (const float*)w.xs, (const float*)w.sq, dpad, x, ldx, y, ldy, p, w.vscale, stream);
-      if (rbf_split_f16_mode() == 1)
+      if (rbf_mode(op) == -1)
         return rbf_mfma_apply_h(op, (const float*)w.xs, (const float*)w.sq, dpad, x, ldx, y, ldy, p, w.vscale, stream);
       return rbf_mfma_apply(op, (const float*)w.xs, (const float*)w.sq, dpad, x, ldx, y, ldy, p, stream);
     }
@@ -395,12 +405,17 @@ static int rbf_grad(const mfx_operator* op, const T* L, int64_t ldl, const T* R,
   const int dpad = rbf_dpad(op->d);
   MFX_REQUIRE(dpad > 0, MFX_ERR_UNSUPPORTED, "RBF operator supports d <= 32 (got %d)", op->d);
   RbfWs w;
-  MFX_REQUIRE(rbf_carve(op, ws, ws_bytes, &w) <= ws_bytes && ws, MFX_ERR_WORKSPACE, "RBF workspace too small");
+  MFX_REQUIRE(rbf_carve(op, ws, ws_bytes, &w, batch) <= ws_bytes && ws, MFX_ERR_WORKSPACE, "RBF workspace too small");
   MFX_TRY(rbf_prep<T>(op, w, dpad, stream));
   int64_t nblocks = (op->n + 255) / 256;
   bool done = false;
+  const float* scales = nullptr;
   if constexpr (sizeof(T) == 4) {
-    if (rbf_mfma_grad_supported(op, batch)) {
+    if (rbf_mfma_grad_supported(op, batch) && rbf_mode(op) == MFX_RBF_F16X3_GRAD && w.hws) {
+      MFX_TRY(rbf_mfma_grad_h(op, (const float*)w.xs, (const float*)w.sq, dpad, L, ldl, R, ldr, batch, w.partial, &nblocks,
+                              w.hws, &scales, stream));
+      done = true;
+    } else if (rbf_mfma_grad_supported(op, batch)) {
       MFX_TRY(rbf_mfma_grad(op, (const float*)w.xs, (const float*)w.sq, dpad, L, ldl, R, ldr, batch, w.partial,
                             &nblocks, stream));
       done = true;
@@ -422,7 +437,7 @@ static int rbf_grad(const mfx_operator* op, const T* L, int64_t ldl, const T* R,
   }
   k_rbf_grad_final<T><<<1, 64, 0, stream>>>(w.partial, nblocks, dpad, op->d, op->ard, (const T*)op->lengthscale,
                                             (const T*)op->outputscale, (T*)grads->lengthscale,
-                                            (T*)grads->outputscale, (T*)grads->noise);
+                                            (T*)grads->outputscale, (T*)grads->noise, scales);
   MFX_CHECK_LAUNCH();
   return MFX_OK;
 }
@@ -430,8 +445,8 @@ static int rbf_grad(const mfx_operator* op, const T* L, int64_t ldl, const T* R,
 // ================================================================================================
 // dispatch
 // ================================================================================================
-int64_t op_workspace_bytes(const mfx_operator* op, int64_t /*p*/) {
-  if (op->kind == MFX_OP_RBF) return rbf_carve(op, nullptr, 0, nullptr);
+int64_t op_workspace_bytes(const mfx_operator* op, int64_t batch_hint) {
+  if (op->kind == MFX_OP_RBF) return rbf_carve(op, nullptr, 0, nullptr, batch_hint);
   return 256;
 }
 

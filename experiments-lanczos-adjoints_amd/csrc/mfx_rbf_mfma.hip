@@ -23,6 +23,10 @@ namespace mfx {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
+// geometry of the parameter-gradient GEMM (both the fp32 and the 3 x f16 variant)
+constexpr int kGM = 128, kGN = 128, kGK = 32, kGSplit = 8;
+constexpr int kGLd = kGM + 4;  // padded row of the transposed S tile: conflict-free ds_write_b128
+
 
 // -log2(e)/2: exp(-dist/2) = exp2(kNegHalfLog2e * dist)
 constexpr float kNegHalfLog2e = -0.72134752044448170368f;
@@ -763,9 +767,322 @@ int rbf_mfma_apply_h3(const mfx_operator* op, const float* xs, const float* sq, 
 #undef MFX_H3_CASE
 }
 
-int rbf_split_f16_mode() {
-  static const int mode = [] { const char* e = getenv("MFX_RBF_SPLIT_F16"); return e ? atoi(e) : 0; }();
-  return mode;  // 0: exact fp32 MFMA, 1: 3 x f16 contraction (un-pipelined), 2: pipelined 3 x f16 kernel (h3)
+// ================================================================================================
+// Parameter-gradient sweep, 3 x f16 split: S = L^T R on the f16 matrix pipe.
+//   pre-pass  k_pack_f16: (batch, n) fp32 rows -> hi/lo f16 packs [kb][i][8] (8 consecutive batch rows of
+//             column i = one 16-byte MFMA A/B fragment), scaled by one power of two per operand
+//             (global |max| -> 2^14), zero padded to batch % 32 == 0 and n % 128 == 0: the GEMM main loop
+//             has no conversions, no bounds checks, fragment loads are plain ds_read_b128;
+//   GEMM      same 128 x 128 tiling / epilogue as k_rbf_mfma_grad, 24 f16 MFMAs per 32-row stage instead
+//             of 64 fp32 MFMAs at twice the cycles.
+// ================================================================================================
+__global__ __launch_bounds__(256) void k_row_amax(const float* __restrict__ x, int64_t ldx, int64_t n,
+                                                  float* __restrict__ amax) {
+  __shared__ float sm[4];
+  const int64_t b = blockIdx.x;
+  float m = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(x[b * ldx + i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) amax[b] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+}
+
+// scale[0] = 2^(14 - e), scale[1] = 1 / scale[0] with max_b amax[b] = f 2^e
+__global__ void k_global_scale(const float* __restrict__ amax, int64_t rows, float* __restrict__ scale) {
+  __shared__ float sm[256];
+  float m = 0.f;
+  for (int64_t i = threadIdx.x; i < rows; i += 256) m = fmaxf(m, amax[i]);
+  sm[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sm[threadIdx.x] = fmaxf(sm[threadIdx.x], sm[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    int e = 0;
+    float s = 1.f;
+    if (sm[0] > 0.f && sm[0] < 3.0e38f) {
+      frexpf(sm[0], &e);
+      s = ldexpf(1.f, 14 - e);
+    }
+    scale[0] = s;
+    scale[1] = 1.f / s;
+  }
+}
+
+// hi/lo packs: out[(kb * npad + i) * 8 + q] = piece of scale * x[8 kb + q][i]
+__global__ __launch_bounds__(256) void k_pack_f16(const float* __restrict__ x, int64_t ldx, int64_t batch, int64_t n,
+                                                  int64_t npad, const float* __restrict__ scale,
+                                                  _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t kb = blockIdx.y;
+  if (i >= npad) return;
+  const float s = scale[0];
+  half8 h, l;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int64_t bt = kb * 8 + q;
+    const float v = (bt < batch && i < n) ? x[bt * ldx + i] * s : 0.f;
+    float fh, fl;
+    split_hi_lo(v, fh, fl);
+    h[q] = (_Float16)fh;
+    l[q] = (_Float16)fl;
+  }
+  *reinterpret_cast<half8*>(hi + (kb * npad + i) * 8) = h;
+  *reinterpret_cast<half8*>(lo + (kb * npad + i) * 8) = l;
+}
+
+template <int DPAD>
+struct GradSmemH {
+  union {
+    struct {
+      _Float16 a_hi[2][4][kGM][8];  // [stage][kb within stage][i][8]
+      _Float16 a_lo[2][4][kGM][8];
+      _Float16 b_hi[2][4][kGN][8];
+      _Float16 b_lo[2][4][kGN][8];
+    } st;
+    float s_t[kGN][kGLd];
+  } u;
+  float xi[kGM][DPAD];
+  float sqi[kGM];
+  float xj[kGN][DPAD];
+  float sqj[kGN];
+  double red[4][DPAD + 2];
+};
+
+template <int DPAD>
+__global__ __launch_bounds__(256, 2) void k_rbf_mfma_grad_h(const float* __restrict__ xs, const float* __restrict__ sq,
+                                                            int64_t n, int64_t npad, int ard,
+                                                            const _Float16* __restrict__ Lh, const _Float16* __restrict__ Ll,
+                                                            const _Float16* __restrict__ Rh, const _Float16* __restrict__ Rl,
+                                                            int64_t nkb /* batch_pad / 8 */, int tiles_per_block,
+                                                            double* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  GradSmemH<DPAD>& sm = *reinterpret_cast<GradSmemH<DPAD>*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int64_t i0 = (int64_t)blockIdx.y * kGM;
+  const int64_t ntj = (n + kGN - 1) / kGN;
+  const int64_t tj_begin = (int64_t)blockIdx.x * tiles_per_block;
+  int64_t tj_end = tj_begin + tiles_per_block;
+  if (tj_end > ntj) tj_end = ntj;
+
+  for (int t = tid; t < kGM * DPAD; t += 256) {
+    const int64_t g = i0 * DPAD + t;
+    (&sm.xi[0][0])[t] = g < n * DPAD ? xs[g] : 0.f;
+  }
+  if (tid < kGM) sm.sqi[tid] = (i0 + tid < n) ? sq[i0 + tid] : 0.f;
+
+  double gsum[DPAD + 2];
+#pragma unroll
+  for (int c = 0; c < DPAD + 2; ++c) gsum[c] = 0.0;
+
+  // staging: per stage 4 kb-groups x 128 columns x 16 B per operand piece = 512 chunks -> 2 per thread
+  const int64_t nstage = nkb / 4;
+  half8 ra_h[2], ra_l[2], rb_h[2], rb_l[2];
+  auto load_stage = [&](int64_t st, int64_t j0) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int c = tid + 256 * u;  // chunk: kbl = c / 128, col = c % 128
+      const int64_t kb = st * 4 + (c >> 7);
+      const int col = c & 127;
+      ra_h[u] = *reinterpret_cast<const half8*>(Lh + (kb * npad + i0 + col) * 8);
+      ra_l[u] = *reinterpret_cast<const half8*>(Ll + (kb * npad + i0 + col) * 8);
+      rb_h[u] = *reinterpret_cast<const half8*>(Rh + (kb * npad + j0 + col) * 8);
+      rb_l[u] = *reinterpret_cast<const half8*>(Rl + (kb * npad + j0 + col) * 8);
+    }
+  };
+  auto store_stage = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int c = tid + 256 * u;
+      *reinterpret_cast<half8*>(&sm.u.st.a_hi[buf][c >> 7][c & 127][0]) = ra_h[u];
+      *reinterpret_cast<half8*>(&sm.u.st.a_lo[buf][c >> 7][c & 127][0]) = ra_l[u];
+      *reinterpret_cast<half8*>(&sm.u.st.b_hi[buf][c >> 7][c & 127][0]) = rb_h[u];
+      *reinterpret_cast<half8*>(&sm.u.st.b_lo[buf][c >> 7][c & 127][0]) = rb_l[u];
+    }
+  };
+
+  for (int64_t tj = tj_begin; tj < tj_end; ++tj) {
+    const int64_t j0 = tj * kGN;
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    load_stage(0, j0);
+    __syncthreads();  // previous tile's epilogue reads of the overlaid S^T tile are done
+    store_stage(0);
+    __syncthreads();
+    for (int64_t st = 0; st < nstage; ++st) {
+      const int cur = (int)(st & 1);
+      if (st + 1 < nstage) load_stage(st + 1, j0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {  // two 16-deep k-steps per stage: kb-groups 2 ks + lhi
+        half8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          ah[a] = *reinterpret_cast<const half8*>(&sm.u.st.a_hi[cur][2 * ks + lhi][wm * 64 + a * 32 + l31][0]);
+          al[a] = *reinterpret_cast<const half8*>(&sm.u.st.a_lo[cur][2 * ks + lhi][wm * 64 + a * 32 + l31][0]);
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          bh[b] = *reinterpret_cast<const half8*>(&sm.u.st.b_hi[cur][2 * ks + lhi][wn * 64 + b * 32 + l31][0]);
+          bl[b] = *reinterpret_cast<const half8*>(&sm.u.st.b_lo[cur][2 * ks + lhi][wn * 64 + b * 32 + l31][0]);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
+          }
+      }
+      if (st + 1 < nstage) store_stage(cur ^ 1);
+      __syncthreads();
+    }
+    // ---- epilogue (as in k_rbf_mfma_grad) -------------------------------------------------------
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float4 q;
+          q.x = acc[a][b][4 * g + 0]; q.y = acc[a][b][4 * g + 1]; q.z = acc[a][b][4 * g + 2]; q.w = acc[a][b][4 * g + 3];
+          *reinterpret_cast<float4*>(&sm.u.s_t[wn * 64 + b * 32 + l31][wm * 64 + a * 32 + 8 * g + 4 * lhi]) = q;
+        }
+    for (int t = tid; t < kGN * DPAD; t += 256) {
+      const int64_t g = j0 * DPAD + t;
+      (&sm.xj[0][0])[t] = g < n * DPAD ? xs[g] : 0.f;
+    }
+    if (tid < kGN) sm.sqj[tid] = (j0 + tid < n) ? sq[j0 + tid] : 0.f;
+    __syncthreads();
+    {
+      const int il = tid & (kGM - 1), jh = (tid >> 7) * 64;
+      const int64_t i = i0 + il;
+      float xiv[DPAD];
+#pragma unroll
+      for (int c = 0; c < DPAD; c += 4) {
+        const float4 q = *reinterpret_cast<const float4*>(&sm.xi[il][c]);
+        xiv[c] = q.x; xiv[c + 1] = q.y; xiv[c + 2] = q.z; xiv[c + 3] = q.w;
+      }
+      const float si = sm.sqi[il];
+      float gt[DPAD + 2];
+#pragma unroll
+      for (int c = 0; c < DPAD + 2; ++c) gt[c] = 0.f;
+#pragma unroll 2
+      for (int jj = 0; jj < 64; ++jj) {
+        const int jl = jh + jj;
+        const int64_t j = j0 + jl;
+        float xjv[DPAD];
+#pragma unroll
+        for (int c = 0; c < DPAD; c += 4) {
+          const float4 q = *reinterpret_cast<const float4*>(&sm.xj[jl][c]);
+          xjv[c] = q.x; xjv[c + 1] = q.y; xjv[c + 2] = q.z; xjv[c + 3] = q.w;
+        }
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < DPAD; ++c) dot = fmaf(xiv[c], xjv[c], dot);
+        float dist = fmaf(-2.f, dot, si + sm.sqj[jl]);
+        dist = fmaxf(dist, 0.f);
+        const bool live = (i < n) && (j < n);
+        const float s_ij = live ? sm.u.s_t[jl][il] : 0.f;
+        const float w = s_ij * __builtin_amdgcn_exp2f(kNegHalfLog2e * dist);
+        gt[DPAD] += w;
+        if (ard) {
+#pragma unroll
+          for (int c = 0; c < DPAD; ++c) {
+            const float df = xiv[c] - xjv[c];
+            gt[c] = fmaf(w * df, df, gt[c]);
+          }
+        } else {
+          gt[0] = fmaf(w, dist, gt[0]);
+        }
+        if (i == j) gt[DPAD + 1] += s_ij;
+      }
+#pragma unroll
+      for (int c = 0; c < DPAD + 2; ++c) gsum[c] += (double)gt[c];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < DPAD + 2; ++c) {
+    const double v = wave_sum(gsum[c]);
+    if (lane == 0) sm.red[wid][c] = v;
+  }
+  __syncthreads();
+  if (tid < DPAD + 2) {
+    const int64_t blk = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+    partial[blk * (DPAD + 2) + tid] = sm.red[0][tid] + sm.red[1][tid] + sm.red[2][tid] + sm.red[3][tid];
+  }
+}
+
+int64_t rbf_grad_h_ws_bytes(int64_t n, int64_t batch) {
+  const int64_t npad = (n + 127) / 128 * 128, bpad = (batch + 31) / 32 * 32;
+  return 4 * bpad * npad * (int64_t)sizeof(_Float16) + 2 * bpad * (int64_t)sizeof(float) + 1024;
+}
+
+template <int DPAD>
+static int launch_grad_h(const mfx_operator* op, const float* xs, const float* sq, const float* L, int64_t ldl,
+                         const float* R, int64_t ldr, int64_t batch, double* partial, int64_t* nblocks_out,
+                         void* hws, hipStream_t stream) {
+  const int64_t n = op->n;
+  const int64_t npad = (n + 127) / 128 * 128, bpad = (batch + 31) / 32 * 32;
+  char* base = static_cast<char*>(hws);
+  float* amaxL = reinterpret_cast<float*>(base);
+  float* amaxR = amaxL + bpad;
+  float* scl = amaxR + bpad;  // [sL, 1/sL, sR, 1/sR]
+  _Float16* Lh = reinterpret_cast<_Float16*>(base + align_up(2 * bpad * 4 + 64, 256));
+  _Float16* Ll = Lh + bpad * npad;
+  _Float16* Rh = Ll + bpad * npad;
+  _Float16* Rl = Rh + bpad * npad;
+  k_row_amax<<<(unsigned)batch, 256, 0, stream>>>(L, ldl, n, amaxL);
+  k_row_amax<<<(unsigned)batch, 256, 0, stream>>>(R, ldr, n, amaxR);
+  k_global_scale<<<1, 256, 0, stream>>>(amaxL, batch, scl);
+  k_global_scale<<<1, 256, 0, stream>>>(amaxR, batch, scl + 2);
+  const dim3 pgrid((unsigned)((npad + 255) / 256), (unsigned)(bpad / 8));
+  k_pack_f16<<<pgrid, 256, 0, stream>>>(L, ldl, batch, n, npad, scl, Lh, Ll);
+  k_pack_f16<<<pgrid, 256, 0, stream>>>(R, ldr, batch, n, npad, scl + 2, Rh, Rl);
+  MFX_CHECK_LAUNCH();
+  const int64_t nti = (n + kGM - 1) / kGM, ntj = (n + kGN - 1) / kGN;
+  const int tiles_per_block = (int)((ntj + kGSplit - 1) / kGSplit);
+  const dim3 grid(kGSplit, (unsigned)nti);
+  const size_t sh = sizeof(GradSmemH<DPAD>);
+  MFX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rbf_mfma_grad_h<DPAD>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+  k_rbf_mfma_grad_h<DPAD><<<grid, 256, sh, stream>>>(xs, sq, n, npad, op->ard, Lh, Ll, Rh, Rl, bpad / 8, tiles_per_block, partial);
+  MFX_CHECK_LAUNCH();
+  *nblocks_out = nti * kGSplit;
+  return MFX_OK;
+}
+
+// returns the device pointer holding [sL, 1/sL, sR, 1/sR] through scales_out
+int rbf_mfma_grad_h(const mfx_operator* op, const float* xs, const float* sq, int dpad, const float* L, int64_t ldl,
+                    const float* R, int64_t ldr, int64_t batch, double* partial, int64_t* nblocks_out, void* hws,
+                    const float** scales_out, hipStream_t stream) {
+  const int64_t bpad = (batch + 31) / 32 * 32;
+  *scales_out = reinterpret_cast<const float*>(hws) + 2 * bpad;
+  switch (dpad) {
+    case 4: return launch_grad_h<4>(op, xs, sq, L, ldl, R, ldr, batch, partial, nblocks_out, hws, stream);
+    case 8: return launch_grad_h<8>(op, xs, sq, L, ldl, R, ldr, batch, partial, nblocks_out, hws, stream);
+    case 12: return launch_grad_h<12>(op, xs, sq, L, ldl, R, ldr, batch, partial, nblocks_out, hws, stream);
+    case 16: return launch_grad_h<16>(op, xs, sq, L, ldl, R, ldr, batch, partial, nblocks_out, hws, stream);
+    default: set_error("RBF MFMA path supports d <= 16"); return MFX_ERR_UNSUPPORTED;
+  }
+}
+
+// 0: exact fp32 MFMA, 1: 3 x f16 matvec (pipelined kernel h3), 2: also the gradient GEMM split.
+// MFX_RBF_MODE in the environment overrides the descriptor (A/B experiments: -1 = un-pipelined split kernel).
+int rbf_mode(const mfx_operator* op) {
+  static const int env = [] { const char* e = getenv("MFX_RBF_MODE"); return e ? atoi(e) : -100; }();
+  return env != -100 ? env : op->rbf_mode;
 }
 
 bool rbf_mfma_supported(const mfx_operator* op, int64_t p) {
@@ -836,9 +1153,7 @@ int rbf_mfma_apply(const mfx_operator* op, const float* xs, const float* sq, int
 // 64 resident workgroups of one XCD walk the SAME R panel (1.3 MB, L2-resident) while their L panels
 // come from the Infinity Cache.
 // ================================================================================================
-constexpr int kGM = 128, kGN = 128, kGK = 32, kGSplit = 8;
 
-constexpr int kGLd = kGM + 4;  // padded row of the transposed S tile: conflict-free ds_write_b128
 
 template <int DPAD>
 struct GradSmem {

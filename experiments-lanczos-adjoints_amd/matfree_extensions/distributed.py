@@ -28,8 +28,9 @@ def reduce_estimate(local_values, local_grads, num_total: int, group=None):
     local_grads : tuple of tensors = d/dtheta of SUM_b value_b over this rank's probes.
     -> (mean, std over probes, tuple of gradients of the mean)
     """
-    flat = [local_values.sum().reshape(1), (local_values**2).sum().reshape(1)]
-    flat += [g.reshape(-1) for g in local_grads]
+    lv = local_values.double()  # mean^2 ~ 1e10 at n = 1e5: the second moment needs fp64
+    flat = [lv.sum().reshape(1), (lv**2).sum().reshape(1)]
+    flat += [g.reshape(-1).double() for g in local_grads]
     buf = torch.cat(flat).contiguous()
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
@@ -37,7 +38,7 @@ def reduce_estimate(local_values, local_grads, num_total: int, group=None):
     var = torch.clamp_min(buf[1] / num_total - mean**2, 0.0)
     grads, off = [], 2
     for g in local_grads:
-        grads.append((buf[off : off + g.numel()] / num_total).reshape(g.shape))
+        grads.append((buf[off : off + g.numel()] / num_total).reshape(g.shape).to(g.dtype))
         off += g.numel()
     return mean, var.sqrt(), tuple(grads)
 

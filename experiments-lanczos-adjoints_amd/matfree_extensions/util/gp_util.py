@@ -64,7 +64,7 @@ def gram_matrix(fun, /):
     return gram
 
 
-def gram_operator(inputs, *, noise_minval=0.0):
+def gram_operator(inputs, *, noise_minval=0.0, precision="f16x3"):
     """Matrix-free (K(X, X) + noise I) operator: the native replacement for
     gram_matvec / gram_matvec_partitioned / gram_matvec_sequential applied to the lazy RBF kernel
     with the noise on its diagonal (util/gp_util.py:225-226, 434-543).  No partition count is
@@ -72,7 +72,7 @@ def gram_operator(inputs, *, noise_minval=0.0):
 
     Use as  ``A = gram_operator(X).bind(raw_lengthscale, raw_outputscale, raw_noise)``.
     """
-    return RbfGramOp(inputs, noise_minval=noise_minval)
+    return RbfGramOp(inputs, noise_minval=noise_minval, precision=precision)
 
 
 def krylov_logdet_slq(krylov_depth, /, *, sample, num_batches: int, checkpoint: bool = False):

@@ -31,6 +31,14 @@ extern "C" {
 enum { MFX_F32 = 0, MFX_F64 = 1 };
 enum { MFX_OP_DENSE = 0, MFX_OP_CSR = 1, MFX_OP_RBF = 2, MFX_OP_CALLBACK = 3 };
 enum { MFX_REORTHO_NONE = 0, MFX_REORTHO_FULL = 1 };
+/* fp32 RBF Gram matvec arithmetic (wide probe batches, p >= 16):
+ *   MFX_RBF_FP32     exact fp32 MFMA (v_mfma_f32_32x32x2_f32, a round-to-nearest fmaf chain)
+ *   MFX_RBF_F16X3    fp32 emulated on the f16 matrix pipe: operands split hi + lo (2 x 11 bits), products
+ *                    hi*hi + hi*lo + lo*hi accumulated in fp32; distances/exponent stay on the fp32 MFMA.
+ *                    ~2x faster and (measured against the fp64 path) at least as accurate as MFX_RBF_FP32.
+ *   MFX_RBF_F16X3_GRAD  additionally runs the parameter-gradient GEMM split (experimental: 2.6x faster,
+ *                    but the gradient's cancellation amplifies the f16 MFMA's truncating accumulation). */
+enum { MFX_RBF_FP32 = 0, MFX_RBF_F16X3 = 1, MFX_RBF_F16X3_GRAD = 2 };
 enum {
   MFX_OK = 0,
   MFX_ERR_INVALID = -1,     /* bad argument (shape, null pointer, depth out of range) */
@@ -83,6 +91,8 @@ typedef struct mfx_operator {
   const void* x;
   int32_t d;
   int32_t ard;
+  int32_t rbf_mode; /* MFX_RBF_* arithmetic of the fp32 Gram kernels (ignored for fp64) */
+  int32_t reserved;
   const void* lengthscale;
   const void* outputscale;
   const void* noise;

@@ -75,17 +75,18 @@ def test_csr_op(dtype, tol):
     assert close(gvals, ref[order.numpy()], tol)
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-11), (torch.float32, 5e-5)])
+@pytest.mark.parametrize("dtype,tol,precision", [(torch.float64, 1e-11, "fp32"), (torch.float32, 5e-5, "fp32"),
+                                                 (torch.float32, 5e-5, "f16x3"), (torch.float32, 5e-5, "f16x3+grad")])
 @pytest.mark.parametrize("ard", [False, True])
 @pytest.mark.parametrize("n,d,p", [(300, 3, 1), (515, 8, 5), (700, 9, 8), (640, 8, 64), (333, 5, 17), (1000, 8, 40)])
-def test_rbf_op_apply_and_param_sweep(dtype, tol, ard, n, d, p):
-    """p >= 16 in fp32 takes the MFMA kernel, everything else the VALU kernel."""
+def test_rbf_op_apply_and_param_sweep(dtype, tol, precision, ard, n, d, p):
+    """p >= 16 in fp32 takes the MFMA kernels (exact fp32 or the 3 x f16 split), everything else the VALU kernel."""
     rng = np.random.default_rng(2)
     X = rng.standard_normal((n, d))
     raw = (rng.standard_normal(d) * 0.3 + 0.5 if ard else np.array(0.7), np.array(0.4), np.array(-1.0))
     V, Cc = rng.standard_normal((p, n)), rng.standard_normal((p, n))
     o = orc.RbfGramOp(X, noise_minval=1e-4)
-    op = RbfGramOp(T(X, dtype), noise_minval=1e-4)
+    op = RbfGramOp(T(X, dtype), noise_minval=1e-4, precision=precision)
     params = [T(r, dtype, True) for r in raw]
     Vt = T(V, dtype, True)
     y = op(Vt, *params)
@@ -333,11 +334,12 @@ def test_c1_config_dense_512():
         assert close(dA[0], g["c1_dA_row0"], gtol, atol_rel=gtol)
 
 
-@pytest.mark.parametrize("dtype,vtol,gtol", [(torch.float64, 1e-9, 1e-6), (torch.float32, 1e-4, 2e-3)])
+@pytest.mark.parametrize("dtype,vtol,gtol,precision", [(torch.float64, 1e-9, 1e-6, "fp32"), (torch.float32, 1e-4, 2e-3, "fp32"),
+                                                       (torch.float32, 1e-4, 2e-3, "f16x3")])
 @pytest.mark.parametrize("tag", ["ard", "iso"])
-def test_slq_rbf_golden(dtype, vtol, gtol, tag):
+def test_slq_rbf_golden(dtype, vtol, gtol, precision, tag):
     g = np.load(os.path.join(GOLD, "slq_rbf_n96.npz"))
-    op = gp_util.gram_operator(T(g["X"], dtype), noise_minval=float(g["noise_minval"]))
+    op = gp_util.gram_operator(T(g["X"], dtype), noise_minval=float(g["noise_minval"]), precision=precision)
     params = [T(g[f"{tag}_raw_l"], dtype, True), T(g["raw_s"], dtype, True), T(g["raw_n"], dtype, True)]
     integrand = lanczos.integrand_spd(torch.log, 8, op)
     probes = T(g["probes"], dtype)
@@ -350,17 +352,18 @@ def test_slq_rbf_golden(dtype, vtol, gtol, tag):
         assert close(gr.reshape(g[f"{tag}_{name}"].shape), g[f"{tag}_{name}"], gtol, atol_rel=gtol)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "f16x3", "f16x3+grad"])
 @pytest.mark.parametrize("n,d,k,p", [(1536, 8, 12, 64), (1000, 9, 10, 24)])
-def test_slq_rbf_mfma_path_downsized_c4_c2(n, d, k, p):
-    """Down-sized BASELINE configs 4 (d=8, 64 probes) and 2 (d=9): fp32 MFMA Gram matvec inside the full
-    SLQ value-and-gradient, against the fp64 oracle on identical explicit probes."""
+def test_slq_rbf_mfma_path_downsized_c4_c2(n, d, k, p, precision):
+    """Down-sized BASELINE configs 4 (d=8, 64 probes) and 2 (d=9): MFMA Gram matvec (exact fp32 and the
+    3 x f16 split) inside the full SLQ value-and-gradient, against the fp64 oracle on identical explicit probes."""
     rng = np.random.default_rng(4)
     X = rng.standard_normal((n, d))
     ls = 2.0
     raw = (np.array(np.log(np.expm1(ls))), np.array(np.log(np.expm1(1.0))), np.array(np.log(np.expm1(0.1))))
     probes = orc.rademacher(5, p, n)
     ref_val, ref_g, ref_vals = orc.hutchinson_value_and_grad(orc.RbfGramOp(X), k, probes, raw)
-    op = gp_util.gram_operator(T(X, torch.float32))
+    op = gp_util.gram_operator(T(X, torch.float32), precision=precision)
     params = [T(r, torch.float32, True) for r in raw]
     integrand = lanczos.integrand_spd(torch.log, k, op)
     vals = integrand(T(probes, torch.float32), *params)
