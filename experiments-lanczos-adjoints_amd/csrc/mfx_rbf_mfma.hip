@@ -618,8 +618,14 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
     const int s = pr >> 2, q = (pr & 3) * 2;
     const float k0 = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(kd[8 * s + q], -3.0e38f, kKShift));
     const float k1 = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(kd[8 * s + q + 1], -3.0e38f, kKShift));
-    const half2v h = {(_Float16)k0, (_Float16)k1};
-    const half2v l = {(_Float16)(k0 - (float)h[0]), (_Float16)(k1 - (float)h[1])};
+    const half2v h = {(_Float16)k0, (_Float16)k1};  // one v_cvt_pk_f16_f32 (round to nearest)
+    // lo = k - hi in ONE instruction each: v_fma_mix_f32 reads the f16 half directly (no v_cvt_f32_f16 + v_sub).
+    // Inputs/outputs are VALU values only, so no MFMA hazard hides inside the asm.
+    float l0, l1;
+    const unsigned hb = __builtin_bit_cast(unsigned, h);
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hb), "v"(k0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hb), "v"(k1));
+    const half2v l = {(_Float16)l0, (_Float16)l1};
     ah[s][q] = h[0]; ah[s][q + 1] = h[1];
     al[s][q] = l[0]; al[s][q + 1] = l[1];
   };
@@ -671,7 +677,8 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
         acc[mi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w == 2 ? al[s] : ah[s], w == 1 ? bl[s][nb] : bh[s][nb],
                                                              acc[mi][nb], 0, 0, 0);
       };
-      // ---- phase 1: distance MFMAs of the next block between the first NM1 contraction MFMAs ----
+      // ---- phase 1: the distance MFMAs of the next block, issued as early as possible (two per
+      //      contraction MFMA) so that their result latency is covered by the rest of phase 1 -------
 #pragma unroll
       for (int m = 0; m < NM1; ++m) {
         __builtin_amdgcn_sched_barrier(0);
@@ -679,15 +686,20 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
         if (has_next) {
 #pragma unroll
           for (int s = 0; s < KS; ++s)
-            if (s >= KS * m / NM1 && s < KS * (m + 1) / NM1)
+            if (s >= 2 * m && s < 2 * (m + 1))
               kdn = __builtin_amdgcn_mfma_f32_32x32x2f32(ajn[s], bi[min_][s], kdn, 0, 0, 0);
         }
+      }
+      if (has_next) {  // distance steps that did not fit next to the NM1 contraction MFMAs (d > 8 with one probe block)
+#pragma unroll
+        for (int s = 2 * NM1; s < KS; ++s) kdn = __builtin_amdgcn_mfma_f32_32x32x2f32(ajn[s], bi[min_][s], kdn, 0, 0, 0);
       }
       // ---- phase 2: exp / split of the next block between the remaining contraction MFMAs -------
 #pragma unroll
       for (int m = NM1; m < NM; ++m) {
         __builtin_amdgcn_sched_barrier(0);
         contraction(m);
+        __builtin_amdgcn_sched_barrier(0);
         if (has_next) {
 #pragma unroll
           for (int pr = 0; pr < 8; ++pr)
