@@ -44,8 +44,8 @@ def parse():
     ap.add_argument("--probes-per-gpu", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-n", type=int, default=3072)
-    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "fp32", "f16x3+grad"],
-                    help="arithmetic of the fp32 Gram matvec: 3 x f16 split on the f16 matrix pipe (default) or exact fp32 MFMA")
+    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f16x3-matvec", "fp32"],
+                    help="arithmetic of the fp32 Gram kernels: 3 x f16 split on the f16 matrix pipe (default; -matvec keeps the gradient GEMM in exact fp32) or exact fp32 MFMA")
     return ap.parse_args()
 
 

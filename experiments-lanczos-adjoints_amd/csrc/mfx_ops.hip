@@ -322,7 +322,7 @@ static int64_t rbf_carve(const mfx_operator* op, void* ws, int64_t ws_bytes, Rbf
   // per-workgroup gradient partials: VALU sweep n/256 rows, MFMA sweep 8 * n/128 rows, <= 34 doubles each
   r.partial = static_cast<double*>(cv.take(((op->n + 127) / 128) * 8 * 34 * sizeof(double)));
   r.vscale = static_cast<float*>(cv.take(65536 * 2 * sizeof(float)));
-  r.hws_bytes = (op->dtype == MFX_F32 && rbf_mode(op) == MFX_RBF_F16X3_GRAD && batch_hint > 0) ? rbf_grad_h_ws_bytes(op->n, batch_hint) : 0;
+  r.hws_bytes = (op->dtype == MFX_F32 && rbf_mode(op) == MFX_RBF_F16X3 && batch_hint > 0) ? rbf_grad_h_ws_bytes(op->n, batch_hint) : 0;
   r.hws = r.hws_bytes ? cv.take(r.hws_bytes) : nullptr;
   if (out) *out = r;
   return cv.off;
@@ -383,7 +383,7 @@ static int rbf_apply(const mfx_operator* op, const T* x, int64_t ldx, T* y, int6
   MFX_TRY(rbf_prep<T>(op, w, dpad, stream));
   if constexpr (sizeof(T) == 4) {
     if (rbf_mfma_supported(op, p)) {
-      if (rbf_mode(op) >= MFX_RBF_F16X3)
+      if (rbf_mode(op) >= MFX_RBF_F16X3_MATVEC)
         return rbf_mfma_apply_h3(op, (const float*)w.xs, (const float*)w.sq, dpad, x, ldx, y, ldy, p, w.vscale, stream);
       if (rbf_mode(op) == -1)
         return rbf_mfma_apply_h(op, (const float*)w.xs, (const float*)w.sq, dpad, x, ldx, y, ldy, p, w.vscale, stream);
@@ -411,7 +411,7 @@ static int rbf_grad(const mfx_operator* op, const T* L, int64_t ldl, const T* R,
   bool done = false;
   const float* scales = nullptr;
   if constexpr (sizeof(T) == 4) {
-    if (rbf_mfma_grad_supported(op, batch) && rbf_mode(op) == MFX_RBF_F16X3_GRAD && w.hws) {
+    if (rbf_mfma_grad_supported(op, batch) && rbf_mode(op) == MFX_RBF_F16X3 && w.hws) {
       MFX_TRY(rbf_mfma_grad_h(op, (const float*)w.xs, (const float*)w.sq, dpad, L, ldl, R, ldr, batch, w.partial, &nblocks,
                               w.hws, &scales, stream));
       done = true;

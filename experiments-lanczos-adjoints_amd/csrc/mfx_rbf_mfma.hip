@@ -825,13 +825,15 @@ __global__ void k_global_scale(const float* __restrict__ amax, int64_t rows, flo
 }
 
 // hi/lo packs: out[(kb * npad + i) * 8 + q] = piece of scale * x[8 kb + q][i]
+// sign_period > 0: rows of every other block of `sign_period` batch rows are stored NEGATED (see kGChunk)
 __global__ __launch_bounds__(256) void k_pack_f16(const float* __restrict__ x, int64_t ldx, int64_t batch, int64_t n,
-                                                  int64_t npad, const float* __restrict__ scale,
+                                                  int64_t npad, const float* __restrict__ scale, int sign_period,
                                                   _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t kb = blockIdx.y;
   if (i >= npad) return;
-  const float s = scale[0];
+  float s = scale[0];
+  if (sign_period > 0 && ((kb * 8 / sign_period) & 1)) s = -s;
   half8 h, l;
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
@@ -864,6 +866,21 @@ struct GradSmemH {
   double red[4][DPAD + 2];
 };
 
+// async global -> LDS copy of 16 bytes per lane (global_load_lds_dwordx4): the destination is
+// wave-uniform base + lane * 16, which is exactly the [kb][column][8 halves] stage layout
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// The f16 MFMA truncates its internal sum towards -infinity: a bias of a fraction of an ulp per MFMA, invisible in
+// any single accumulator but COHERENT across all n^2 accumulators of S, and the gradient sum_ij S_ij dK_ij/dtheta
+// cancels to ~1e-4..1e-5 of its terms -- measured as a 0.1-1 % gradient error.  Cure at zero cost: the L operand of
+// every other K-chunk (kGChunk stages = 64 batch rows) is packed NEGATED and that chunk's accumulator is
+// SUBTRACTED from the fp32 master accumulator (round-to-nearest VALU adds), so the floor bias enters with
+// alternating sign and cancels.
+constexpr int kGChunk = 2;
+
 template <int DPAD>
 __global__ __launch_bounds__(256, 2) void k_rbf_mfma_grad_h(const float* __restrict__ xs, const float* __restrict__ sq,
                                                             int64_t n, int64_t npad, int ard,
@@ -873,7 +890,8 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_grad_h(const float* __restr
                                                             double* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   GradSmemH<DPAD>& sm = *reinterpret_cast<GradSmemH<DPAD>*>(smem_raw);
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5;
   const int wm = wid >> 1, wn = wid & 1;
   const int64_t i0 = (int64_t)blockIdx.y * kGM;
@@ -892,49 +910,42 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_grad_h(const float* __restr
 #pragma unroll
   for (int c = 0; c < DPAD + 2; ++c) gsum[c] = 0.0;
 
-  // staging: per stage 4 kb-groups x 128 columns x 16 B per operand piece = 512 chunks -> 2 per thread
+  // staging by LDS-DMA: per stage 4 kb-groups x 128 columns x 16 B per operand piece = 512 chunks, chunk c lives
+  // at byte 16 c of its piece: wave w copies chunks [64 w + 256 u, +64), u = 0, 1 -- no staging registers
   const int64_t nstage = nkb / 4;
-  half8 ra_h[2], ra_l[2], rb_h[2], rb_l[2];
-  auto load_stage = [&](int64_t st, int64_t j0) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int c = tid + 256 * u;  // chunk: kbl = c / 128, col = c % 128
-      const int64_t kb = st * 4 + (c >> 7);
-      const int col = c & 127;
-      ra_h[u] = *reinterpret_cast<const half8*>(Lh + (kb * npad + i0 + col) * 8);
-      ra_l[u] = *reinterpret_cast<const half8*>(Ll + (kb * npad + i0 + col) * 8);
-      rb_h[u] = *reinterpret_cast<const half8*>(Rh + (kb * npad + j0 + col) * 8);
-      rb_l[u] = *reinterpret_cast<const half8*>(Rl + (kb * npad + j0 + col) * 8);
-    }
-  };
-  auto store_stage = [&](int buf) {
+  auto issue_stage = [&](int64_t st, int64_t j0, int buf) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int c = tid + 256 * u;
-      *reinterpret_cast<half8*>(&sm.u.st.a_hi[buf][c >> 7][c & 127][0]) = ra_h[u];
-      *reinterpret_cast<half8*>(&sm.u.st.a_lo[buf][c >> 7][c & 127][0]) = ra_l[u];
-      *reinterpret_cast<half8*>(&sm.u.st.b_hi[buf][c >> 7][c & 127][0]) = rb_h[u];
-      *reinterpret_cast<half8*>(&sm.u.st.b_lo[buf][c >> 7][c & 127][0]) = rb_l[u];
+      const int64_t kb = st * 4 + (c >> 7);
+      const int col = c & 127;
+      const int cw = wid * 64 + 256 * u;  // first chunk of this wave-instruction (wave-uniform)
+      glds16(Lh + (kb * npad + i0 + col) * 8, &sm.u.st.a_hi[buf][cw >> 7][cw & 127][0]);
+      glds16(Ll + (kb * npad + i0 + col) * 8, &sm.u.st.a_lo[buf][cw >> 7][cw & 127][0]);
+      glds16(Rh + (kb * npad + j0 + col) * 8, &sm.u.st.b_hi[buf][cw >> 7][cw & 127][0]);
+      glds16(Rl + (kb * npad + j0 + col) * 8, &sm.u.st.b_lo[buf][cw >> 7][cw & 127][0]);
     }
   };
 
   for (int64_t tj = tj_begin; tj < tj_end; ++tj) {
     const int64_t j0 = tj * kGN;
-    floatx16 acc[2][2];
+    floatx16 acc[2][2], master[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        for (int r = 0; r < 16; ++r) {
+          acc[a][b][r] = 0.f;
+          master[a][b][r] = 0.f;
+        }
 
-    load_stage(0, j0);
     __syncthreads();  // previous tile's epilogue reads of the overlaid S^T tile are done
-    store_stage(0);
-    __syncthreads();
+    issue_stage(0, j0, 0);
+    __syncthreads();  // (drains the LDS-DMA: __syncthreads waits vmcnt(0))
     for (int64_t st = 0; st < nstage; ++st) {
       const int cur = (int)(st & 1);
-      if (st + 1 < nstage) load_stage(st + 1, j0);
+      if (st + 1 < nstage) issue_stage(st + 1, j0, cur ^ 1);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {  // two 16-deep k-steps per stage: kb-groups 2 ks + lhi
         half8 ah[2], al[2], bh[2], bl[2];
@@ -957,7 +968,18 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_grad_h(const float* __restr
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
           }
       }
-      if (st + 1 < nstage) store_stage(cur ^ 1);
+      if ((st % kGChunk) == kGChunk - 1 || st + 1 == nstage) {
+        const float sgn = ((st / kGChunk) & 1) ? -1.f : 1.f;  // odd chunks hold -L
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              master[a][b][r] = fmaf(sgn, acc[a][b][r], master[a][b][r]);
+              acc[a][b][r] = 0.f;
+            }
+      }
       __syncthreads();
     }
     // ---- epilogue (as in k_rbf_mfma_grad) -------------------------------------------------------
@@ -968,7 +990,7 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_grad_h(const float* __restr
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           float4 q;
-          q.x = acc[a][b][4 * g + 0]; q.y = acc[a][b][4 * g + 1]; q.z = acc[a][b][4 * g + 2]; q.w = acc[a][b][4 * g + 3];
+          q.x = master[a][b][4 * g + 0]; q.y = master[a][b][4 * g + 1]; q.z = master[a][b][4 * g + 2]; q.w = master[a][b][4 * g + 3];
           *reinterpret_cast<float4*>(&sm.u.s_t[wn * 64 + b * 32 + l31][wm * 64 + a * 32 + 8 * g + 4 * lhi]) = q;
         }
     for (int t = tid; t < kGN * DPAD; t += 256) {
@@ -1060,8 +1082,8 @@ static int launch_grad_h(const mfx_operator* op, const float* xs, const float* s
   k_global_scale<<<1, 256, 0, stream>>>(amaxL, batch, scl);
   k_global_scale<<<1, 256, 0, stream>>>(amaxR, batch, scl + 2);
   const dim3 pgrid((unsigned)((npad + 255) / 256), (unsigned)(bpad / 8));
-  k_pack_f16<<<pgrid, 256, 0, stream>>>(L, ldl, batch, n, npad, scl, Lh, Ll);
-  k_pack_f16<<<pgrid, 256, 0, stream>>>(R, ldr, batch, n, npad, scl + 2, Rh, Rl);
+  k_pack_f16<<<pgrid, 256, 0, stream>>>(L, ldl, batch, n, npad, scl, kGK * kGChunk, Lh, Ll);
+  k_pack_f16<<<pgrid, 256, 0, stream>>>(R, ldr, batch, n, npad, scl + 2, 0, Rh, Rl);
   MFX_CHECK_LAUNCH();
   const int64_t nti = (n + kGM - 1) / kGM, ntj = (n + kGN - 1) / kGN;
   const int tiles_per_block = (int)((ntj + kGSplit - 1) / kGSplit);

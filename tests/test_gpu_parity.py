@@ -76,7 +76,7 @@ def test_csr_op(dtype, tol):
 
 
 @pytest.mark.parametrize("dtype,tol,precision", [(torch.float64, 1e-11, "fp32"), (torch.float32, 5e-5, "fp32"),
-                                                 (torch.float32, 5e-5, "f16x3"), (torch.float32, 5e-5, "f16x3+grad")])
+                                                 (torch.float32, 5e-5, "f16x3-matvec"), (torch.float32, 5e-5, "f16x3")])
 @pytest.mark.parametrize("ard", [False, True])
 @pytest.mark.parametrize("n,d,p", [(300, 3, 1), (515, 8, 5), (700, 9, 8), (640, 8, 64), (333, 5, 17), (1000, 8, 40)])
 def test_rbf_op_apply_and_param_sweep(dtype, tol, precision, ard, n, d, p):
@@ -352,7 +352,7 @@ def test_slq_rbf_golden(dtype, vtol, gtol, precision, tag):
         assert close(gr.reshape(g[f"{tag}_{name}"].shape), g[f"{tag}_{name}"], gtol, atol_rel=gtol)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "f16x3", "f16x3+grad"])
+@pytest.mark.parametrize("precision", ["fp32", "f16x3-matvec", "f16x3"])
 @pytest.mark.parametrize("n,d,k,p", [(1536, 8, 12, 64), (1000, 9, 10, 24)])
 def test_slq_rbf_mfma_path_downsized_c4_c2(n, d, k, p, precision):
     """Down-sized BASELINE configs 4 (d=8, 64 probes) and 2 (d=9): MFMA Gram matvec (exact fp32 and the

@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 from matfree_extensions import hutchinson, lanczos, arnoldi
 from matfree_extensions.util import gp_util
 import matfree_extensions.arnoldi as A
-n,d,k,p = 32768,8,40,64
+n,d,k,p = int(os.environ.get("DIAG_N", "32768")),8,40,64
 dev=torch.device("cuda:0")
 gen=torch.Generator().manual_seed(4)
 X=torch.randn((n,d),generator=gen,dtype=torch.float32).to(dev)
