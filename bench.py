@@ -88,12 +88,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (there is no CPU product path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm; one rank per GPU
 
     from matfree_extensions import _lib, hutchinson, lanczos
     from matfree_extensions.distributed import reduce_estimate, shard_probes

@@ -80,7 +80,7 @@ def test_csr_op(dtype, tol):
 @pytest.mark.parametrize("ard", [False, True])
 @pytest.mark.parametrize("n,d,p", [(300, 3, 1), (515, 8, 5), (700, 9, 8), (640, 8, 64), (333, 5, 17), (1000, 8, 40)])
 def test_rbf_op_apply_and_param_sweep(dtype, tol, precision, ard, n, d, p):
-    """p >= 16 in fp32 takes the MFMA kernels (exact fp32 or the 3 x f16 split), everything else the VALU kernel."""
+    """p >= 4 in fp32 takes the MFMA kernels (exact fp32 or the 3 x f16 split), everything else the VALU kernel."""
     rng = np.random.default_rng(2)
     X = rng.standard_normal((n, d))
     raw = (rng.standard_normal(d) * 0.3 + 0.5 if ard else np.array(0.7), np.array(0.4), np.array(-1.0))

@@ -1,0 +1,88 @@
+"""Timings of the other BASELINE configs (parity cases of bench.py's headline config) on one MI355X.
+
+    python tools/bench_configs.py            # C1 dense 512, C2-like RBF 45730x9, C3 CSR Laplacian 102400 (fp64)
+
+Each line: forward (tridiag / SLQ value) and forward+adjoint wall time, median of 5 after 2 warm-ups.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "experiments-lanczos-adjoints_amd"))
+from matfree_extensions import lanczos  # noqa: E402
+from matfree_extensions.operators import CsrOp, DenseOp  # noqa: E402
+from matfree_extensions.util import gp_util  # noqa: E402
+from oracle import slq_oracle as orc  # noqa: E402  (input generators only)
+
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, reps=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    return 1e3 * float(np.median(ts))
+
+
+def c1():
+    A = torch.tensor(orc.spd_diag_plus_lowrank(512, 4, seed=0), device=dev)
+    probe = torch.tensor(orc.rademacher(1, 1, 512)[0], device=dev)
+    for dt in (torch.float64, torch.float32):
+        At = A.to(dt).requires_grad_(True)
+        f = lanczos.integrand_spd(torch.log, 20, DenseOp())
+        fwd = timeit(lambda: f(probe.to(dt), At))
+        both = timeit(lambda: torch.autograd.grad(f(probe.to(dt), At), At))
+        print(f"C1 dense 512x512 k=20 p=1 {dt}: value {fwd:.3f} ms, value+grad {both:.3f} ms")
+
+
+def c2():
+    n, d, k, p = 45730, 9, 30, 8
+    g = torch.Generator().manual_seed(2)
+    X = torch.randn(n, d, generator=g, dtype=torch.float32).to(dev)
+    params = [torch.zeros((d,) if i == 0 else (), dtype=torch.float32, device=dev, requires_grad=True) for i in range(3)]
+    probes = torch.tensor(orc.rademacher(2, p, n), dtype=torch.float32, device=dev)
+    f = lanczos.integrand_spd(torch.log, k, gp_util.gram_operator(X, noise_minval=1e-4))
+    fwd = timeit(lambda: f(probes, *params), reps=3, warm=1)
+    both = timeit(lambda: torch.autograd.grad(f(probes, *params).sum(), params), reps=3, warm=1)
+    print(f"C2-like RBF N={n} d={d} ARD k={k} p={p} fp32 (synthetic X; UCI protein has this shape): value {fwd:.2f} ms, value+grad {both:.2f} ms")
+
+
+def c3():
+    m = 320
+    r, c, vals, n = orc.laplacian_2d_plus_identity(m)
+    op, v, _ = CsrOp.from_coo(r, c, vals, n, dev)
+    vec = torch.randn(n, dtype=torch.float64, device=dev)
+    for reortho in ("full", "none"):
+        vt = v.clone().requires_grad_(True)
+        x0 = vec.clone().requires_grad_(True)
+        alg = lanczos.tridiag(op, 50, reortho=reortho)
+
+        def fwd_only():
+            return alg(x0, vt)
+
+        (Q, (a, b)), (q, br) = alg(x0, vt)
+        cot = [torch.randn_like(t) for t in (Q, a, b, q, br)]
+
+        def both():
+            (Q, (a, b)), (q, br) = alg(x0, vt)
+            return torch.autograd.grad((Q, a, b, q, br), (x0, vt), cot)
+
+        print(f"C3 CSR 5-pt Laplacian+I N={n} nnz={op.nnz} k=50 fp64 reortho={reortho}: forward {timeit(fwd_only):.3f} ms, "
+              f"forward+adjoint (all outputs, grad wrt all nnz) {timeit(both):.3f} ms")
+
+
+if __name__ == "__main__":
+    c1()
+    c2()
+    c3()
