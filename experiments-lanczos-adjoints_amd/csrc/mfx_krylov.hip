@@ -24,7 +24,7 @@ __device__ __forceinline__ void load_own(T (&dst)[kEpt], const T* __restrict__ b
   constexpr int U = kEpt / VEC;
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    const int64_t off = slice0 + (int64_t)(u * kBlock + tid) * VEC;
+    const int64_t off = slice0 + (int64_t)(u * (int)blockDim.x + tid) * VEC;
     if (off < n) {
       Pack<T, VEC> p = load_pack<T, VEC>(base + off);
 #pragma unroll
@@ -42,7 +42,7 @@ __device__ __forceinline__ void store_own(const T (&src)[kEpt], T* __restrict__ 
   constexpr int U = kEpt / VEC;
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    const int64_t off = slice0 + (int64_t)(u * kBlock + tid) * VEC;
+    const int64_t off = slice0 + (int64_t)(u * (int)blockDim.x + tid) * VEC;
     if (off < n) {
       Pack<T, VEC> p;
 #pragma unroll
@@ -72,12 +72,26 @@ __global__ __launch_bounds__(kBlock) void k_dots(const T* __restrict__ rows, int
   T* sm = reinterpret_cast<T*>(smem_raw);  // [4][m]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int b = blockIdx.y, blk = blockIdx.x;
-  const int64_t slice0 = (int64_t)blk * kSlice;
+  const int64_t slice0 = (int64_t)blk * ((int64_t)blockDim.x * kEpt);
   T xr[kEpt];
   load_own<T, VEC>(xr, x + (int64_t)b * ldx, slice0, n, tid);
   const T* rb = rows + (int64_t)b * rows_ldb;
-
-  for (int j = 0; j < m; ++j) {
+  constexpr int JT = 4;  // rows in flight per thread: 4 x 8 elements of loads before the first use
+  int j = 0;
+  for (; j + JT <= m; j += JT) {
+    T rr[JT][kEpt];
+#pragma unroll
+    for (int q = 0; q < JT; ++q) load_own<T, VEC>(rr[q], rb + (int64_t)(j + q) * row_stride, slice0, n, tid);
+#pragma unroll
+    for (int q = 0; q < JT; ++q) {
+      T acc = T(0);
+#pragma unroll
+      for (int e = 0; e < kEpt; ++e) acc += rr[q][e] * xr[e];
+      acc = wave_sum(acc);
+      if (lane == 0) sm[wid * m + j + q] = acc;
+    }
+  }
+  for (; j < m; ++j) {
     T rr[kEpt];
     load_own<T, VEC>(rr, rb + (int64_t)j * row_stride, slice0, n, tid);
     T acc = T(0);
@@ -87,8 +101,12 @@ __global__ __launch_bounds__(kBlock) void k_dots(const T* __restrict__ rows, int
     if (lane == 0) sm[wid * m + j] = acc;
   }
   __syncthreads();
-  for (int j = tid; j < m; j += kBlock)
-    partial[((int64_t)b * kmax + j) * nblk + blk] = sm[j] + sm[m + j] + sm[2 * m + j] + sm[3 * m + j];
+  for (int j = tid; j < m; j += (int)blockDim.x)
+  {
+    T sum = T(0);
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sum += sm[w * m + j];
+    partial[((int64_t)b * kmax + j) * nblk + blk] = sum;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -127,9 +145,9 @@ __global__ __launch_bounds__(kBlock) void k_update(UpdateArgs<T> a) {
   T* sm = coef + a.m;                         // [4][m] (DOTS) ; [4] (NORM) after that
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int b = blockIdx.y, blk = blockIdx.x;
-  const int64_t slice0 = (int64_t)blk * kSlice;
+  const int64_t slice0 = (int64_t)blk * ((int64_t)blockDim.x * kEpt);
   const int m = a.m;
-  for (int j = tid; j < m; j += kBlock) {
+  for (int j = tid; j < m; j += (int)blockDim.x) {
     T c = T(0);
     if (a.partial_in) c = a.s1 * reduce_partials(a.partial_in + ((int64_t)b * a.kmax + j) * a.nblk, a.nblk);
     if (a.extra) c += a.s2 * a.extra[(int64_t)b * a.extra_ldb + (int64_t)j * a.extra_stride];
@@ -145,19 +163,46 @@ __global__ __launch_bounds__(kBlock) void k_update(UpdateArgs<T> a) {
     for (int e = 0; e < kEpt; ++e) xr[e] = T(0);
   }
   const T* rb = a.rows + (int64_t)b * a.rows_ldb;
-
-  for (int j = 0; j < m; ++j) {
-    T rr[kEpt];
-    load_own<T, VEC>(rr, rb + (int64_t)j * a.row_stride, slice0, a.n, tid);
-    const T c = coef[j];
+  constexpr int JT = 4;  // rows in flight per thread
+  {
+    int j = 0;
+    for (; j + JT <= m; j += JT) {
+      T rr[JT][kEpt];
 #pragma unroll
-    for (int e = 0; e < kEpt; ++e) xr[e] -= c * rr[e];
+      for (int q = 0; q < JT; ++q) load_own<T, VEC>(rr[q], rb + (int64_t)(j + q) * a.row_stride, slice0, a.n, tid);
+#pragma unroll
+      for (int q = 0; q < JT; ++q) {
+        const T c = coef[j + q];
+#pragma unroll
+        for (int e = 0; e < kEpt; ++e) xr[e] -= c * rr[q][e];
+      }
+    }
+    for (; j < m; ++j) {
+      T rr[kEpt];
+      load_own<T, VEC>(rr, rb + (int64_t)j * a.row_stride, slice0, a.n, tid);
+      const T c = coef[j];
+#pragma unroll
+      for (int e = 0; e < kEpt; ++e) xr[e] -= c * rr[e];
+    }
   }
   store_own<T, VEC>(xr, a.y + (int64_t)b * a.ldy, slice0, a.n, tid);
   if (a.y2) store_own<T, VEC>(xr, a.y2 + (int64_t)b * a.ldy2, slice0, a.n, tid);
   if constexpr (DOTS) {
-
-    for (int j = 0; j < m; ++j) {
+    int j = 0;
+    for (; j + JT <= m; j += JT) {
+      T rr[JT][kEpt];
+#pragma unroll
+      for (int q = 0; q < JT; ++q) load_own<T, VEC>(rr[q], rb + (int64_t)(j + q) * a.row_stride, slice0, a.n, tid);
+#pragma unroll
+      for (int q = 0; q < JT; ++q) {
+        T acc = T(0);
+#pragma unroll
+        for (int e = 0; e < kEpt; ++e) acc += rr[q][e] * xr[e];
+        acc = wave_sum(acc);
+        if (lane == 0) sm[wid * m + j + q] = acc;
+      }
+    }
+    for (; j < m; ++j) {
       T rr[kEpt];
       load_own<T, VEC>(rr, rb + (int64_t)j * a.row_stride, slice0, a.n, tid);
       T acc = T(0);
@@ -167,9 +212,12 @@ __global__ __launch_bounds__(kBlock) void k_update(UpdateArgs<T> a) {
       if (lane == 0) sm[wid * m + j] = acc;
     }
     __syncthreads();
-    for (int j = tid; j < m; j += kBlock)
-      a.partial_out[((int64_t)b * a.kmax + j) * a.nblk + blk] =
-          sm[j] + sm[m + j] + sm[2 * m + j] + sm[3 * m + j];
+    for (int j = tid; j < m; j += (int)blockDim.x)
+    {
+      T sum = T(0);
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sum += sm[w * m + j];
+      a.partial_out[((int64_t)b * a.kmax + j) * a.nblk + blk] = sum;
+    }
   }
   if constexpr (NORM) {
     T* smn = sm + (DOTS ? 4 * m : 0);
@@ -179,7 +227,11 @@ __global__ __launch_bounds__(kBlock) void k_update(UpdateArgs<T> a) {
     acc = wave_sum(acc);
     if (lane == 0) smn[wid] = acc;
     __syncthreads();
-    if (tid == 0) a.partial_norm[(int64_t)b * a.nblk + blk] = smn[0] + smn[1] + smn[2] + smn[3];
+    if (tid == 0) {
+      T sum = T(0);
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sum += smn[w];
+      a.partial_norm[(int64_t)b * a.nblk + blk] = sum;
+    }
   }
 }
 
@@ -193,14 +245,18 @@ __global__ __launch_bounds__(kBlock) void k_sumsq(const T* __restrict__ x, int64
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int b = blockIdx.y, blk = blockIdx.x;
   T xr[kEpt];
-  load_own<T, VEC>(xr, x + (int64_t)b * ldx, (int64_t)blk * kSlice, n, tid);
+  load_own<T, VEC>(xr, x + (int64_t)b * ldx, (int64_t)blk * ((int64_t)blockDim.x * kEpt), n, tid);
   T acc = T(0);
 #pragma unroll
   for (int e = 0; e < kEpt; ++e) acc += xr[e] * xr[e];
   acc = wave_sum(acc);
   if (lane == 0) smn[wid] = acc;
   __syncthreads();
-  if (tid == 0) partial_norm[(int64_t)b * nblk + blk] = smn[0] + smn[1] + smn[2] + smn[3];
+  if (tid == 0) {
+    T sum = T(0);
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sum += smn[w];
+    partial_norm[(int64_t)b * nblk + blk] = sum;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -238,10 +294,10 @@ __global__ __launch_bounds__(kBlock) void k_scale(const T* __restrict__ x, int64
   if (!y) return;
   const T f = f_sh;
   T xr[kEpt];
-  load_own<T, VEC>(xr, x + (int64_t)b * ldx, (int64_t)blk * kSlice, n, tid);
+  load_own<T, VEC>(xr, x + (int64_t)b * ldx, (int64_t)blk * ((int64_t)blockDim.x * kEpt), n, tid);
 #pragma unroll
   for (int e = 0; e < kEpt; ++e) xr[e] *= f;
-  store_own<T, VEC>(xr, y + (int64_t)b * ldy, (int64_t)blk * kSlice, n, tid);
+  store_own<T, VEC>(xr, y + (int64_t)b * ldy, (int64_t)blk * ((int64_t)blockDim.x * kEpt), n, tid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -304,7 +360,7 @@ __global__ __launch_bounds__(kBlock) void k_adj_combine(CombineArgs<T> a) {
   const int64_t kk = (int64_t)k * k;
   const T* Hb = a.H + (int64_t)b * kk;
   T* Gb = a.Gam + (int64_t)b * kk;
-  for (int j = tid; j < k; j += kBlock) {
+  for (int j = tid; j < k; j += (int)blockDim.x) {
     T gj;
     if (j <= idx) {
       const T zq = reduce_partials(a.partial + ((int64_t)b * a.kmax + j) * a.nblk, a.nblk);
@@ -323,7 +379,7 @@ __global__ __launch_bounds__(kBlock) void k_adj_combine(CombineArgs<T> a) {
   const T alpha = Hb[(int64_t)idx * k + idx];
   const T bminus = (idx == 0) ? T(1) : Hb[(int64_t)idx * k + idx - 1];
   const T eta_i = a.eta[(int64_t)b * k + idx];
-  const int64_t slice0 = (int64_t)blk * kSlice;
+  const int64_t slice0 = (int64_t)blk * ((int64_t)blockDim.x * kEpt);
   const int64_t n = a.n;
   const T* Qb = a.Q + (int64_t)b * k * n;
   const T* Lb = a.Lam + (int64_t)b * k * n;
@@ -340,19 +396,44 @@ __global__ __launch_bounds__(kBlock) void k_adj_combine(CombineArgs<T> a) {
 #pragma unroll
     for (int e = 0; e < kEpt; ++e) acc[e] += t[e];
   }
-
-  for (int j = 0; j < k; ++j) {
-    load_own<T, VEC>(t, Qb + (int64_t)j * n, slice0, n, tid);
-    const T gj = g[j];
+  constexpr int JT = 4;  // rows in flight per thread
+  {
+    int j = 0;
+    for (; j + JT <= k; j += JT) {
+      T rr[JT][kEpt];
 #pragma unroll
-    for (int e = 0; e < kEpt; ++e) acc[e] += gj * t[e];
-  }
-
-  for (int j = idx + 1; j < k; ++j) {
-    load_own<T, VEC>(t, Lb + (int64_t)j * n, slice0, n, tid);
-    const T hj = hp[j];
+      for (int q = 0; q < JT; ++q) load_own<T, VEC>(rr[q], Qb + (int64_t)(j + q) * n, slice0, n, tid);
 #pragma unroll
-    for (int e = 0; e < kEpt; ++e) acc[e] -= hj * t[e];
+      for (int q = 0; q < JT; ++q) {
+        const T gj = g[j + q];
+#pragma unroll
+        for (int e = 0; e < kEpt; ++e) acc[e] += gj * rr[q][e];
+      }
+    }
+    for (; j < k; ++j) {
+      load_own<T, VEC>(t, Qb + (int64_t)j * n, slice0, n, tid);
+      const T gj = g[j];
+#pragma unroll
+      for (int e = 0; e < kEpt; ++e) acc[e] += gj * t[e];
+    }
+    j = idx + 1;
+    for (; j + JT <= k; j += JT) {
+      T rr[JT][kEpt];
+#pragma unroll
+      for (int q = 0; q < JT; ++q) load_own<T, VEC>(rr[q], Lb + (int64_t)(j + q) * n, slice0, n, tid);
+#pragma unroll
+      for (int q = 0; q < JT; ++q) {
+        const T hj = hp[j + q];
+#pragma unroll
+        for (int e = 0; e < kEpt; ++e) acc[e] -= hj * rr[q][e];
+      }
+    }
+    for (; j < k; ++j) {
+      load_own<T, VEC>(t, Lb + (int64_t)j * n, slice0, n, tid);
+      const T hj = hp[j];
+#pragma unroll
+      for (int e = 0; e < kEpt; ++e) acc[e] -= hj * t[e];
+    }
   }
   const T inv = T(1) / bminus;
 #pragma unroll
@@ -374,7 +455,7 @@ __global__ __launch_bounds__(kBlock) void k_lz_adj_dots(const T* __restrict__ xj
   __shared__ T sm[4][3];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int b = blockIdx.y, blk = blockIdx.x;
-  const int64_t slice0 = (int64_t)blk * kSlice;
+  const int64_t slice0 = (int64_t)blk * ((int64_t)blockDim.x * kEpt);
   T x0[kEpt], x1[kEpt], xv[kEpt], lp[kEpt];
   load_own<T, VEC>(x0, xj + (int64_t)b * ldxs, slice0, n, tid);
   load_own<T, VEC>(x1, xj1 + (int64_t)b * ldxs, slice0, n, tid);
@@ -401,7 +482,11 @@ __global__ __launch_bounds__(kBlock) void k_lz_adj_dots(const T* __restrict__ xj
     sm[wid][2] = d2;
   }
   __syncthreads();
-  if (tid < 3) partial[((int64_t)b * 3 + tid) * nblk + blk] = sm[0][tid] + sm[1][tid] + sm[2][tid] + sm[3][tid];
+  if (tid < 3) {
+    T sum = T(0);
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sum += sm[w][tid];
+    partial[((int64_t)b * 3 + tid) * nblk + blk] = sum;
+  }
 }
 
 template <typename T, int VEC>
@@ -432,7 +517,7 @@ __global__ __launch_bounds__(kBlock) void k_lz_adj_lambda(const T* __restrict__ 
   }
   __syncthreads();
   const T mu = sc[0], nu = sc[1], ib = sc[2];
-  const int64_t slice0 = (int64_t)blk * kSlice;
+  const int64_t slice0 = (int64_t)blk * ((int64_t)blockDim.x * kEpt);
   T x0[kEpt], x1[kEpt], xv[kEpt];
   load_own<T, VEC>(x0, xj + (int64_t)b * ldxs, slice0, n, tid);
   load_own<T, VEC>(x1, xj1 + (int64_t)b * ldxs, slice0, n, tid);
@@ -454,7 +539,7 @@ __global__ __launch_bounds__(kBlock) void k_lz_adj_xi(const T* __restrict__ dxj,
   const int b = blockIdx.y, blk = blockIdx.x;
   const T aj = alpha[(int64_t)b * k + j], bj = beta[(int64_t)b * k + j];
   const T nu = munu[(int64_t)b * 2 + 1];
-  const int64_t slice0 = (int64_t)blk * kSlice;
+  const int64_t slice0 = (int64_t)blk * ((int64_t)blockDim.x * kEpt);
   T acc[kEpt], t[kEpt];
   load_own<T, VEC>(acc, Alam + (int64_t)b * n, slice0, n, tid);
 #pragma unroll
@@ -510,7 +595,7 @@ __global__ __launch_bounds__(kBlock) void k_lz_adj_dvec(const T* __restrict__ x0
   }
   __syncthreads();
   const T d = sc[0], inv = sc[1];
-  const int64_t slice0 = (int64_t)blk * kSlice;
+  const int64_t slice0 = (int64_t)blk * ((int64_t)blockDim.x * kEpt);
   T a[kEpt], x[kEpt];
   load_own<T, VEC>(a, xi + (int64_t)b * n, slice0, n, tid);
   load_own<T, VEC>(x, x0 + (int64_t)b * ldxs, slice0, n, tid);
@@ -540,11 +625,19 @@ static int pick_vec(int64_t n, std::initializer_list<const void*> ptrs) {
     __VA_ARGS__;                                \
   }
 
+// workgroup size of the vector kernels: 256 threads (2048-element slices); one wave (512-element slices) only for
+// tiny problems.  (Measured on config 3, n = 102400, p = 1: 50 workgroups x 4 waves beat 200 x 1 wave -- what
+// counts is loads in flight per CU, not the number of CUs touched.)
+static int pick_wg(int64_t n, int64_t p) { return ((n + kSlice - 1) / kSlice) * p >= 16 ? kBlock : 64; }
+
 template <typename T>
 struct Ctx {
   int64_t n, k, p;
-  int nblk, kmax, vec;
+  int wg, nblk, kmax, vec;
   hipStream_t stream;
+  Ctx(int64_t n_, int64_t k_, int64_t p_, int vec_, hipStream_t s)
+      : n(n_), k(k_), p(p_), wg(pick_wg(n_, p_)), nblk((int)((n_ + (int64_t)wg * kEpt - 1) / ((int64_t)wg * kEpt))),
+        kmax((int)(k_ + 1)), vec(vec_), stream(s) {}
   dim3 grid() const { return dim3(nblk, (unsigned)p); }
 };
 
@@ -553,7 +646,7 @@ static int launch_dots(const Ctx<T>& c, const T* rows, int64_t rows_ldb, int64_t
                        const T* x, int64_t ldx, T* partial) {
   if (m <= 0) return MFX_OK;
   const size_t sh = (size_t)4 * m * sizeof(T);
-  MFX_VEC_SWITCH(c.vec, (k_dots<T, VEC><<<c.grid(), kBlock, sh, c.stream>>>(
+  MFX_VEC_SWITCH(c.vec, (k_dots<T, VEC><<<c.grid(), c.wg, sh, c.stream>>>(
                             rows, rows_ldb, row_stride, m, x, ldx, c.n, partial, c.kmax, c.nblk)));
   MFX_CHECK_LAUNCH();
   return MFX_OK;
@@ -566,13 +659,13 @@ static int launch_update(const Ctx<T>& c, UpdateArgs<T> a, bool dots, bool norm)
   a.nblk = c.nblk;
   const size_t sh = (size_t)(a.m + (dots ? 4 * a.m : 0) + 4) * sizeof(T);
   if (dots && norm) {
-    MFX_VEC_SWITCH(c.vec, (k_update<T, VEC, true, true><<<c.grid(), kBlock, sh, c.stream>>>(a)));
+    MFX_VEC_SWITCH(c.vec, (k_update<T, VEC, true, true><<<c.grid(), c.wg, sh, c.stream>>>(a)));
   } else if (dots) {
-    MFX_VEC_SWITCH(c.vec, (k_update<T, VEC, true, false><<<c.grid(), kBlock, sh, c.stream>>>(a)));
+    MFX_VEC_SWITCH(c.vec, (k_update<T, VEC, true, false><<<c.grid(), c.wg, sh, c.stream>>>(a)));
   } else if (norm) {
-    MFX_VEC_SWITCH(c.vec, (k_update<T, VEC, false, true><<<c.grid(), kBlock, sh, c.stream>>>(a)));
+    MFX_VEC_SWITCH(c.vec, (k_update<T, VEC, false, true><<<c.grid(), c.wg, sh, c.stream>>>(a)));
   } else {
-    MFX_VEC_SWITCH(c.vec, (k_update<T, VEC, false, false><<<c.grid(), kBlock, sh, c.stream>>>(a)));
+    MFX_VEC_SWITCH(c.vec, (k_update<T, VEC, false, false><<<c.grid(), c.wg, sh, c.stream>>>(a)));
   }
   MFX_CHECK_LAUNCH();
   return MFX_OK;
@@ -580,7 +673,7 @@ static int launch_update(const Ctx<T>& c, UpdateArgs<T> a, bool dots, bool norm)
 
 template <typename T>
 static int launch_sumsq(const Ctx<T>& c, const T* x, int64_t ldx, T* partial_norm) {
-  MFX_VEC_SWITCH(c.vec, (k_sumsq<T, VEC><<<c.grid(), kBlock, 0, c.stream>>>(x, ldx, c.n, partial_norm, c.nblk)));
+  MFX_VEC_SWITCH(c.vec, (k_sumsq<T, VEC><<<c.grid(), c.wg, 0, c.stream>>>(x, ldx, c.n, partial_norm, c.nblk)));
   MFX_CHECK_LAUNCH();
   return MFX_OK;
 }
@@ -589,7 +682,7 @@ template <typename T>
 static int launch_scale(const Ctx<T>& c, const T* x, int64_t ldx, T* y, int64_t ldy, const T* partial_norm,
                         const T* scale, int mode, T* len_out, int64_t len_ld, T* inv_out) {
   dim3 grid = y ? c.grid() : dim3(1, (unsigned)c.p);
-  MFX_VEC_SWITCH(c.vec, (k_scale<T, VEC><<<grid, kBlock, 0, c.stream>>>(x, ldx, y, ldy, c.n, partial_norm, c.nblk,
+  MFX_VEC_SWITCH(c.vec, (k_scale<T, VEC><<<grid, c.wg, 0, c.stream>>>(x, ldx, y, ldy, c.n, partial_norm, c.nblk,
                                                                         scale, mode, len_out, len_ld, inv_out)));
   MFX_CHECK_LAUNCH();
   return MFX_OK;
@@ -611,7 +704,7 @@ struct KrylovWs {
 static int64_t carve_ws(const mfx_operator* op, int64_t n, int64_t k, int64_t p, void* ws, int64_t ws_bytes,
                         KrylovWs* out) {
   const size_t es = dtype_size(op->dtype);
-  const int64_t nblk = num_slices(n);
+  const int64_t nblk = (n + 64 * kEpt - 1) / (64 * kEpt);  // the finest slicing the drivers may choose
   const int64_t kmax = k + 1;
   Carver cv(ws, ws_bytes);
   KrylovWs r;
@@ -633,7 +726,7 @@ template <typename T>
 static int arnoldi_forward_t(const mfx_operator* op, const T* v0, int64_t n, int64_t k, int64_t p,
                              int second_pass, T* Q, T* H, T* r, T* cinv, const KrylovWs& ws,
                              hipStream_t stream) {
-  Ctx<T> c{n, k, p, (int)num_slices(n), (int)(k + 1), pick_vec<T>(n, {v0, Q, r, ws.w}), stream};
+  Ctx<T> c(n, k, p, pick_vec<T>(n, {v0, Q, r, ws.w}), stream);
   T* P1 = static_cast<T*>(ws.p1);
   T* P2 = static_cast<T*>(ws.p2);
   T* PN = static_cast<T*>(ws.pn);
@@ -678,7 +771,7 @@ static int arnoldi_adjoint_t(const mfx_operator* op, int64_t n, int64_t k, int64
                              const T* r, const T* cinv, const T* dQ, const T* dH, const T* dr, const T* dc,
                              int reortho, T* dv, T* Lam, const mfx_op_grads* grads, const KrylovWs& ws,
                              hipStream_t stream) {
-  Ctx<T> c{n, k, p, (int)num_slices(n), (int)(k + 1), pick_vec<T>(n, {Q, r, dQ, dr, dv, Lam, ws.w}), stream};
+  Ctx<T> c(n, k, p, pick_vec<T>(n, {Q, r, dQ, dr, dv, Lam, ws.w}), stream);
   T* P1 = static_cast<T*>(ws.p1);
   T* lam = static_cast<T*>(ws.w);  // current lambda (p, n)
   T* z = lam + p * n;              // A^T lambda     (p, n)
@@ -730,7 +823,7 @@ static int arnoldi_adjoint_t(const mfx_operator* op, int64_t n, int64_t k, int64
     MFX_TRY(launch_dots<T>(c, Q, ldq, n, (int)(idx + 1), z, n, P1));
     CombineArgs<T> ca{Q, Lam, H, pig, eta, r, dQ, z, P1, Gam, lam, n, (int)k, (int)idx, c.kmax, c.nblk};
     const size_t sh = (size_t)2 * k * sizeof(T);
-    MFX_VEC_SWITCH(c.vec, (k_adj_combine<T, VEC><<<c.grid(), kBlock, sh, stream>>>(ca)));
+    MFX_VEC_SWITCH(c.vec, (k_adj_combine<T, VEC><<<c.grid(), c.wg, sh, stream>>>(ca)));
     MFX_CHECK_LAUNCH();
   }
   {
@@ -747,7 +840,7 @@ static int arnoldi_adjoint_t(const mfx_operator* op, int64_t n, int64_t k, int64
 template <typename T>
 static int lanczos_forward_t(const mfx_operator* op, const T* v0, int64_t n, int64_t k, int64_t p, T* xs,
                              T* alpha, T* beta, T* vnorm, const KrylovWs& ws, hipStream_t stream) {
-  Ctx<T> c{n, k, p, (int)num_slices(n), (int)(k + 1), pick_vec<T>(n, {v0, xs, ws.w}), stream};
+  Ctx<T> c(n, k, p, pick_vec<T>(n, {v0, xs, ws.w}), stream);
   T* P1 = static_cast<T*>(ws.p1);
   T* PN = static_cast<T*>(ws.pn);
   T* w = static_cast<T*>(ws.w);
@@ -779,7 +872,7 @@ template <typename T>
 static int lanczos_adjoint_t(const mfx_operator* op, int64_t n, int64_t k, int64_t p, const T* xs, const T* alpha,
                              const T* beta, const T* vnorm, const T* dxs, const T* dalpha, const T* dbeta, T* dv,
                              T* Lam, const mfx_op_grads* grads, const KrylovWs& ws, hipStream_t stream) {
-  Ctx<T> c{n, k, p, (int)num_slices(n), (int)(k + 1), pick_vec<T>(n, {xs, dxs, dv, Lam, ws.w}), stream};
+  Ctx<T> c(n, k, p, pick_vec<T>(n, {xs, dxs, dv, Lam, ws.w}), stream);
   T* P1 = static_cast<T*>(ws.p1);
   T* PN = static_cast<T*>(ws.pn);
   T* xi = static_cast<T*>(ws.w);
@@ -799,16 +892,16 @@ static int lanczos_adjoint_t(const mfx_operator* op, int64_t n, int64_t k, int64
     T* lam_j = Lam + j * n;
     {
       ScopedTimer t(2, stream);
-      MFX_VEC_SWITCH(c.vec, (k_lz_adj_dots<T, VEC><<<c.grid(), kBlock, 0, stream>>>(xj, xj1, ldx, xi, lam_plus, ldl, n, PN, c.nblk)));
+      MFX_VEC_SWITCH(c.vec, (k_lz_adj_dots<T, VEC><<<c.grid(), c.wg, 0, stream>>>(xj, xj1, ldx, xi, lam_plus, ldl, n, PN, c.nblk)));
       MFX_CHECK_LAUNCH();
-      MFX_VEC_SWITCH(c.vec, (k_lz_adj_lambda<T, VEC><<<c.grid(), kBlock, 0, stream>>>(
+      MFX_VEC_SWITCH(c.vec, (k_lz_adj_lambda<T, VEC><<<c.grid(), c.wg, 0, stream>>>(
                                 xj, xj1, ldx, xi, n, PN, c.nblk, beta, dalpha, dbeta, (int)k, (int)j, lam_j, ldl, munu)));
       MFX_CHECK_LAUNCH();
     }
     // A lambda (Q4: not A^T), parameter gradient of x_j^T A(theta) lambda (lanczos.py:328-329)
     MFX_TRY(apply_any(op, 2, lam_j, ldl, xj, ldx, y, n, p, ws.opws, ws.opws_bytes, stream));
     ScopedTimer t(2, stream);
-    MFX_VEC_SWITCH(c.vec, (k_lz_adj_xi<T, VEC><<<c.grid(), kBlock, 0, stream>>>(
+    MFX_VEC_SWITCH(c.vec, (k_lz_adj_xi<T, VEC><<<c.grid(), c.wg, 0, stream>>>(
                               dxs ? dxs + j * n : nullptr, ldx, y, lam_j, ldl, lam_plus, ldl, xj1, ldx, n, alpha, beta,
                               (int)k, (int)j, munu, xi)));
     MFX_CHECK_LAUNCH();
@@ -816,7 +909,7 @@ static int lanczos_adjoint_t(const mfx_operator* op, int64_t n, int64_t k, int64
   {
     ScopedTimer t(2, stream);
     MFX_TRY(launch_dots<T>(c, xs, ldx, n, 1, xi, n, P1));  // xi . x_0 (Q3: "lambda_1" is the final xi)
-    MFX_VEC_SWITCH(c.vec, (k_lz_adj_dvec<T, VEC><<<c.grid(), kBlock, 0, stream>>>(xs, ldx, xi, n, P1, c.kmax, c.nblk, vnorm, dv)));
+    MFX_VEC_SWITCH(c.vec, (k_lz_adj_dvec<T, VEC><<<c.grid(), c.wg, 0, stream>>>(xs, ldx, xi, n, P1, c.kmax, c.nblk, vnorm, dv)));
     MFX_CHECK_LAUNCH();
   }
   if (op->kind != MFX_OP_CALLBACK && grads) {

@@ -423,3 +423,51 @@ def test_hutchinson_variants():
 def test_no_cpu_fallback():
     with pytest.raises(_lib.MfxError, match="no CPU fallback"):
         arnoldi.hessenberg(DenseOp(), 2, reortho="full")(torch.ones(4), torch.eye(4))
+
+
+def test_error_paths_on_device():
+    n = 16
+    A = T(np.eye(n) * 2.0)
+    v = T(np.ones(n))
+
+    def boom(x, p):
+        raise ZeroDivisionError("matvec failed on purpose")
+
+    with pytest.raises(ZeroDivisionError, match="on purpose"):  # exceptions in Python matvecs cross the C loop intact
+        arnoldi.hessenberg(boom, 3, reortho="full")(v, A)
+    # the on-device tridiagonal eigen-solver is LDS-resident: k <= 120
+    big = T(orc.spd_diag_plus_lowrank(256, 2, seed=0))
+    with pytest.raises(_lib.MfxError, match="k <= 120"):
+        lanczos.integrand_spd(torch.log, 121, DenseOp())(T(np.ones(256)), big)
+    # ... while plain tridiagonalisation has no such limit
+    (Q, (d, e)), _ = lanczos.tridiag(DenseOp(), 200, reortho="full")(T(np.ones(256) + np.arange(256) * 1e-3), big)
+    assert Q.shape == (200, 256) and torch.isfinite(d).all()
+    with pytest.raises(ValueError, match="square"):
+        DenseOp()(v, T(np.ones((n, n + 1))))
+    with pytest.raises(TypeError):
+        arnoldi.hessenberg(DenseOp(), 3, reortho="full")(v.to(torch.float16), A.to(torch.float16))
+    out = arnoldi.hessenberg(DenseOp(), 3, reortho="full", custom_vjp=False)(T(np.ones(n), grad=True), A)
+    with pytest.raises(RuntimeError, match="not differentiable"):
+        out[1].sum().backward()
+
+
+def test_pytree_start_vector_and_matfuns():
+    """lanczos.py:24,28-33: integrand_spd ravels a pytree v0 and unravels it for the matvec."""
+    n1, n2, k = 5, 7, 6
+    rng = np.random.default_rng(8)
+    A = orc.symmetric_matrix_from_eigenvalues(np.linspace(1.0, 3.0, n1 + n2), seed=8)
+    At = T(A, grad=True)
+
+    def matvec(tree, p):
+        flat = torch.cat([tree["a"].reshape(-1), tree["b"].reshape(-1)])
+        out = p @ flat
+        return {"a": out[:n1], "b": out[n1:].reshape(n2, 1)}
+
+    v0 = {"a": T(rng.standard_normal(n1)), "b": T(rng.standard_normal((n2, 1)))}
+    flat = np.concatenate([N(v0["a"]), N(v0["b"]).ravel()])
+    for name, fn in (("log", torch.log), ("exp", torch.exp), ("inv", lambda x: 1.0 / x), ("sqrt", torch.sqrt)):
+        val = lanczos.integrand_spd(fn, k, matvec)(v0, At)
+        (g,) = torch.autograd.grad(val, At)
+        rv, _, (rg,) = orc.integrand_spd_value_and_grad(orc.DenseOp(), k, flat, (A,), matfun=name)
+        assert close(val, rv, 1e-9), name
+        assert close(g, rg, 1e-7, atol_rel=1e-7), name
