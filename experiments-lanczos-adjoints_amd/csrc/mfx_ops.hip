@@ -279,13 +279,19 @@ __global__ __launch_bounds__(256) void k_rbf_grad(const T* __restrict__ xs, cons
 
 // grads += factors * sum_blocks partial  (chain to the constrained parameters l, s, noise)
 template <typename T>
-__global__ void k_rbf_grad_final(const double* __restrict__ partial, int64_t nblocks, int dpad, int d, int ard,
-                                 const T* __restrict__ ls, const T* __restrict__ outputscale, T* __restrict__ g_ls,
-                                 T* __restrict__ g_s, T* __restrict__ g_noise, const float* __restrict__ scales) {
-  const int c = threadIdx.x;
-  if (c >= dpad + 2) return;
+__global__ __launch_bounds__(256) void k_rbf_grad_final(const double* __restrict__ partial, int64_t nblocks, int dpad, int d,
+                                                        int ard, const T* __restrict__ ls, const T* __restrict__ outputscale,
+                                                        T* __restrict__ g_ls, T* __restrict__ g_s, T* __restrict__ g_noise,
+                                                        const float* __restrict__ scales) {
+  __shared__ double sm[4];
+  const int c = blockIdx.x;  // one workgroup per output column, fixed summation order (deterministic)
   double acc = 0.0;
-  for (int64_t q = 0; q < nblocks; ++q) acc += partial[q * (dpad + 2) + c];
+  for (int64_t q = threadIdx.x; q < nblocks; q += 256) acc += partial[q * (dpad + 2) + c];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  acc = sm[0] + sm[1] + sm[2] + sm[3];
   if (scales) acc *= (double)scales[1] * (double)scales[3];  // undo the power-of-two operand scales of the split GEMM
   const double s = (double)outputscale[0];
   if (c < dpad) {
@@ -321,7 +327,7 @@ static int64_t rbf_carve(const mfx_operator* op, void* ws, int64_t ws_bytes, Rbf
   r.sq = cv.take(op->n * es);
   // per-workgroup gradient partials: VALU sweep n/256 rows, MFMA sweep 8 * n/128 rows, <= 34 doubles each
   r.partial = static_cast<double*>(cv.take(((op->n + 127) / 128) * 8 * 34 * sizeof(double)));
-  r.vscale = static_cast<float*>(cv.take(65536 * 2 * sizeof(float)));
+  r.vscale = static_cast<float*>(cv.take(65536 * 3 * sizeof(float)));  // [s, 1/s] per row + |max| bit patterns
   r.hws_bytes = (op->dtype == MFX_F32 && rbf_mode(op) == MFX_RBF_F16X3 && batch_hint > 0) ? rbf_grad_h_ws_bytes(op->n, batch_hint) : 0;
   r.hws = r.hws_bytes ? cv.take(r.hws_bytes) : nullptr;
   if (out) *out = r;
@@ -435,7 +441,7 @@ static int rbf_grad(const mfx_operator* op, const T* L, int64_t ldl, const T* R,
 #undef MFX_RBF_GRAD
     MFX_CHECK_LAUNCH();
   }
-  k_rbf_grad_final<T><<<1, 64, 0, stream>>>(w.partial, nblocks, dpad, op->d, op->ard, (const T*)op->lengthscale,
+  k_rbf_grad_final<T><<<dpad + 2, 256, 0, stream>>>(w.partial, nblocks, dpad, op->d, op->ard, (const T*)op->lengthscale,
                                             (const T*)op->outputscale, (T*)grads->lengthscale,
                                             (T*)grads->outputscale, (T*)grads->noise, scales);
   MFX_CHECK_LAUNCH();
