@@ -125,6 +125,31 @@ __global__ __launch_bounds__(256) void k_csr_grad(const int32_t* __restrict__ ro
 // ================================================================================================
 __device__ __forceinline__ float exp_neg_half(float d) { return __expf(-0.5f * d); }
 __device__ __forceinline__ double exp_neg_half(double d) { return exp(-0.5 * d); }
+__device__ __forceinline__ float exp_neg(float r) { return __expf(-r); }
+__device__ __forceinline__ double exp_neg(double r) { return exp(-r); }
+template <typename T> __device__ __forceinline__ T dtype_eps();
+template <> __device__ __forceinline__ float dtype_eps<float>() { return 1.1920928955078125e-7f; }
+template <> __device__ __forceinline__ double dtype_eps<double>() { return 2.220446049250313e-16; }
+
+// K_ij / outputscale and the lengthscale weight w (dK_ij/dl_c = outputscale w (x_ic - x_jc)^2 / l_c^3) from the clamped
+// scaled squared distance (util/gp_util.py:69-184; kinds = MFX_KERNEL_*)
+template <typename T>
+__device__ __forceinline__ void kernel_eval(int kind, T dist, T& kv, T& wl) {
+  if (kind == MFX_KERNEL_RBF) {
+    kv = exp_neg_half(dist);
+    wl = kv;
+  } else if (kind == MFX_KERNEL_MATERN32) {
+    const T r = sqrt(T(3) * dist + dtype_eps<T>());
+    const T e = exp_neg(r);
+    kv = (T(1) + r) * e;
+    wl = T(3) * e;
+  } else {
+    const T r = sqrt(dist + dtype_eps<T>());
+    const T e = exp_neg(r);
+    kv = e;
+    wl = dist > T(0) ? e / r : T(0);  // d max(0, s)/ds = 0 on the clamped side
+  }
+}
 
 // xs[i][c] = X[i][c] / l_c (zero padded to DPAD), sq[i] = |xs_i|^2
 template <typename T>
@@ -148,7 +173,7 @@ template <typename T, int DPAD, int PB>
 __global__ __launch_bounds__(256) void k_rbf_apply(const T* __restrict__ xs, const T* __restrict__ sq, int64_t n,
                                                    const T* __restrict__ outputscale, const T* __restrict__ noise,
                                                    const T* __restrict__ x, int64_t ldx, T* __restrict__ y,
-                                                   int64_t ldy, int64_t p) {
+                                                   int64_t ldy, int64_t p, int kind) {
   __shared__ __attribute__((aligned(16))) T xj[kRbfTJ][DPAD];
   __shared__ T sqj[kRbfTJ];
   __shared__ T vj[PB][kRbfTJ];
@@ -181,7 +206,13 @@ __global__ __launch_bounds__(256) void k_rbf_apply(const T* __restrict__ xs, con
       for (int c = 0; c < DPAD; ++c) dot += xi[c] * xj[jj][c];
       T dist = sqi + sqj[jj] - T(2) * dot;
       dist = dist > T(0) ? dist : T(0);
-      const T kv = exp_neg_half(dist);
+      T kv, wl;
+      if (kind == MFX_KERNEL_RBF) {
+        kv = exp_neg_half(dist);
+      } else {
+        if (j0 + jj == i) dist = T(0);  // a point's distance to itself is exactly 0 (sqrt amplifies round-off)
+        kernel_eval<T>(kind, dist, kv, wl);
+      }
 #pragma unroll
       for (int q = 0; q < PB; ++q) acc[q] += kv * vj[q][jj];
     }
@@ -203,7 +234,7 @@ constexpr int kGradBC = 32;
 
 template <typename T, int DPAD>
 __global__ __launch_bounds__(256) void k_rbf_grad(const T* __restrict__ xs, const T* __restrict__ sq, int64_t n,
-                                                  int ard, const T* __restrict__ L, int64_t ldl,
+                                                  int ard, int kind, const T* __restrict__ L, int64_t ldl,
                                                   const T* __restrict__ R, int64_t ldr, int64_t batch,
                                                   double* __restrict__ partial /* (nblocks, DPAD + 2) */) {
   __shared__ __attribute__((aligned(16))) T xj[kGradTJ][DPAD];
@@ -254,8 +285,11 @@ __global__ __launch_bounds__(256) void k_rbf_grad(const T* __restrict__ xs, cons
       for (int c = 0; c < DPAD; ++c) dot += xi[c] * xj[jj][c];
       T dist = sqi + sqj[jj] - T(2) * dot;
       dist = dist > T(0) ? dist : T(0);
-      const T w = S[jj] * exp_neg_half(dist);
-      g[DPAD] += (double)w;
+      if (kind != MFX_KERNEL_RBF && j0 + jj == i) dist = T(0);
+      T kv, wl;
+      kernel_eval<T>(kind, dist, kv, wl);
+      g[DPAD] += (double)(S[jj] * kv);
+      const T w = S[jj] * wl;
       if (ard) {
 #pragma unroll
         for (int c = 0; c < DPAD; ++c) {
@@ -364,7 +398,7 @@ static int rbf_apply_d(const mfx_operator* op, const RbfWs& w, const T* x, int64
   const unsigned gx = (unsigned)((op->n + 255) / 256);
 #define MFX_RBF_LAUNCH(PB)                                                                           \
   k_rbf_apply<T, DPAD, PB><<<dim3(gx, (unsigned)((p + PB - 1) / PB)), 256, 0, stream>>>(               \
-      (const T*)w.xs, (const T*)w.sq, op->n, (const T*)op->outputscale, (const T*)op->noise, x, ldx, y, ldy, p)
+      (const T*)w.xs, (const T*)w.sq, op->n, (const T*)op->outputscale, (const T*)op->noise, x, ldx, y, ldy, p, op->kernel_fn)
   if (p == 1) {
     MFX_RBF_LAUNCH(1);
   } else if (p == 2) {
@@ -391,7 +425,7 @@ static int rbf_apply(const mfx_operator* op, const T* x, int64_t ldx, T* y, int6
     if (rbf_mfma_supported(op, p)) {
       if (rbf_mode(op) >= MFX_RBF_F16X3_MATVEC)
         return rbf_mfma_apply_h3(op, (const float*)w.xs, (const float*)w.sq, dpad, x, ldx, y, ldy, p, w.vscale, stream);
-      if (rbf_mode(op) == -1)
+      if (rbf_mode(op) == -1 && op->kernel_fn == MFX_KERNEL_RBF)
         return rbf_mfma_apply_h(op, (const float*)w.xs, (const float*)w.sq, dpad, x, ldx, y, ldy, p, w.vscale, stream);
       return rbf_mfma_apply(op, (const float*)w.xs, (const float*)w.sq, dpad, x, ldx, y, ldy, p, stream);
     }
@@ -429,7 +463,7 @@ static int rbf_grad(const mfx_operator* op, const T* L, int64_t ldl, const T* R,
   }
   if (!done) {
 #define MFX_RBF_GRAD(D)                                                                                    \
-  k_rbf_grad<T, D><<<(unsigned)nblocks, 256, 0, stream>>>((const T*)w.xs, (const T*)w.sq, op->n, op->ard, L, ldl, R, \
+  k_rbf_grad<T, D><<<(unsigned)nblocks, 256, 0, stream>>>((const T*)w.xs, (const T*)w.sq, op->n, op->ard, op->kernel_fn, L, ldl, R, \
                                                            ldr, batch, w.partial)
     switch (dpad) {
       case 4: MFX_RBF_GRAD(4); break;

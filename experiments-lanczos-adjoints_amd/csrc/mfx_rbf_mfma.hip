@@ -31,6 +31,40 @@ constexpr int kGLd = kGM + 4;  // padded row of the transposed S tile: conflict-
 // -log2(e)/2: exp(-dist/2) = exp2(kNegHalfLog2e * dist)
 constexpr float kNegHalfLog2e = -0.72134752044448170368f;
 
+// Matern kernels: the distance product is scaled by log2(e)^2 (x 3 for nu = 3/2), so that r' = sqrt(t) is already
+// log2(e) * r:  K = exp2(-r') [nu = 1/2],  (1 + r'/log2(e)) exp2(-r') [nu = 3/2]   (util/gp_util.py:69-148)
+constexpr float kLog2e = 1.44269504088896340736f;
+constexpr float kLn2 = 0.69314718055994530942f;
+constexpr float kEpsF32 = 1.1920928955078125e-7f;
+__device__ __forceinline__ float dist_factor(int kind) {  // multiplies the squared distance inside the MFMA product
+  return kind == MFX_KERNEL_RBF ? -0.72134752044448170368f : (kind == MFX_KERNEL_MATERN32 ? 3.f : 1.f) * kLog2e * kLog2e;
+}
+// K / outputscale from t = factor * dist (un-clamped), shift = log2 of an optional power-of-two scale of K
+template <int KIND>
+__device__ __forceinline__ float matern_from_t(float t, float shift) {
+  const float rp = __builtin_sqrtf(fmaxf(t, 0.f) + kEpsF32 * kLog2e * kLog2e);
+  const float e = __builtin_amdgcn_exp2f(shift - rp);
+  return KIND == MFX_KERNEL_MATERN32 ? fmaf(e * rp, kLn2, e) : e;
+}
+
+// epilogue of the gradient GEMMs: K_ij / outputscale and the lengthscale weight from the clamped squared distance
+__device__ __forceinline__ void grad_weights(int kind, float dist, float& kv, float& wl) {
+  if (kind == MFX_KERNEL_RBF) {
+    kv = __builtin_amdgcn_exp2f(-0.72134752044448170368f * dist);
+    wl = kv;
+  } else if (kind == MFX_KERNEL_MATERN32) {
+    const float r = __builtin_sqrtf(3.f * dist + kEpsF32);
+    const float e = __builtin_amdgcn_exp2f(-kLog2e * r);
+    kv = (1.f + r) * e;
+    wl = 3.f * e;
+  } else {
+    const float r = __builtin_sqrtf(dist + kEpsF32);
+    const float e = __builtin_amdgcn_exp2f(-kLog2e * r);
+    kv = e;
+    wl = dist > 0.f ? e / r : 0.f;
+  }
+}
+
 // exp2(min(x, 0)) in ONE VALU instruction: v_exp_f32 with the clamp output modifier ([0, 1]); exp2 is
 // monotone, so clamping the result equals clamping the argument (the reference clamps the squared
 // distance at 0, util/gp_util.py:173).  fp32 MFMA shares the FP32 lanes with the VALU on gfx950
@@ -64,8 +98,9 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply(const float* __restri
                                                            int64_t n, const float* __restrict__ outputscale,
                                                            const float* __restrict__ noise,
                                                            const float* __restrict__ x, int64_t ldx,
-                                                           float* __restrict__ y, int64_t ldy, int64_t p) {
+                                                           float* __restrict__ y, int64_t ldy, int64_t p, int kind) {
   using Tile = RbfTile<DPAD, NB, kTJ>;
+  const float cfac = dist_factor(kind);
   constexpr int KD = Tile::KD, KS = KD / 2;
   __shared__ __attribute__((aligned(16))) Tile tile[2];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -142,11 +177,11 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply(const float* __restri
 #pragma unroll
     for (int u = 0; u < kXPT; ++u) {
       const int t = tid + 256 * u;
-      if (t < kTJ * DPAD) tl.aj[t % DPAD][t / DPAD] = -2.f * kNegHalfLog2e * rx[u];
+      if (t < kTJ * DPAD) tl.aj[t % DPAD][t / DPAD] = -2.f * cfac * rx[u];
     }
     if (tid < kTJ) {
-      tl.aj[DPAD][tid] = kNegHalfLog2e * rsq;
-      tl.aj[DPAD + 1][tid] = kNegHalfLog2e;
+      tl.aj[DPAD][tid] = cfac * rsq;
+      tl.aj[DPAD + 1][tid] = cfac;
     }
   };
 
@@ -169,8 +204,20 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply(const float* __restri
         for (int r = 0; r < 16; ++r) kd[r] = 0.f;
 #pragma unroll
         for (int s = 0; s < KS; ++s) kd = __builtin_amdgcn_mfma_f32_32x32x2f32(aj[s], bi[mi][s], kd, 0, 0, 0);
+        if (kind == MFX_KERNEL_RBF) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) kd[r] = exp2_clamped(kd[r]);
+          for (int r = 0; r < 16; ++r) kd[r] = exp2_clamped(kd[r]);
+        } else {
+          // the diagonal 32 x 32 block: a point's distance to itself is exactly 0
+          const bool diag_blk = (t * kTJ + jb * 32) == (i_wave + mi * 32);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float tv = kd[r];
+            if (diag_blk && l31 == (r & 3) + 8 * (r >> 2) + 4 * lhi) tv = 0.f;
+            kd[r] = kind == MFX_KERNEL_MATERN32 ? matern_from_t<MFX_KERNEL_MATERN32>(tv, 0.f)
+                                                : matern_from_t<MFX_KERNEL_MATERN12>(tv, 0.f);
+          }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int jr = jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
@@ -299,6 +346,7 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h(const float* __rest
                                                              const float* __restrict__ vscale,
                                                              const float* __restrict__ x, int64_t ldx,
                                                              float* __restrict__ y, int64_t ldy, int64_t p) {
+  constexpr float cfac = kNegHalfLog2e;  // RBF only (A/B variant of the pipelined kernel)
   constexpr int kMI = 2, kTJ = 64;
   using Tile = RbfTileH<DPAD, NB, kTJ>;
   constexpr int KD = Tile::KD, KS = KD / 2;
@@ -390,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h(const float* __rest
 #pragma unroll
     for (int u = 0; u < kXPT; ++u) {
       const int t = tid + 256 * u;
-      if (t < kTJ * DPAD) tl.aj[t % DPAD][t / DPAD] = -2.f * kNegHalfLog2e * rx[u];
+      if (t < kTJ * DPAD) tl.aj[t % DPAD][t / DPAD] = -2.f * cfac * rx[u];
     }
     if (tid < kTJ) {
       tl.aj[DPAD][tid] = kNegHalfLog2e * rsq + kKShift;  // K' = 2^15 K: keeps lo(K') a NORMAL f16 for K >= 4e-6
@@ -526,7 +574,7 @@ int rbf_mfma_apply_h(const mfx_operator* op, const float* xs, const float* sq, i
 // truncates its internal sum (tools/mfma_f16_rounding.hip: up to -1.75 ulp, biased), which is harmless in
 // the sign-mixed contraction but showed up as a 5x larger gradient error when used for the exponent.
 // ================================================================================================
-template <int DPAD, int NB, bool VEC4>
+template <int DPAD, int NB, bool VEC4, int KIND>
 __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __restrict__ xs, const float* __restrict__ sq,
                                                               int64_t n, const float* __restrict__ outputscale,
                                                               const float* __restrict__ noise,
@@ -536,6 +584,7 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
   constexpr int kMI = 2, kTJ = 64;
   using Tile = RbfTileH<DPAD, NB, kTJ>;
   constexpr int KD = Tile::KD, KS = KD / 2;
+  constexpr float cfac = KIND == MFX_KERNEL_RBF ? kNegHalfLog2e : (KIND == MFX_KERNEL_MATERN32 ? 3.f : 1.f) * kLog2e * kLog2e;
   __shared__ __attribute__((aligned(16))) Tile tile[2];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
@@ -623,19 +672,30 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
 #pragma unroll
     for (int u = 0; u < kXPT; ++u) {
       const int t = tid + 256 * u;
-      if (t < kTJ * DPAD) tl.aj[t % DPAD][t / DPAD] = -2.f * kNegHalfLog2e * rx[u];
+      if (t < kTJ * DPAD) tl.aj[t % DPAD][t / DPAD] = -2.f * cfac * rx[u];
     }
     if (tid < kTJ) {
-      tl.aj[DPAD][tid] = kNegHalfLog2e * rsq + kKShift;  // K' = 2^15 K: lo(K') stays a NORMAL f16 for K >= 4e-6
-      tl.aj[DPAD + 1][tid] = kNegHalfLog2e;
+      // K' = 2^15 K: lo(K') stays a NORMAL f16 for K >= 4e-6 (RBF: shift folded into the product; Matern: into exp2)
+      tl.aj[DPAD][tid] = cfac * rsq + (KIND == MFX_KERNEL_RBF ? kKShift : 0.f);
+      tl.aj[DPAD + 1][tid] = cfac;
     }
   };
   // entries (2 pr, 2 pr + 1): K' = exp2(min(arg, 15)) and its hi/lo f16 pieces.  min as ONE compiler-visible
   // v_med3_f32 (fminf adds a canonicalising v_max; inline asm would hide the MFMA-result hazard from hipcc).
-  auto exp_split_pair = [&](const floatx16& kd, int pr, half8 (&ah)[2], half8 (&al)[2]) {
+  auto exp_split_pair = [&](const floatx16& kd, int pr, bool diag_blk, half8 (&ah)[2], half8 (&al)[2]) {
     const int s = pr >> 2, q = (pr & 3) * 2;
-    const float k0 = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(kd[8 * s + q], -3.0e38f, kKShift));
-    const float k1 = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(kd[8 * s + q + 1], -3.0e38f, kKShift));
+    float k0, k1;
+    if constexpr (KIND == MFX_KERNEL_RBF) {
+      k0 = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(kd[8 * s + q], -3.0e38f, kKShift));
+      k1 = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(kd[8 * s + q + 1], -3.0e38f, kKShift));
+    } else {
+      // register r <-> column (r & 3) + 8 (r >> 2) + 4 lhi of the block: zero self-distance on the diagonal block
+      const int r0 = 8 * s + q, r1 = r0 + 1;
+      const float t0 = (diag_blk && l31 == (r0 & 3) + 8 * (r0 >> 2) + 4 * lhi) ? 0.f : kd[r0];
+      const float t1 = (diag_blk && l31 == (r1 & 3) + 8 * (r1 >> 2) + 4 * lhi) ? 0.f : kd[r1];
+      k0 = matern_from_t<KIND>(t0, kKShift);
+      k1 = matern_from_t<KIND>(t1, kKShift);
+    }
     const half2v h = {(_Float16)k0, (_Float16)k1};  // one v_cvt_pk_f16_f32 (round to nearest)
     // lo = k - hi in ONE instruction each: v_fma_mix_f32 reads the f16 half directly (no v_cvt_f32_f16 + v_sub).
     // Inputs/outputs are VALU values only, so no MFMA hazard hides inside the asm.
@@ -663,7 +723,7 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
 #pragma unroll
       for (int s = 0; s < KS; ++s) kd = __builtin_amdgcn_mfma_f32_32x32x2f32(tl.aj[2 * s + lhi][l31], bi[0][s], kd, 0, 0, 0);
 #pragma unroll
-      for (int pr = 0; pr < 8; ++pr) exp_split_pair(kd, pr, ah, al);
+      for (int pr = 0; pr < 8; ++pr) exp_split_pair(kd, pr, t * kTJ == i_wave, ah, al);
     }
 #pragma unroll
     for (int blk = 0; blk < 2 * kMI; ++blk) {
@@ -721,7 +781,8 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
         if (has_next) {
 #pragma unroll
           for (int pr = 0; pr < 8; ++pr)
-            if (pr >= 8 * (m - NM1) / (NM - NM1) && pr < 8 * (m - NM1 + 1) / (NM - NM1)) exp_split_pair(kdn, pr, ahn, aln);
+            if (pr >= 8 * (m - NM1) / (NM - NM1) && pr < 8 * (m - NM1 + 1) / (NM - NM1))
+              exp_split_pair(kdn, pr, t * kTJ + jbn * 32 == i_wave + min_ * 32, ahn, aln);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -761,23 +822,34 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
     }
 }
 
-template <int DPAD, int NB>
-static int launch_apply_h3(const mfx_operator* op, const float* xs, const float* sq, const float* x, int64_t ldx,
-                           float* y, int64_t ldy, int64_t p, float* vscale, hipStream_t stream) {
+template <int DPAD, int NB, int KIND>
+static int launch_apply_h3k(const mfx_operator* op, const float* xs, const float* sq, const float* x, int64_t ldx,
+                            float* y, int64_t ldy, int64_t p, float* vscale, hipStream_t stream) {
   const int64_t n = op->n;
   MFX_TRY(row_scales(x, ldx, n, p, vscale, stream));
   const dim3 grid((unsigned)((n + 255) / 256), (unsigned)((p + NB * 32 - 1) / (NB * 32)));
   const bool vec4 = (n % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) &&
                     (reinterpret_cast<uintptr_t>(y) % 16 == 0);
   if (vec4) {
-    k_rbf_mfma_apply_h3<DPAD, NB, true><<<grid, 256, 0, stream>>>(xs, sq, n, (const float*)op->outputscale,
-                                                                  (const float*)op->noise, vscale, x, ldx, y, ldy, p);
+    k_rbf_mfma_apply_h3<DPAD, NB, true, KIND><<<grid, 256, 0, stream>>>(xs, sq, n, (const float*)op->outputscale,
+                                                                        (const float*)op->noise, vscale, x, ldx, y, ldy, p);
   } else {
-    k_rbf_mfma_apply_h3<DPAD, NB, false><<<grid, 256, 0, stream>>>(xs, sq, n, (const float*)op->outputscale,
-                                                                   (const float*)op->noise, vscale, x, ldx, y, ldy, p);
+    k_rbf_mfma_apply_h3<DPAD, NB, false, KIND><<<grid, 256, 0, stream>>>(xs, sq, n, (const float*)op->outputscale,
+                                                                         (const float*)op->noise, vscale, x, ldx, y, ldy, p);
   }
   MFX_CHECK_LAUNCH();
   return MFX_OK;
+}
+
+template <int DPAD, int NB>
+static int launch_apply_h3(const mfx_operator* op, const float* xs, const float* sq, const float* x, int64_t ldx,
+                           float* y, int64_t ldy, int64_t p, float* vscale, hipStream_t stream) {
+  switch (op->kernel_fn) {
+    case MFX_KERNEL_RBF: return launch_apply_h3k<DPAD, NB, MFX_KERNEL_RBF>(op, xs, sq, x, ldx, y, ldy, p, vscale, stream);
+    case MFX_KERNEL_MATERN12: return launch_apply_h3k<DPAD, NB, MFX_KERNEL_MATERN12>(op, xs, sq, x, ldx, y, ldy, p, vscale, stream);
+    case MFX_KERNEL_MATERN32: return launch_apply_h3k<DPAD, NB, MFX_KERNEL_MATERN32>(op, xs, sq, x, ldx, y, ldy, p, vscale, stream);
+    default: set_error("unknown kernel_fn %d", op->kernel_fn); return MFX_ERR_INVALID;
+  }
 }
 
 int rbf_mfma_apply_h3(const mfx_operator* op, const float* xs, const float* sq, int dpad, const float* x, int64_t ldx,
@@ -900,7 +972,7 @@ constexpr int kGChunk = 2;
 
 template <int DPAD>
 __global__ __launch_bounds__(256, 2) void k_rbf_mfma_grad_h(const float* __restrict__ xs, const float* __restrict__ sq,
-                                                            int64_t n, int64_t npad, int ard,
+                                                            int64_t n, int64_t npad, int ard, int kind,
                                                             const _Float16* __restrict__ Lh, const _Float16* __restrict__ Ll,
                                                             const _Float16* __restrict__ Rh, const _Float16* __restrict__ Rl,
                                                             int64_t nkb /* batch_pad / 8 */, int tiles_per_block,
@@ -1046,8 +1118,10 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_grad_h(const float* __restr
         dist = fmaxf(dist, 0.f);
         const bool live = (i < n) && (j < n);
         const float s_ij = live ? sm.u.s_t[jl][il] : 0.f;
-        const float w = s_ij * __builtin_amdgcn_exp2f(kNegHalfLog2e * dist);
-        gt[DPAD] += w;
+        float kv, wl;
+        grad_weights(kind, i == j ? 0.f : dist, kv, wl);
+        gt[DPAD] = fmaf(s_ij, kv, gt[DPAD]);
+        const float w = s_ij * wl;
         if (ard) {
 #pragma unroll
           for (int c = 0; c < DPAD; ++c) {
@@ -1108,7 +1182,7 @@ static int launch_grad_h(const mfx_operator* op, const float* xs, const float* s
   const size_t sh = sizeof(GradSmemH<DPAD>);
   MFX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rbf_mfma_grad_h<DPAD>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-  k_rbf_mfma_grad_h<DPAD><<<grid, 256, sh, stream>>>(xs, sq, n, npad, op->ard, Lh, Ll, Rh, Rl, bpad / 8, tiles_per_block, partial);
+  k_rbf_mfma_grad_h<DPAD><<<grid, 256, sh, stream>>>(xs, sq, n, npad, op->ard, op->kernel_fn, Lh, Ll, Rh, Rl, bpad / 8, tiles_per_block, partial);
   MFX_CHECK_LAUNCH();
   *nblocks_out = nti * kGSplit;
   return MFX_OK;
@@ -1150,10 +1224,10 @@ static int launch_apply_mi(const mfx_operator* op, const float* xs, const float*
                     (reinterpret_cast<uintptr_t>(y) % 16 == 0);
   if (vec4) {
     k_rbf_mfma_apply<DPAD, NB, true, MI, TJ><<<grid, 256, 0, stream>>>(xs, sq, n, (const float*)op->outputscale,
-                                                                   (const float*)op->noise, x, ldx, y, ldy, p);
+                                                                   (const float*)op->noise, x, ldx, y, ldy, p, op->kernel_fn);
   } else {
     k_rbf_mfma_apply<DPAD, NB, false, MI, TJ><<<grid, 256, 0, stream>>>(xs, sq, n, (const float*)op->outputscale,
-                                                                    (const float*)op->noise, x, ldx, y, ldy, p);
+                                                                    (const float*)op->noise, x, ldx, y, ldy, p, op->kernel_fn);
   }
   MFX_CHECK_LAUNCH();
   return MFX_OK;
@@ -1262,7 +1336,7 @@ __device__ __forceinline__ void grad_load_stage(float4 (&ra)[4], float4 (&rb)[4]
 
 template <int DPAD, bool VEC4>
 __global__ __launch_bounds__(256, 2) void k_rbf_mfma_grad(const float* __restrict__ xs, const float* __restrict__ sq,
-                                                          int64_t n, int ard, const float* __restrict__ L,
+                                                          int64_t n, int ard, int kind, const float* __restrict__ L,
                                                           int64_t ldl, const float* __restrict__ R, int64_t ldr,
                                                           int64_t batch, int tiles_per_block,
                                                           double* __restrict__ partial) {
@@ -1383,8 +1457,10 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_grad(const float* __restric
         dist = fmaxf(dist, 0.f);
         const bool live = (i < n) && (j < n);
         const float s_ij = live ? sm.u.s_t[jl][il] : 0.f;
-        const float w = s_ij * __builtin_amdgcn_exp2f(-0.72134752044448170368f * dist);
-        gt[DPAD] += w;
+        float kv, wl;
+        grad_weights(kind, i == j ? 0.f : dist, kv, wl);
+        gt[DPAD] = fmaf(s_ij, kv, gt[DPAD]);
+        const float w = s_ij * wl;
         if (ard) {
 #pragma unroll
           for (int c = 0; c < DPAD; ++c) {
@@ -1433,11 +1509,11 @@ static int launch_grad(const mfx_operator* op, const float* xs, const float* sq,
   if (vec4) {
     MFX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rbf_mfma_grad<DPAD, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    k_rbf_mfma_grad<DPAD, true><<<grid, 256, sh, stream>>>(xs, sq, n, op->ard, L, ldl, R, ldr, batch, tiles_per_block, partial);
+    k_rbf_mfma_grad<DPAD, true><<<grid, 256, sh, stream>>>(xs, sq, n, op->ard, op->kernel_fn, L, ldl, R, ldr, batch, tiles_per_block, partial);
   } else {
     MFX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rbf_mfma_grad<DPAD, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    k_rbf_mfma_grad<DPAD, false><<<grid, 256, sh, stream>>>(xs, sq, n, op->ard, L, ldl, R, ldr, batch, tiles_per_block, partial);
+    k_rbf_mfma_grad<DPAD, false><<<grid, 256, sh, stream>>>(xs, sq, n, op->ard, op->kernel_fn, L, ldl, R, ldr, batch, tiles_per_block, partial);
   }
   MFX_CHECK_LAUNCH();
   *nblocks_out = nti * kGSplit;

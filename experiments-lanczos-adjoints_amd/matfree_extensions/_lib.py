@@ -20,6 +20,7 @@ MFX_F32, MFX_F64 = 0, 1
 OP_DENSE, OP_CSR, OP_RBF, OP_CALLBACK = 0, 1, 2, 3
 REORTHO_NONE, REORTHO_FULL = 0, 1
 RBF_FP32, RBF_F16X3_MATVEC, RBF_F16X3 = 0, 1, 2
+KERNEL_RBF, KERNEL_MATERN12, KERNEL_MATERN32 = 0, 1, 2
 
 CALLBACK_T = C.CFUNCTYPE(
     C.c_int,  # return
@@ -58,7 +59,7 @@ class Operator(C.Structure):
         ("d", C.c_int32),
         ("ard", C.c_int32),
         ("rbf_mode", C.c_int32),
-        ("reserved", C.c_int32),
+        ("kernel_fn", C.c_int32),
         ("lengthscale", C.c_void_p),
         ("outputscale", C.c_void_p),
         ("noise", C.c_void_p),

@@ -194,7 +194,9 @@ def softplus(x, beta=1.0, threshold=20.0):
 
 
 class RbfGramOp(NativeOp):
-    """(K(X, X) + noise I) v with the reference's scaled-RBF parametrisation, matrix-free.
+    """(K(X, X) + noise I) v with the reference's scaled-kernel parametrisation, matrix-free.
+
+    kernel: "rbf" (kernel_scaled_rbf, util/gp_util.py:151-184), "matern32" (:69-107), "matern12" (:110-148).
 
     params = (raw_lengthscale [() or (d,)], raw_outputscale (), raw_noise ());
     lengthscale = softplus(raw_l), outputscale = softplus(raw_s)         (util/gp_util.py:164-165)
@@ -211,11 +213,16 @@ class RbfGramOp(NativeOp):
     kind = _lib.OP_RBF
     _MODES = {"fp32": _lib.RBF_FP32, "f16x3-matvec": _lib.RBF_F16X3_MATVEC, "f16x3": _lib.RBF_F16X3}
 
-    def __init__(self, X, noise_minval=0.0, precision="f16x3"):
+    _KERNELS = {"rbf": _lib.KERNEL_RBF, "matern12": _lib.KERNEL_MATERN12, "matern32": _lib.KERNEL_MATERN32}
+
+    def __init__(self, X, noise_minval=0.0, precision="f16x3", kernel="rbf"):
         if X.dim() != 2:
             raise ValueError("RbfGramOp expects inputs of shape (n, d)")
         if precision not in self._MODES:
             raise ValueError(f"precision must be one of {sorted(self._MODES)}")
+        if kernel not in self._KERNELS:
+            raise ValueError(f"kernel must be one of {sorted(self._KERNELS)}")
+        self.kernel = kernel
         self.X = X.contiguous()
         self.n, self.d = X.shape
         self.noise_minval = noise_minval
@@ -239,6 +246,7 @@ class RbfGramOp(NativeOp):
         desc.x, desc.d = self.X.data_ptr(), self.d
         desc.ard = int(ls.numel() == self.d)
         desc.rbf_mode = self._MODES[self.precision]
+        desc.kernel_fn = self._KERNELS[self.kernel]
         desc.lengthscale, desc.outputscale, desc.noise = ls.data_ptr(), s.data_ptr(), nz.data_ptr()
 
     def new_grads(self, ls, s, nz):
@@ -344,6 +352,9 @@ class CallbackOp:
         desc.n = n
         desc.callback = cb
         return desc, (cb, failure), accum
+
+
+KernelGramOp = RbfGramOp  # the operator covers the reference's three stationary kernels
 
 
 def as_operator(matvec):

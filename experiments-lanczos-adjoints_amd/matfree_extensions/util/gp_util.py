@@ -44,6 +44,43 @@ def kernel_scaled_rbf(*, shape_in, shape_out):
     return parametrize, params_like
 
 
+def _scaled_kernel(shape_in, shape_out, radial):
+    constrain = constraint_greater_than(0.0)
+
+    def parametrize(*, raw_lengthscale, raw_outputscale):
+        def k(x, y):
+            _assert_shapes(x, y, shape_in)
+            lengthscale = constrain(raw_lengthscale)
+            outputscale = constrain(raw_outputscale)
+            xs, ys = x / lengthscale, y / lengthscale
+            scaled = torch.clamp_min((xs * xs).sum() + (ys * ys).sum() - 2 * (xs * ys).sum(), 0.0)
+            return outputscale * radial(scaled)
+
+        return k
+
+    params_like = {"raw_lengthscale": torch.empty(shape_in), "raw_outputscale": torch.empty(shape_out)}
+    return parametrize, params_like
+
+
+def kernel_scaled_matern_32(*, shape_in, shape_out):
+    """util/gp_util.py:69-107: (1 + r) exp(-r), r = sqrt(3 |x/l - y/l|^2 + eps).  Hot path: gram_operator(kernel="matern32")."""
+
+    def radial(s):
+        r = torch.sqrt(3.0 * s + torch.finfo(s.dtype).eps)
+        return (1 + r) * torch.exp(-r)
+
+    return _scaled_kernel(shape_in, shape_out, radial)
+
+
+def kernel_scaled_matern_12(*, shape_in, shape_out):
+    """util/gp_util.py:110-148: exp(-r), r = sqrt(|x/l - y/l|^2 + eps).  Hot path: gram_operator(kernel="matern12")."""
+
+    def radial(s):
+        return torch.exp(-torch.sqrt(s + torch.finfo(s.dtype).eps))
+
+    return _scaled_kernel(shape_in, shape_out, radial)
+
+
 def _assert_shapes(x, y, shape_in):
     if tuple(x.shape) != tuple(y.shape):
         error = "The arguments have different shapes: "
@@ -64,7 +101,7 @@ def gram_matrix(fun, /):
     return gram
 
 
-def gram_operator(inputs, *, noise_minval=0.0, precision="f16x3"):
+def gram_operator(inputs, *, noise_minval=0.0, precision="f16x3", kernel="rbf"):
     """Matrix-free (K(X, X) + noise I) operator: the native replacement for
     gram_matvec / gram_matvec_partitioned / gram_matvec_sequential applied to the lazy RBF kernel
     with the noise on its diagonal (util/gp_util.py:225-226, 434-543).  No partition count is
@@ -72,7 +109,7 @@ def gram_operator(inputs, *, noise_minval=0.0, precision="f16x3"):
 
     Use as  ``A = gram_operator(X).bind(raw_lengthscale, raw_outputscale, raw_noise)``.
     """
-    return RbfGramOp(inputs, noise_minval=noise_minval, precision=precision)
+    return RbfGramOp(inputs, noise_minval=noise_minval, precision=precision, kernel=kernel)
 
 
 def krylov_logdet_slq(krylov_depth, /, *, sample, num_batches: int, checkpoint: bool = False):

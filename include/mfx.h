@@ -40,6 +40,13 @@ enum { MFX_REORTHO_NONE = 0, MFX_REORTHO_FULL = 1 };
  *                         K-chunks that cancel the f16 MFMA's round-towards-minus-infinity bias.  Fastest mode,
  *                         accuracy on par with MFX_RBF_FP32. */
 enum { MFX_RBF_FP32 = 0, MFX_RBF_F16X3_MATVEC = 1, MFX_RBF_F16X3 = 2 };
+/* Kernel family of the Gram operator, with s = |x_i/l - x_j/l|^2 clamped at 0 (util/gp_util.py:69-184):
+ *   MFX_KERNEL_RBF       sigma exp(-s/2)                                   kernel_scaled_rbf        :151-184
+ *   MFX_KERNEL_MATERN12  sigma exp(-r),          r = sqrt(s + eps)         kernel_scaled_matern_12  :110-148
+ *   MFX_KERNEL_MATERN32  sigma (1 + r) exp(-r),  r = sqrt(3 s + eps)       kernel_scaled_matern_32  :69-107
+ * eps = machine epsilon of the dtype (util/gp_util.py:99,140).  The distance of a point to itself is taken as
+ * exactly 0 (the reference's expanded form leaves round-off there, which sqrt amplifies to 3e-4 in fp32). */
+enum { MFX_KERNEL_RBF = 0, MFX_KERNEL_MATERN12 = 1, MFX_KERNEL_MATERN32 = 2 };
 enum {
   MFX_OK = 0,
   MFX_ERR_INVALID = -1,     /* bad argument (shape, null pointer, depth out of range) */
@@ -64,7 +71,7 @@ typedef int (*mfx_callback_fn)(void* ctx, int mode, const void* x, int64_t ldx, 
  * Replaces the reference's `matvec(v, *params)` closures:
  *   DENSE    p @ x                          tests/test_lanczos/test_tridiag_forward.py:18
  *   CSR      BCOO((vals, idx)) @ x          experiments/benchmarks/.../suite_sparse/benchmark.py:64-68
- *   RBF      (K(X,X) + noise I) x           util/gp_util.py:160-176,225-226,525-549
+ *   RBF      (K(X,X) + noise I) x           util/gp_util.py:69-184 (RBF / Matern kernels),225-226,525-549
  *   CALLBACK any Python callable                                                              */
 typedef struct mfx_operator {
   int32_t kind;  /* MFX_OP_* */
@@ -92,8 +99,8 @@ typedef struct mfx_operator {
   const void* x;
   int32_t d;
   int32_t ard;
-  int32_t rbf_mode; /* MFX_RBF_* arithmetic of the fp32 Gram kernels (ignored for fp64) */
-  int32_t reserved;
+  int32_t rbf_mode;  /* MFX_RBF_* arithmetic of the fp32 Gram kernels (ignored for fp64) */
+  int32_t kernel_fn; /* MFX_KERNEL_*: which stationary kernel the Gram operator evaluates */
   const void* lengthscale;
   const void* outputscale;
   const void* noise;

@@ -106,15 +106,62 @@ def rbf_kernel_matrix(Xa, Xb, lengthscale, outputscale):
     return outputscale * np.exp(-0.5 * sq)
 
 
+def scaled_sqdist(Xa, Xb, lengthscale, diag_offset=None):
+    """max(0, |x/l|^2 + |y/l|^2 - 2 (x/l).(y/l)) -- the clamped expanded form shared by all three kernels.
+
+    diag_offset: Xa = Xb[diag_offset : diag_offset + len(Xa)]; the distance of a point to itself is then set to its
+    exact value 0.  (The expanded form leaves O(eps |x|^2) there, which the Matern kernels' sqrt turns into an
+    O(sqrt(eps)) error of K_ii -- 3e-4 in fp32 -- in the reference as well; RBF is insensitive to it.)"""
+    xa = Xa / lengthscale
+    xb = Xb / lengthscale
+    sq = (xa * xa).sum(-1)[:, None] + (xb * xb).sum(-1)[None, :] - 2.0 * (xa @ xb.T)
+    sq = np.maximum(0.0, sq)
+    if diag_offset is not None:
+        sq[np.arange(len(Xa)), diag_offset + np.arange(len(Xa))] = 0.0
+    return sq
+
+
+def kernel_matrix(kind, Xa, Xb, lengthscale, outputscale, diag_offset=None, eps=None):
+    """util/gp_util.py:160-176 (rbf), :69-107 (matern32: sqrt(3) x / l, (1 + r) exp(-r)), :110-148 (matern12: exp(-r));
+    r = sqrt(clamped squared distance + eps(dtype)) (util/gp_util.py:99-100,140-141)."""
+    if kind == "rbf":
+        return rbf_kernel_matrix(Xa, Xb, lengthscale, outputscale)
+    sq = scaled_sqdist(Xa, Xb, lengthscale, diag_offset)
+    eps = np.finfo(np.result_type(Xa, Xb)).eps if eps is None else eps  # the reference takes eps of the COMPUTE dtype
+    if kind == "matern32":
+        r = np.sqrt(3.0 * sq + eps)
+        return outputscale * (1.0 + r) * np.exp(-r)
+    if kind == "matern12":
+        r = np.sqrt(sq + eps)
+        return outputscale * np.exp(-r)
+    raise ValueError(kind)
+
+
+def kernel_lengthscale_weight(kind, Xa, Xb, lengthscale, diag_offset=None, eps=None):
+    """w with  dK_ij / d l_c = outputscale * w_ij * (x_ic - x_jc)^2 / l_c^3  (differentiating the formulas above)."""
+    sq = scaled_sqdist(Xa, Xb, lengthscale, diag_offset)
+    if kind == "rbf":
+        return np.exp(-0.5 * sq)
+    eps = np.finfo(np.result_type(Xa, Xb)).eps if eps is None else eps
+    if kind == "matern32":
+        return 3.0 * np.exp(-np.sqrt(3.0 * sq + eps))
+    r = np.sqrt(sq + eps)
+    return np.where(sq > 0.0, np.exp(-r) / r, 0.0)  # d max(0, s)/ds = 0 on the clamped side
+
+
 class RbfGramOp:
     """K(X,X; raw_l, raw_s) + noise I, matrix-free semantics of util/gp_util.py:225-226,525-549.
+
+    `kernel` selects the reference's kernel family: "rbf" (kernel_scaled_rbf), "matern32", "matern12".
 
     params = (raw_lengthscale [() or (d,)], raw_outputscale (), raw_noise ());
     lengthscale = softplus(raw_l), outputscale = softplus(raw_s), noise = minval + softplus(raw_noise).
     Row-chunked so that n up to a few 1e4 stays in memory.
     """
 
-    def __init__(self, X, noise_minval=0.0, chunk=2048, cache_limit=4096):
+    def __init__(self, X, noise_minval=0.0, chunk=2048, cache_limit=4096, kernel="rbf", eps=None):
+        self.kernel = kernel
+        self.eps = eps  # Matern: eps of the dtype the compared implementation computes in (default: dtype of X)
         self.X = np.asarray(X)
         self.n, self.d = self.X.shape
         self.noise_minval = noise_minval
@@ -127,7 +174,7 @@ class RbfGramOp:
             return None
         key = (np.asarray(ls).tobytes(), np.asarray(s).tobytes())
         if self._cache[0] != key:
-            self._cache = (key, rbf_kernel_matrix(self.X, self.X, ls, s))
+            self._cache = (key, kernel_matrix(self.kernel, self.X, self.X, ls, s, diag_offset=0, eps=self.eps))
         return self._cache[1]
 
     def constrained(self, raw_l, raw_s, raw_noise):
@@ -141,7 +188,7 @@ class RbfGramOp:
         out = np.empty(v.shape, dtype=np.result_type(v, self.X))
         for a in range(0, self.n, self.chunk):
             b = min(self.n, a + self.chunk)
-            K = rbf_kernel_matrix(self.X[a:b], self.X, ls, s)
+            K = kernel_matrix(self.kernel, self.X[a:b], self.X, ls, s, diag_offset=a, eps=self.eps)
             out[..., a:b] = v @ K.T  # supports v of shape (n,) or (p, n)
         return out + noise * v
 
@@ -159,10 +206,10 @@ class RbfGramOp:
         Kd = self._dense_k(ls, s)
         for a in range(0, self.n, self.chunk):
             b = min(self.n, a + self.chunk)
-            K = Kd[a:b] if Kd is not None else rbf_kernel_matrix(self.X[a:b], self.X, ls, s)
+            K = Kd[a:b] if Kd is not None else kernel_matrix(self.kernel, self.X[a:b], self.X, ls, s, diag_offset=a, eps=self.eps)
             S = C[:, a:b].T @ V  # (chunk, n): sum_b cot_b[i] v_b[j]
-            W = S * K
-            g_s += W.sum() / s
+            g_s += (S * K).sum() / s
+            W = S * (s * kernel_lengthscale_weight(self.kernel, self.X[a:b], self.X, ls, diag_offset=a, eps=self.eps))
             if ard:
                 for c in range(self.d):
                     diff2 = (self.X[a:b, c][:, None] - self.X[None, :, c]) ** 2
@@ -170,6 +217,7 @@ class RbfGramOp:
             else:
                 sqn = (self.X * self.X).sum(-1)
                 diff2 = np.maximum(0.0, sqn[a:b, None] + sqn[None, :] - 2.0 * self.X[a:b] @ self.X.T)
+                diff2[np.arange(b - a), np.arange(a, b)] = 0.0  # exact zero distance of a point to itself
                 g_l += (W * diff2).sum() / ls**3
         g_noise = float((C * V).sum())
         return (

@@ -77,16 +77,20 @@ def test_csr_op(dtype, tol):
 
 @pytest.mark.parametrize("dtype,tol,precision", [(torch.float64, 1e-11, "fp32"), (torch.float32, 5e-5, "fp32"),
                                                  (torch.float32, 5e-5, "f16x3-matvec"), (torch.float32, 5e-5, "f16x3")])
+@pytest.mark.parametrize("kernel", ["rbf", "matern32", "matern12"])
 @pytest.mark.parametrize("ard", [False, True])
 @pytest.mark.parametrize("n,d,p", [(300, 3, 1), (515, 8, 5), (700, 9, 8), (640, 8, 64), (333, 5, 17), (1000, 8, 40)])
-def test_rbf_op_apply_and_param_sweep(dtype, tol, precision, ard, n, d, p):
-    """p >= 4 in fp32 takes the MFMA kernels (exact fp32 or the 3 x f16 split), everything else the VALU kernel."""
+def test_rbf_op_apply_and_param_sweep(dtype, tol, precision, ard, n, d, p, kernel):
+    """p >= 4 in fp32 takes the MFMA kernels (exact fp32 or the 3 x f16 split), everything else the VALU kernel;
+    kernels: util/gp_util.py:69-184 (scaled RBF, Matern-3/2, Matern-1/2)."""
     rng = np.random.default_rng(2)
     X = rng.standard_normal((n, d))
     raw = (rng.standard_normal(d) * 0.3 + 0.5 if ard else np.array(0.7), np.array(0.4), np.array(-1.0))
     V, Cc = rng.standard_normal((p, n)), rng.standard_normal((p, n))
-    o = orc.RbfGramOp(X, noise_minval=1e-4)
-    op = RbfGramOp(T(X, dtype), noise_minval=1e-4, precision=precision)
+    # Matern kernels add eps(compute dtype) under the square root (util/gp_util.py:99,140): give the fp64 oracle the
+    # eps of the dtype under test, otherwise K_ii differs by sqrt(eps_fp32) = 3.5e-4 by definition
+    o = orc.RbfGramOp(X, noise_minval=1e-4, kernel=kernel, eps=float(torch.finfo(dtype).eps))
+    op = RbfGramOp(T(X, dtype), noise_minval=1e-4, precision=precision, kernel=kernel)
     params = [T(r, dtype, True) for r in raw]
     Vt = T(V, dtype, True)
     y = op(Vt, *params)
@@ -352,9 +356,10 @@ def test_slq_rbf_golden(dtype, vtol, gtol, precision, tag):
         assert close(gr.reshape(g[f"{tag}_{name}"].shape), g[f"{tag}_{name}"], gtol, atol_rel=gtol)
 
 
+@pytest.mark.parametrize("kernel", ["rbf", "matern32"])
 @pytest.mark.parametrize("precision", ["fp32", "f16x3-matvec", "f16x3"])
 @pytest.mark.parametrize("n,d,k,p", [(1536, 8, 12, 64), (1000, 9, 10, 24)])
-def test_slq_rbf_mfma_path_downsized_c4_c2(n, d, k, p, precision):
+def test_slq_rbf_mfma_path_downsized_c4_c2(n, d, k, p, precision, kernel):
     """Down-sized BASELINE configs 4 (d=8, 64 probes) and 2 (d=9): MFMA Gram matvec (exact fp32 and the
     3 x f16 split) inside the full SLQ value-and-gradient, against the fp64 oracle on identical explicit probes."""
     rng = np.random.default_rng(4)
@@ -362,8 +367,9 @@ def test_slq_rbf_mfma_path_downsized_c4_c2(n, d, k, p, precision):
     ls = 2.0
     raw = (np.array(np.log(np.expm1(ls))), np.array(np.log(np.expm1(1.0))), np.array(np.log(np.expm1(0.1))))
     probes = orc.rademacher(5, p, n)
-    ref_val, ref_g, ref_vals = orc.hutchinson_value_and_grad(orc.RbfGramOp(X), k, probes, raw)
-    op = gp_util.gram_operator(T(X, torch.float32), precision=precision)
+    ref_val, ref_g, ref_vals = orc.hutchinson_value_and_grad(
+        orc.RbfGramOp(X, kernel=kernel, eps=float(np.finfo(np.float32).eps)), k, probes, raw)
+    op = gp_util.gram_operator(T(X, torch.float32), precision=precision, kernel=kernel)
     params = [T(r, torch.float32, True) for r in raw]
     integrand = lanczos.integrand_spd(torch.log, k, op)
     vals = integrand(T(probes, torch.float32), *params)

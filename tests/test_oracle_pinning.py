@@ -222,21 +222,41 @@ def test_rbf_kernel_and_softplus():
     assert np.isclose(orc.softplus(19.0), np.log1p(np.exp(19.0)))
 
 
+def _torch_kernel(kind, xs, outputscale):
+    """the reference formulas (util/gp_util.py:69-176) in torch, expanded + clamped squared distance"""
+    sq = (xs * xs).sum(-1)[:, None] + (xs * xs).sum(-1)[None, :] - 2 * xs @ xs.T
+    if kind != "rbf":
+        # Matern: r = sqrt(sq + eps) is not differentiable at 0, and the expanded form leaves O(1e-15) round-off
+        # on the diagonal, which the 1/r factor amplifies to ~1e-7 of the gradient (in the reference too).  The
+        # oracle takes the mathematically exact d(i, i) = 0, i.e. the direct-difference form:
+        sq = ((xs[:, None] - xs[None]) ** 2).sum(-1)
+    sq = torch.clamp_min(sq, 0.0)
+    eps = torch.finfo(xs.dtype).eps
+    if kind == "rbf":
+        return outputscale * torch.exp(-0.5 * sq)
+    if kind == "matern32":
+        r = torch.sqrt(3.0 * sq + eps)
+        return outputscale * (1 + r) * torch.exp(-r)
+    r = torch.sqrt(sq + eps)
+    return outputscale * torch.exp(-r)
+
+
+@pytest.mark.parametrize("kind", ["rbf", "matern32", "matern12"])
 @pytest.mark.parametrize("ard", [False, True])
-def test_rbf_param_vjp_matches_autodiff(ard):
+def test_rbf_param_vjp_matches_autodiff(ard, kind):
     rng = np.random.default_rng(1)
     n, d = 23, 4
     X = rng.standard_normal((n, d))
     raw_l = rng.standard_normal(d) if ard else np.array(0.2)
     raw_s, raw_n = np.array(0.4), np.array(-1.0)
-    op = orc.RbfGramOp(X, noise_minval=1e-4, chunk=8)
+    op = orc.RbfGramOp(X, noise_minval=1e-4, chunk=8, kernel=kind)
     v, cot = rng.standard_normal((2, n)), rng.standard_normal((2, n))
     g = op.param_vjp(v, cot, raw_l, raw_s, raw_n)
     Xt = torch.tensor(X)
     tl, ts, tn = (torch.tensor(a, requires_grad=True) for a in (raw_l, raw_s, raw_n))
     sp = torch.nn.functional.softplus
     xs = Xt / sp(tl)
-    K = sp(ts) * torch.exp(-0.5 * torch.cdist(xs, xs) ** 2) + (1e-4 + sp(tn)) * torch.eye(n)
+    K = _torch_kernel(kind, xs, sp(ts)) + (1e-4 + sp(tn)) * torch.eye(n)
     val = (torch.tensor(cot) * (torch.tensor(v) @ K.T)).sum()
     ref = torch.autograd.grad(val, (tl, ts, tn))
     for a, b in zip(g, ref):
