@@ -17,6 +17,8 @@
 // Bound: fp32 MFMA (2 n^2 p flop per matvec) -- the exp/distance VALU work co-issues underneath.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "mfx_internal.h"
 
 namespace mfx {
@@ -682,7 +684,7 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
   };
   // entries (2 pr, 2 pr + 1): K' = exp2(min(arg, 15)) and its hi/lo f16 pieces.  min as ONE compiler-visible
   // v_med3_f32 (fminf adds a canonicalising v_max; inline asm would hide the MFMA-result hazard from hipcc).
-  auto exp_split_pair = [&](const floatx16& kd, int pr, bool diag_blk, half8 (&ah)[2], half8 (&al)[2]) {
+  auto exp_split_pair = [&](const floatx16& kd, int pr, const bool diag_blk, half8 (&ah)[2], half8 (&al)[2]) {
     const int s = pr >> 2, q = (pr & 3) * 2;
     float k0, k1;
     if constexpr (KIND == MFX_KERNEL_RBF) {
@@ -715,6 +717,10 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
   for (int64_t t = 0; t < ntile; ++t) {
     const Tile& tl = tile[t & 1];
     if (t + 1 < ntile) load_tile((t + 1) * kTJ);
+    // the one tile whose 64 columns are this wave's 64 rows holds the diagonal: only there (and only for the Matern
+    // kernels) the per-entry self-distance fix is compiled in -- two copies of the tile body, chosen wave-uniformly
+    auto do_tile = [&](auto diag_tag) {
+    constexpr bool kDiag = decltype(diag_tag)::value;
     half8 ah[2], al[2];
     {  // pipeline prologue: fragments of block 0 of this tile
       floatx16 kd;
@@ -723,7 +729,7 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
 #pragma unroll
       for (int s = 0; s < KS; ++s) kd = __builtin_amdgcn_mfma_f32_32x32x2f32(tl.aj[2 * s + lhi][l31], bi[0][s], kd, 0, 0, 0);
 #pragma unroll
-      for (int pr = 0; pr < 8; ++pr) exp_split_pair(kd, pr, t * kTJ == i_wave, ah, al);
+      for (int pr = 0; pr < 8; ++pr) exp_split_pair(kd, pr, kDiag, ah, al);  // block (jb 0, mi 0) is diagonal in that tile
     }
 #pragma unroll
     for (int blk = 0; blk < 2 * kMI; ++blk) {
@@ -782,7 +788,7 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
 #pragma unroll
           for (int pr = 0; pr < 8; ++pr)
             if (pr >= 8 * (m - NM1) / (NM - NM1) && pr < 8 * (m - NM1 + 1) / (NM - NM1))
-              exp_split_pair(kdn, pr, t * kTJ + jbn * 32 == i_wave + min_ * 32, ahn, aln);
+              exp_split_pair(kdn, pr, kDiag && jbn == min_, ahn, aln);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -790,6 +796,12 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
         ah[0] = ahn[0]; ah[1] = ahn[1];
         al[0] = aln[0]; al[1] = aln[1];
       }
+    }
+    };
+    if (KIND != MFX_KERNEL_RBF && t * kTJ == i_wave) {
+      do_tile(std::true_type{});
+    } else {
+      do_tile(std::false_type{});
     }
     if (t + 1 < ntile) store_tile(tile[(t + 1) & 1]);
     __syncthreads();
