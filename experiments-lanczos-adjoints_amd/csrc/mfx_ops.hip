@@ -5,6 +5,7 @@
 // The RBF kernels in this file are the generic VALU path (any dtype, any number of probes); the
 // fp32 MFMA path for wide probe batches lives in mfx_rbf_mfma.hip and is selected in rbf_apply().
 #include "mfx_internal.h"
+#include "mfx_kernel_fn.h"
 
 namespace mfx {
 
@@ -123,33 +124,6 @@ __global__ __launch_bounds__(256) void k_csr_grad(const int32_t* __restrict__ ro
 // RBF Gram  K_ij = s exp(-max(0, |x_i/l|^2 + |x_j/l|^2 - 2 (x_i/l).(x_j/l)) / 2) + noise delta_ij
 //   (util/gp_util.py:160-176 kernel, :225-226 noise inside the lazy kernel, :525-549 gram matvec)
 // ================================================================================================
-__device__ __forceinline__ float exp_neg_half(float d) { return __expf(-0.5f * d); }
-__device__ __forceinline__ double exp_neg_half(double d) { return exp(-0.5 * d); }
-__device__ __forceinline__ float exp_neg(float r) { return __expf(-r); }
-__device__ __forceinline__ double exp_neg(double r) { return exp(-r); }
-template <typename T> __device__ __forceinline__ T dtype_eps();
-template <> __device__ __forceinline__ float dtype_eps<float>() { return 1.1920928955078125e-7f; }
-template <> __device__ __forceinline__ double dtype_eps<double>() { return 2.220446049250313e-16; }
-
-// K_ij / outputscale and the lengthscale weight w (dK_ij/dl_c = outputscale w (x_ic - x_jc)^2 / l_c^3) from the clamped
-// scaled squared distance (util/gp_util.py:69-184; kinds = MFX_KERNEL_*)
-template <typename T>
-__device__ __forceinline__ void kernel_eval(int kind, T dist, T& kv, T& wl) {
-  if (kind == MFX_KERNEL_RBF) {
-    kv = exp_neg_half(dist);
-    wl = kv;
-  } else if (kind == MFX_KERNEL_MATERN32) {
-    const T r = sqrt(T(3) * dist + dtype_eps<T>());
-    const T e = exp_neg(r);
-    kv = (T(1) + r) * e;
-    wl = T(3) * e;
-  } else {
-    const T r = sqrt(dist + dtype_eps<T>());
-    const T e = exp_neg(r);
-    kv = e;
-    wl = dist > T(0) ? e / r : T(0);  // d max(0, s)/ds = 0 on the clamped side
-  }
-}
 
 // xs[i][c] = X[i][c] / l_c (zero padded to DPAD), sq[i] = |xs_i|^2
 template <typename T>

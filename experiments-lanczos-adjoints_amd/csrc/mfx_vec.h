@@ -1,0 +1,388 @@
+// libmfx: the shared HBM-bound vector kernels (dots / update / sumsq / scale) and their launch helpers.
+// Included by the Krylov drivers (mfx_krylov.hip) and the CG / preconditioner drivers (mfx_cg.hip): every
+// kernel uses grid = (ceil(n / 2048), p) and per-slice partials, see the header comment of mfx_krylov.hip.
+#pragma once
+#include <initializer_list>
+
+#include "mfx_internal.h"
+
+namespace mfx {
+
+// ------------------------------------------------------------------------------------------------
+// thread-owned elements
+// ------------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__device__ __forceinline__ void load_own(T (&dst)[kEpt], const T* __restrict__ base, int64_t slice0,
+                                         int64_t n, int tid) {
+  constexpr int U = kEpt / VEC;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t off = slice0 + (int64_t)(u * (int)blockDim.x + tid) * VEC;
+    if (off < n) {
+      Pack<T, VEC> p = load_pack<T, VEC>(base + off);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) dst[u * VEC + e] = p.v[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) dst[u * VEC + e] = T(0);
+    }
+  }
+}
+
+template <typename T, int VEC>
+__device__ __forceinline__ void store_own(const T (&src)[kEpt], T* __restrict__ base, int64_t slice0,
+                                          int64_t n, int tid) {
+  constexpr int U = kEpt / VEC;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t off = slice0 + (int64_t)(u * (int)blockDim.x + tid) * VEC;
+    if (off < n) {
+      Pack<T, VEC> p;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) p.v[e] = src[u * VEC + e];
+      store_pack<T, VEC>(base + off, p);
+    }
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ T reduce_partials(const T* __restrict__ part, int nblk) {
+  double acc = 0.0;  // few hundred terms at most; fp64 keeps the reduction order-insensitive
+  for (int q = 0; q < nblk; ++q) acc += (double)part[q];
+  return (T)acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K-dots: partial[b][j][blk] = sum_{i in slice} rows[b][j][i] * x[b][i],  j < m
+//   forward  h = Q^T w            (arnoldi.py:87)      adjoint  P lam, z^T Q   (arnoldi.py:204,212)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void k_dots(const T* __restrict__ rows, int64_t rows_ldb,
+                                                 int64_t row_stride, int m,
+                                                 const T* __restrict__ x, int64_t ldx, int64_t n,
+                                                 T* __restrict__ partial, int kmax, int nblk) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* sm = reinterpret_cast<T*>(smem_raw);  // [4][m]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int b = blockIdx.y, blk = blockIdx.x;
+  const int64_t slice0 = (int64_t)blk * ((int64_t)blockDim.x * kEpt);
+  T xr[kEpt];
+  load_own<T, VEC>(xr, x + (int64_t)b * ldx, slice0, n, tid);
+  const T* rb = rows + (int64_t)b * rows_ldb;
+  constexpr int JT = 4;  // rows in flight per thread: 4 x 8 elements of loads before the first use
+  int j = 0;
+  for (; j + JT <= m; j += JT) {
+    T rr[JT][kEpt];
+#pragma unroll
+    for (int q = 0; q < JT; ++q) load_own<T, VEC>(rr[q], rb + (int64_t)(j + q) * row_stride, slice0, n, tid);
+#pragma unroll
+    for (int q = 0; q < JT; ++q) {
+      T acc = T(0);
+#pragma unroll
+      for (int e = 0; e < kEpt; ++e) acc += rr[q][e] * xr[e];
+      acc = wave_sum(acc);
+      if (lane == 0) sm[wid * m + j + q] = acc;
+    }
+  }
+  for (; j < m; ++j) {
+    T rr[kEpt];
+    load_own<T, VEC>(rr, rb + (int64_t)j * row_stride, slice0, n, tid);
+    T acc = T(0);
+#pragma unroll
+    for (int e = 0; e < kEpt; ++e) acc += rr[e] * xr[e];
+    acc = wave_sum(acc);
+    if (lane == 0) sm[wid * m + j] = acc;
+  }
+  __syncthreads();
+  for (int j = tid; j < m; j += (int)blockDim.x)
+  {
+    T sum = T(0);
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sum += sm[w * m + j];
+    partial[((int64_t)b * kmax + j) * nblk + blk] = sum;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K-update: coef_j = s1 * sum_blk partial_in[b][j][:] + s2 * extra[b][j];   y = x - sum_j coef_j row_j
+//   optional: hout[b][j] = coef_j (H column, arnoldi.py:99), second store y2, fused second dots
+//   (re-orthogonalisation pass, arnoldi.py:91-92) and fused |y|^2 partial (arnoldi.py:95).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct UpdateArgs {
+  const T* rows;
+  int64_t rows_ldb, row_stride;
+  int m;
+  const T* partial_in;  // (p, kmax, nblk) or null
+  T s1;
+  const T* extra;  // null or extra[b*extra_ldb + j*extra_stride]
+  int64_t extra_ldb, extra_stride;
+  T s2;
+  T* hout;  // null or hout[b*hout_ldb + j*hout_stride]
+  int64_t hout_ldb, hout_stride;
+  const T* x;  // null = zeros
+  int64_t ldx;
+  T* y;
+  int64_t ldy;
+  T* y2;  // optional second destination
+  int64_t ldy2;
+  int64_t n;
+  T* partial_out;   // DOTS
+  T* partial_norm;  // NORM: (p, nblk)
+  int kmax, nblk;
+};
+
+template <typename T, int VEC, bool DOTS, bool NORM>
+__global__ __launch_bounds__(kBlock) void k_update(UpdateArgs<T> a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* coef = reinterpret_cast<T*>(smem_raw);  // [m]
+  T* sm = coef + a.m;                         // [4][m] (DOTS) ; [4] (NORM) after that
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int b = blockIdx.y, blk = blockIdx.x;
+  const int64_t slice0 = (int64_t)blk * ((int64_t)blockDim.x * kEpt);
+  const int m = a.m;
+  for (int j = tid; j < m; j += (int)blockDim.x) {
+    T c = T(0);
+    if (a.partial_in) c = a.s1 * reduce_partials(a.partial_in + ((int64_t)b * a.kmax + j) * a.nblk, a.nblk);
+    if (a.extra) c += a.s2 * a.extra[(int64_t)b * a.extra_ldb + (int64_t)j * a.extra_stride];
+    coef[j] = c;
+    if (a.hout && blk == 0) a.hout[(int64_t)b * a.hout_ldb + (int64_t)j * a.hout_stride] = c;
+  }
+  __syncthreads();
+  T xr[kEpt];
+  if (a.x) {
+    load_own<T, VEC>(xr, a.x + (int64_t)b * a.ldx, slice0, a.n, tid);
+  } else {
+#pragma unroll
+    for (int e = 0; e < kEpt; ++e) xr[e] = T(0);
+  }
+  const T* rb = a.rows + (int64_t)b * a.rows_ldb;
+  constexpr int JT = 4;  // rows in flight per thread
+  {
+    int j = 0;
+    for (; j + JT <= m; j += JT) {
+      T rr[JT][kEpt];
+#pragma unroll
+      for (int q = 0; q < JT; ++q) load_own<T, VEC>(rr[q], rb + (int64_t)(j + q) * a.row_stride, slice0, a.n, tid);
+#pragma unroll
+      for (int q = 0; q < JT; ++q) {
+        const T c = coef[j + q];
+#pragma unroll
+        for (int e = 0; e < kEpt; ++e) xr[e] -= c * rr[q][e];
+      }
+    }
+    for (; j < m; ++j) {
+      T rr[kEpt];
+      load_own<T, VEC>(rr, rb + (int64_t)j * a.row_stride, slice0, a.n, tid);
+      const T c = coef[j];
+#pragma unroll
+      for (int e = 0; e < kEpt; ++e) xr[e] -= c * rr[e];
+    }
+  }
+  store_own<T, VEC>(xr, a.y + (int64_t)b * a.ldy, slice0, a.n, tid);
+  if (a.y2) store_own<T, VEC>(xr, a.y2 + (int64_t)b * a.ldy2, slice0, a.n, tid);
+  if constexpr (DOTS) {
+    int j = 0;
+    for (; j + JT <= m; j += JT) {
+      T rr[JT][kEpt];
+#pragma unroll
+      for (int q = 0; q < JT; ++q) load_own<T, VEC>(rr[q], rb + (int64_t)(j + q) * a.row_stride, slice0, a.n, tid);
+#pragma unroll
+      for (int q = 0; q < JT; ++q) {
+        T acc = T(0);
+#pragma unroll
+        for (int e = 0; e < kEpt; ++e) acc += rr[q][e] * xr[e];
+        acc = wave_sum(acc);
+        if (lane == 0) sm[wid * m + j + q] = acc;
+      }
+    }
+    for (; j < m; ++j) {
+      T rr[kEpt];
+      load_own<T, VEC>(rr, rb + (int64_t)j * a.row_stride, slice0, a.n, tid);
+      T acc = T(0);
+#pragma unroll
+      for (int e = 0; e < kEpt; ++e) acc += rr[e] * xr[e];
+      acc = wave_sum(acc);
+      if (lane == 0) sm[wid * m + j] = acc;
+    }
+    __syncthreads();
+    for (int j = tid; j < m; j += (int)blockDim.x)
+    {
+      T sum = T(0);
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sum += sm[w * m + j];
+      a.partial_out[((int64_t)b * a.kmax + j) * a.nblk + blk] = sum;
+    }
+  }
+  if constexpr (NORM) {
+    T* smn = sm + (DOTS ? 4 * m : 0);
+    T acc = T(0);
+#pragma unroll
+    for (int e = 0; e < kEpt; ++e) acc += xr[e] * xr[e];
+    acc = wave_sum(acc);
+    if (lane == 0) smn[wid] = acc;
+    __syncthreads();
+    if (tid == 0) {
+      T sum = T(0);
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sum += smn[w];
+      a.partial_norm[(int64_t)b * a.nblk + blk] = sum;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K-sumsq: partial_norm[b][blk] = sum x^2          (arnoldi.py:67, lanczos.py:222)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void k_sumsq(const T* __restrict__ x, int64_t ldx, int64_t n,
+                                                  T* __restrict__ partial_norm, int nblk) {
+  __shared__ T smn[4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int b = blockIdx.y, blk = blockIdx.x;
+  T xr[kEpt];
+  load_own<T, VEC>(xr, x + (int64_t)b * ldx, (int64_t)blk * ((int64_t)blockDim.x * kEpt), n, tid);
+  T acc = T(0);
+#pragma unroll
+  for (int e = 0; e < kEpt; ++e) acc += xr[e] * xr[e];
+  acc = wave_sum(acc);
+  if (lane == 0) smn[wid] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    T sum = T(0);
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sum += smn[w];
+    partial_norm[(int64_t)b * nblk + blk] = sum;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K-scale: len = sqrt(sum_blk partial_norm[b][:]) (or given scale[b]);  y = x * f,
+//   mode 0: f = 1/len   (normalise: arnoldi.py:80, lanczos.py:258)      mode 1: f = scale[b]      mode 2: f = -1
+//   optional scalar outputs: len_out[b*ld] = len, inv_out[b] = 1/len.  y may be null (scalars only).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void k_scale(const T* __restrict__ x, int64_t ldx,
+                                                  T* __restrict__ y, int64_t ldy, int64_t n,
+                                                  const T* __restrict__ partial_norm, int nblk,
+                                                  const T* __restrict__ scale, int mode,
+                                                  T* __restrict__ len_out, int64_t len_ld,
+                                                  T* __restrict__ inv_out) {
+  __shared__ T f_sh;
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y, blk = blockIdx.x;
+  if (tid == 0) {
+    T f;
+    if (mode == 0) {
+      const T len = sqrt(reduce_partials(partial_norm + (int64_t)b * nblk, nblk));
+      f = T(1) / len;
+      if (blk == 0) {
+        if (len_out) len_out[(int64_t)b * len_ld] = len;
+        if (inv_out) inv_out[b] = f;
+      }
+    } else if (mode == 1) {
+      f = scale[b];
+    } else {
+      f = T(-1);
+    }
+    f_sh = f;
+  }
+  __syncthreads();
+  if (!y) return;
+  const T f = f_sh;
+  T xr[kEpt];
+  load_own<T, VEC>(xr, x + (int64_t)b * ldx, (int64_t)blk * ((int64_t)blockDim.x * kEpt), n, tid);
+#pragma unroll
+  for (int e = 0; e < kEpt; ++e) xr[e] *= f;
+  store_own<T, VEC>(xr, y + (int64_t)b * ldy, (int64_t)blk * ((int64_t)blockDim.x * kEpt), n, tid);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side launch helpers
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+static int pick_vec(int64_t n, std::initializer_list<const void*> ptrs) {
+  constexpr int V = VecWidth<T>::value;
+  if (n % V != 0) return 1;
+  for (const void* p : ptrs)
+    if (p && (reinterpret_cast<uintptr_t>(p) % 16) != 0) return 1;
+  return V;
+}
+
+#define MFX_VEC_SWITCH(vec, ...)                \
+  if ((vec) > 1) {                              \
+    constexpr int VEC = VecWidth<T>::value;     \
+    __VA_ARGS__;                                \
+  } else {                                      \
+    constexpr int VEC = 1;                      \
+    __VA_ARGS__;                                \
+  }
+
+// workgroup size of the vector kernels: 256 threads (2048-element slices); one wave (512-element slices) only for
+// tiny problems.  (Measured on config 3, n = 102400, p = 1: 50 workgroups x 4 waves beat 200 x 1 wave -- what
+// counts is loads in flight per CU, not the number of CUs touched.)
+static int pick_wg(int64_t n, int64_t p) { return ((n + kSlice - 1) / kSlice) * p >= 16 ? kBlock : 64; }
+
+template <typename T>
+struct Ctx {
+  int64_t n, k, p;
+  int wg, nblk, kmax, vec;
+  hipStream_t stream;
+  Ctx(int64_t n_, int64_t k_, int64_t p_, int vec_, hipStream_t s)
+      : n(n_), k(k_), p(p_), wg(pick_wg(n_, p_)), nblk((int)((n_ + (int64_t)wg * kEpt - 1) / ((int64_t)wg * kEpt))),
+        kmax((int)(k_ + 1)), vec(vec_), stream(s) {}
+  dim3 grid() const { return dim3(nblk, (unsigned)p); }
+};
+
+template <typename T>
+static int launch_dots(const Ctx<T>& c, const T* rows, int64_t rows_ldb, int64_t row_stride, int m,
+                       const T* x, int64_t ldx, T* partial) {
+  if (m <= 0) return MFX_OK;
+  const size_t sh = (size_t)4 * m * sizeof(T);
+  MFX_VEC_SWITCH(c.vec, (k_dots<T, VEC><<<c.grid(), c.wg, sh, c.stream>>>(
+                            rows, rows_ldb, row_stride, m, x, ldx, c.n, partial, c.kmax, c.nblk)));
+  MFX_CHECK_LAUNCH();
+  return MFX_OK;
+}
+
+template <typename T>
+static int launch_update(const Ctx<T>& c, UpdateArgs<T> a, bool dots, bool norm) {
+  a.n = c.n;
+  a.kmax = c.kmax;
+  a.nblk = c.nblk;
+  const size_t sh = (size_t)(a.m + (dots ? 4 * a.m : 0) + 4) * sizeof(T);
+  if (dots && norm) {
+    MFX_VEC_SWITCH(c.vec, (k_update<T, VEC, true, true><<<c.grid(), c.wg, sh, c.stream>>>(a)));
+  } else if (dots) {
+    MFX_VEC_SWITCH(c.vec, (k_update<T, VEC, true, false><<<c.grid(), c.wg, sh, c.stream>>>(a)));
+  } else if (norm) {
+    MFX_VEC_SWITCH(c.vec, (k_update<T, VEC, false, true><<<c.grid(), c.wg, sh, c.stream>>>(a)));
+  } else {
+    MFX_VEC_SWITCH(c.vec, (k_update<T, VEC, false, false><<<c.grid(), c.wg, sh, c.stream>>>(a)));
+  }
+  MFX_CHECK_LAUNCH();
+  return MFX_OK;
+}
+
+template <typename T>
+static int launch_sumsq(const Ctx<T>& c, const T* x, int64_t ldx, T* partial_norm) {
+  MFX_VEC_SWITCH(c.vec, (k_sumsq<T, VEC><<<c.grid(), c.wg, 0, c.stream>>>(x, ldx, c.n, partial_norm, c.nblk)));
+  MFX_CHECK_LAUNCH();
+  return MFX_OK;
+}
+
+template <typename T>
+static int launch_scale(const Ctx<T>& c, const T* x, int64_t ldx, T* y, int64_t ldy, const T* partial_norm,
+                        const T* scale, int mode, T* len_out, int64_t len_ld, T* inv_out) {
+  dim3 grid = y ? c.grid() : dim3(1, (unsigned)c.p);
+  MFX_VEC_SWITCH(c.vec, (k_scale<T, VEC><<<grid, c.wg, 0, c.stream>>>(x, ldx, y, ldy, c.n, partial_norm, c.nblk,
+                                                                        scale, mode, len_out, len_ld, inv_out)));
+  MFX_CHECK_LAUNCH();
+  return MFX_OK;
+}
+
+static int apply_any(const mfx_operator* op, int mode, const void* x, int64_t ldx, const void* aux,
+                     int64_t ldaux, void* y, int64_t ldy, int64_t p, void* ws, int64_t ws_bytes,
+                     hipStream_t stream) {
+  if (op->kind == MFX_OP_CALLBACK) return op_apply_cb(op, mode, x, ldx, aux, ldaux, y, ldy, p, stream);
+  ScopedTimer t(0, stream);
+  return op_apply(op, x, ldx, y, ldy, p, mode == 1 ? 1 : 0, ws, ws_bytes, stream);
+}
+
+}  // namespace mfx

@@ -102,6 +102,13 @@ SYMBOLS = {
     "mfx_tridiag_eigh": (_I, [_P, _P, _I64, _I64, _I64, _I, _P, _P, _P]),
     "mfx_slq_quadform_bwd": (_I, [_P, _P, _P, _P, _P, _I64, _I64, _I, _P, _P, _I64, _P]),
     "mfx_rademacher": (_I, [C.c_uint64, _I64, _I64, _I64, _I, _P, _P]),
+    "mfx_pcg_workspace_bytes": (_I64, [_OPP, _I64, _I64, _I64]),
+    "mfx_pcg_solve": (
+        _I,
+        [_OPP, _P, _I64, _I64, _I64, _P, _I64, _P, _P, _I64, _I64, C.c_double, C.c_double, _I, _P, _P, _P, _P, _I64, _P],
+    ),
+    "mfx_precond_apply": (_I, [_I, _I64, _I64, _P, _P, _P, _P, _I64, _P, _I64, _I64, _P, _I64, _P]),
+    "mfx_partial_cholesky": (_I, [_OPP, _I64, _I, _I, _P, _P, _P, _P, _I64, _P]),
     "mfx_timing_enable": (_I, [_I]),
     "mfx_timing_reset": (_I, []),
     "mfx_timing_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
@@ -186,6 +193,22 @@ def workspace(desc: Operator, n: int, k: int, p: int, device) -> torch.Tensor:
         buf = torch.empty(int(need * 1.0) + 256, dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
+
+
+def scratch(need: int, device) -> torch.Tensor:
+    """Caller-owned scratch of at least ``need`` bytes from the same per-(device, stream) cache."""
+    if need < 0:
+        raise MfxError("workspace size query failed")
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(int(need) + 256, dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def workspace_pcg(desc: Operator, n: int, p: int, rank: int, device) -> torch.Tensor:
+    return scratch(int(get().mfx_pcg_workspace_bytes(C.byref(desc), n, p, rank)), device)
 
 
 def timing_enable(flag: bool):

@@ -1,0 +1,161 @@
+"""Conjugate gradient solvers -- MI355X build.
+
+Same functional surface as the reference's ``matfree_extensions/cg.py``:
+
+    cg_fixed_step(num_matvecs)(A, b)                         pcg_fixed_step(num_matvecs)(A, b, P)
+    cg_adaptive(atol=, rtol=, maxiter=, miniter=)(A, b)      pcg_adaptive(...)(A, b, P)
+        -> (x, info)   info = {"residual_abs", "residual_rel"[, "num_steps"]}
+
+with the whole iteration (cg.py:27-58, 85-135) executed by libmfx (``mfx_pcg_solve``).  ``A`` is a native operator
+(``op.bind(*params)``) or any callable ``A(v)``; ``b`` may be a batch (p, n) of right-hand sides (each is solved
+independently, adaptive stopping included).  ``P`` is ``low_rank.Preconditioner.bind(s)`` (or ``None``): arbitrary Python
+preconditioners are not supported inside the HIP loop.
+
+Differentiation is the rule of ``jax.lax.custom_linear_solve(..., symmetric=True)`` (cg.py:23-25): the cotangent of the
+right-hand side is another solve with the same solver, the cotangent of the operator's parameters is the parameter sweep
+with (-lambda, x); nothing flows through the preconditioner or the info dict.  ``cg_fixed_step_reortho`` (cg.py:140-219,
+marked "needs more work" by the reference's own test) is not part of this build.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .low_rank import BoundPreconditioner
+from .operators import CallbackOp, _PtrRegistry, as_operator
+
+
+def cg_fixed_step(*args, **kwargs):
+    pcg_solve = pcg_fixed_step(*args, **kwargs)
+
+    def cg(A, b):
+        return pcg_solve(A, b, None)
+
+    return cg
+
+
+def pcg_fixed_step(num_matvecs: int, /):
+    cfg = {"maxiter": int(num_matvecs), "miniter": 0, "atol": 1.0, "rtol": 0.0, "adaptive": False}
+
+    def pcg(A, b, P):
+        x, r, _steps = _solve(A, b, P, cfg)
+        return x, {"residual_abs": r, "residual_rel": r / x.detach().abs()}
+
+    return pcg
+
+
+def cg_adaptive(**kwargs):
+    pcg_solve = pcg_adaptive(**kwargs)
+
+    def cg(A, b):
+        return pcg_solve(A, b, None)
+
+    return cg
+
+
+def pcg_adaptive(*, atol: float, rtol, maxiter: int, miniter: int = 0):
+    """atol and rtol follow allclose logic (cg.py:73-74)."""
+    cfg = {"maxiter": int(maxiter), "miniter": int(miniter), "atol": float(atol), "rtol": float(rtol), "adaptive": True}
+
+    def pcg(A, b, P):
+        x, r, steps = _solve(A, b, P, cfg)
+        return x, {"residual_abs": r, "residual_rel": r / x.detach().abs(), "num_steps": steps}
+
+    return pcg
+
+
+def _solve(A, b, P, cfg):
+    op, bound = as_operator(A)
+    params = tuple(bound) if bound is not None else ()
+    if P is not None and not isinstance(P, BoundPreconditioner):
+        raise TypeError("P must be None or low_rank.Preconditioner.bind(s): the PCG loop runs inside libmfx and "
+                        "cannot call back into an arbitrary Python preconditioner")
+    batched = b.dim() == 2
+    B = b if batched else b[None]
+    cparams = op.constrain(*params)
+    x, r, steps = _PcgFn.apply(op, cfg, P, B, *cparams)
+    if not batched:
+        return x[0], r[0], steps[0]
+    return x, r, steps
+
+
+def _run(op, cfg, P, B, cparams):
+    """One mfx_pcg_solve call on detached tensors -> (x, r, steps)."""
+    lib = _lib.get()
+    B = B.contiguous()
+    p, n = B.shape
+    dt, dev = B.dtype, B.device
+    keep = None
+    if isinstance(op, CallbackOp):
+        reg = _PtrRegistry()
+        desc, keep, _ = op.make(cparams, dt, n, reg, want_grads=False)
+    else:
+        desc = op.descriptor(cparams, dt, n)
+    rank, lt, minv, shift = 0, None, None, None
+    if P is not None:
+        pre = P.pre
+        if pre.n != n or pre.lt.dtype != dt:
+            raise ValueError(f"preconditioner of size {pre.n} ({pre.lt.dtype}) used for a system of size {n} ({dt})")
+        rank, lt = pre.rank, pre.lt
+        minv, shift = pre.minv(P.s)
+    ws = _lib.workspace_pcg(desc, n, p, rank, dev)
+    x = torch.empty_like(B)
+    r = torch.empty_like(B)
+    steps = torch.empty((p,), dtype=torch.int64, device=dev)
+    if keep is not None:
+        reg.add_bytes(ws, dt)
+    rc = lib.mfx_pcg_solve(C.byref(desc), _lib.ptr(B), n, n, p, _lib.ptr(lt), rank, _lib.ptr(minv), _lib.ptr(shift),
+                           cfg["maxiter"], cfg["miniter"], cfg["atol"], cfg["rtol"], int(cfg["adaptive"]),
+                           _lib.ptr(x), _lib.ptr(r), _lib.ptr(steps), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+    if keep is not None and keep[1]:
+        raise keep[1][0]
+    _lib.check(rc)
+    return x, r, steps
+
+
+class _PcgFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, op, cfg, P, B, *cparams):
+        tensors = [q for q in cparams if torch.is_tensor(q)]
+        _lib.require_device(B, *tensors)
+        x, r, steps = _run(op, cfg, P, B, cparams)
+        ctx.op, ctx.cfg, ctx.P = op, cfg, P
+        ctx.nontensor = [None if torch.is_tensor(q) else q for q in cparams]
+        ctx.save_for_backward(x, *tensors)
+        ctx.mark_non_differentiable(r, steps)
+        return x, r, steps
+
+    @staticmethod
+    def backward(ctx, dx, _dr, _dsteps):
+        x, *tensors = ctx.saved_tensors
+        it = iter(tensors)
+        cparams = tuple(next(it) if q is None else q for q in ctx.nontensor)
+        op = ctx.op
+        lam, _r, _s = _run(op, ctx.cfg, ctx.P, dx, cparams)  # symmetric=True: the transpose solve is the same solve
+        p, n = x.shape
+        if isinstance(op, CallbackOp):
+            grads = []
+            diff_idx = [i for i, q in enumerate(cparams) if torch.is_tensor(q) and q.is_floating_point()]
+            acc = {i: torch.zeros_like(cparams[i]) for i in diff_idx}
+            for bidx in range(p):
+                with torch.enable_grad():
+                    live = [q.detach().requires_grad_(True) if i in acc else q for i, q in enumerate(cparams)]
+                    diff = [live[i] for i in diff_idx]
+                    if diff:
+                        out = op.fn(x[bidx].detach(), *live)
+                        gs = torch.autograd.grad(out, diff, -lam[bidx], allow_unused=True)
+                        for i, g in zip(diff_idx, gs):
+                            if g is not None:
+                                acc[i].add_(g)
+            grads = [acc.get(i) for i in range(len(cparams))]
+        else:
+            desc = op.descriptor(cparams, x.dtype, n)
+            gstruct, grads = op.new_grads(*cparams)
+            ws = _lib.workspace(desc, n, 1, p, x.device)
+            L = (-lam).contiguous()
+            _lib.check(_lib.get().mfx_op_vjp_params(C.byref(desc), _lib.ptr(L), n, _lib.ptr(x), n, p, C.byref(gstruct),
+                                                    _lib.ptr(ws), ws.numel(), _lib.stream_ptr(x.device)))
+        return (None, None, None, lam, *grads)

@@ -192,6 +192,38 @@ int mfx_slq_quadform_bwd(const void* evals, const void* evecs, const void* fvals
 int mfx_rademacher(uint64_t seed, int64_t first_probe, int64_t p, int64_t n, int dtype, void* out,
                    void* stream);
 
+/* ---- linear solves ("next" tier: the Mahalanobis half of the GP log-marginal likelihood) -------------------------
+ *
+ * (Preconditioned) conjugate gradients on a (p, n) batch of right-hand sides  (cg.py:19-60 pcg_fixed_step,
+ * :74-137 pcg_adaptive; _safe_divide :222-241).  adaptive = 0: exactly `maxiter` iterations (num_matvecs);
+ * adaptive = 1: per right-hand side, iterate while  rms(r / (atol + |x| rtol)) > 1  or steps < miniter, and
+ * steps < maxiter; right-hand sides that stop are frozen, so a batch equals p independent solves.
+ * Optional preconditioner: the Woodbury solve of  s I + L L^T  (low_rank.py:31-43) given Lt = L^T (rank, n)
+ * row-major, minv = (s I + L^T L)^{-1} (rank, rank) and the device scalar s; precond_lt = NULL: none.
+ * Outputs: x, r (p, n) packed (final iterate and residual, cg.py:39), num_steps int64 (p) or NULL.
+ * Differentiation follows jax.lax.custom_linear_solve (cg.py:23-25): the caller solves again with the cotangent
+ * and feeds (-lambda, x) to mfx_op_vjp_params. */
+int64_t mfx_pcg_workspace_bytes(const mfx_operator* op, int64_t n, int64_t p, int64_t rank);
+int mfx_pcg_solve(const mfx_operator* op, const void* b, int64_t ldb, int64_t n, int64_t p,
+                  const void* precond_lt, int64_t rank, const void* precond_minv,
+                  const void* precond_shift, int64_t maxiter, int64_t miniter, double atol, double rtol,
+                  int adaptive, void* x, void* r, void* num_steps, void* ws, int64_t ws_bytes,
+                  void* stream);
+
+/* z = (v - L (s I + L^T L)^{-1} L^T v) / s on a (p, n) batch: the `solve(v, s)` of low_rank.py:31-43.
+ * Workspace: mfx_pcg_workspace_bytes of any operator of this n and dtype. */
+int mfx_precond_apply(int dtype, int64_t n, int64_t rank, const void* lt, const void* minv,
+                      const void* shift, const void* v, int64_t ldv, void* z, int64_t ldz, int64_t p,
+                      void* ws, int64_t ws_bytes, void* stream);
+
+/* Partial Cholesky factor of a dense or kernel-Gram operator, element access instead of the reference's
+ * lazy_kernel(i, j) callable (low_rank.py:63-120 without pivoting, :123-228 with pivoting).  Output Lt (rank, n)
+ * = the reference's factor transposed, already in the original row order (low_rank.py:227-228); pivots int64
+ * (rank); success int32 (all pivots positive, :205).  with_noise adds the operator's noise to the diagonal
+ * (likelihood_pdf, util/gp_util.py:225-226) or leaves it out (likelihood_pdf_p, :253-254). */
+int mfx_partial_cholesky(const mfx_operator* op, int64_t rank, int pivot, int with_noise, void* lt,
+                         void* pivots, void* success, void* ws, int64_t ws_bytes, void* stream);
+
 /* Per-kernel-class device timing with hipEvents recorded on the caller's stream (no host syncs
  * while enabled; events are read back in mfx_timing_read, which synchronises the events).
  * classes: 0 = operator apply, 1 = operator parameter-gradient sweep, 2 = Krylov vector kernels. */

@@ -556,3 +556,141 @@ def laplacian_2d_plus_identity(m):
         cols += [b.ravel(), a.ravel()]
         vals += [np.full(a.size, -1.0)] * 2
     return np.concatenate(rows), np.concatenate(cols), np.concatenate(vals), m * m
+
+
+# --------------------------------------------------------------------------------------
+# "next" tier: conjugate gradients, partial Cholesky, preconditioner, logpdf
+# --------------------------------------------------------------------------------------
+
+
+def safe_divide(a, b):
+    """cg.py:222-241: a / b where |b| > eps(dtype)^2, else a."""
+    eps = np.finfo(np.asarray(a).dtype).eps ** 2
+    return a / b if abs(b) > eps else a
+
+
+def _pcg_body(A, P, state):
+    """cg.py:44-57 (identical in the fixed-step and the adaptive solver, :112-127)."""
+    x, p, r, z = state
+    Ap = A(p)
+    a = safe_divide(r @ z, p @ Ap)
+    x = x + a * p
+    rold, zold = r, z
+    r = r - a * Ap
+    z = P(r)
+    b = safe_divide(r @ z, rold @ zold)
+    p = z + b * p
+    return x, p, r, z
+
+
+def pcg_fixed_step(A, b, P=None, *, num_matvecs):
+    """cg.py:19-60.  -> (x, info)"""
+    P = (lambda v: v) if P is None else P
+    x = np.zeros_like(b)
+    r = b - A(x)
+    z = P(r)
+    state = (x, z, r, z)
+    for _ in range(num_matvecs):
+        state = _pcg_body(A, P, state)
+    x, _p, r, _z = state
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return x, {"residual_abs": r, "residual_rel": r / np.abs(x)}
+
+
+def pcg_adaptive(A, b, P=None, *, atol, rtol, maxiter, miniter=0):
+    """cg.py:74-137.  -> (x, info)"""
+    P = (lambda v: v) if P is None else P
+    x = np.zeros_like(b)
+    r = b - A(x)
+    z = P(r)
+    state, nsteps = (x, z, r, z), 0
+    while True:
+        x, _p, r, _z = state
+        error_rel = r / (atol + np.abs(x) * rtol)
+        is_error_large = np.sqrt(np.mean(error_rel**2)) > 1.0
+        if not ((is_error_large or nsteps < miniter) and nsteps < maxiter):
+            break
+        state = _pcg_body(A, P, state)
+        nsteps += 1
+    x, _p, r, _z = state
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return x, {"residual_abs": r, "residual_rel": r / np.abs(x), "num_steps": nsteps}
+
+
+def linear_solve_vjp(op, params, solver, x, dx):
+    """The rule of jax.lax.custom_linear_solve(..., symmetric=True) (cg.py:23-25) for x = solver(A(theta), b):
+    db = solver(A, dx) (the transpose solve IS the solve), dtheta = vjp of theta -> A(theta) x with cotangent -db."""
+    lam, _ = solver(lambda v: op.apply(v, *params), dx)
+    return lam, op.param_vjp(x, -lam, *params)
+
+
+def cholesky_partial(element, n, rank):
+    """low_rank.py:63-120.  element(i, j) -> K_ij.  -> L (n, rank)"""
+    if rank > n:
+        raise ValueError(f"Rank exceeds n: {rank} >= {n}.")
+    if rank < 1:
+        raise ValueError(f"Rank must be positive, but {rank} < {1}.")
+    L = np.zeros((n, rank))
+    for i in range(rank):
+        l_ii = np.sqrt(element(i, i) - L[i] @ L[i])
+        column = np.array([element(j, i) for j in range(n)])
+        L[:, i] = (column - L @ L[i, :]) / l_ii
+    return L, {}
+
+
+def cholesky_partial_pivot(element, n, rank):
+    """low_rank.py:123-228, with the reference's explicit row permutations (the HIP kernels work in the original
+    row order instead; the tests check both give the same factor)."""
+    if rank > n:
+        raise ValueError(f"Rank exceeds n: {rank} >= {n}.")
+    if rank < 1:
+        raise ValueError(f"Rank must be positive, but {rank} < {1}.")
+    L = np.zeros((n, rank))
+    P = np.arange(n)
+    Pm = np.arange(n)
+    success = True
+    with np.errstate(invalid="ignore"):
+        for i in range(rank):
+            diagonal = np.array([element(Pm[j], Pm[j]) for j in range(n)])
+            res = np.abs(diagonal - np.einsum("jc,jc->j", L, L))
+            k = int(np.argmax(res))
+            Pm[[i, k]] = Pm[[k, i]]
+            L[[i, k]] = L[[k, i]]
+            P[[i, k]] = P[[k, i]]
+            el = element(Pm[i], Pm[i])
+            column = np.array([element(Pm[j], Pm[i]) for j in range(n)])
+            l_ii_squared = el - L[i] @ L[i]
+            l_ii = np.sqrt(l_ii_squared)
+            l_ji = (column - L @ L[i, :]) / l_ii
+            success = bool(success and l_ii_squared > 0.0)
+            L[:, i] = l_ji
+    return L[np.argsort(P)], {"success": success, "pivots": P[:rank].copy()}
+
+
+def precondition_solve(chol, v, s):
+    """low_rank.py:31-43: (s I + L L^T)^{-1} v via the capacitance matrix."""
+    import scipy.linalg
+
+    N, n = chol.shape
+    assert n <= N, (N, n)
+    U = chol / np.sqrt(s)
+    V = chol.T / np.sqrt(s)
+    v = v / s
+    cap = scipy.linalg.cho_factor(np.eye(n) + V @ U)
+    return v - U @ scipy.linalg.cho_solve(cap, V @ v)
+
+
+def logpdf_cholesky(y, mean, cov):
+    """util/gp_util.py:367-393."""
+    import scipy.linalg
+
+    chol = np.linalg.cholesky(cov)
+    logdet = np.sum(np.log(np.diag(chol)))
+    tmp = scipy.linalg.solve_triangular(chol, y - mean, lower=True)
+    return -logdet - 0.5 * (tmp @ tmp) - len(mean) / 2 * np.log(2 * np.pi)
+
+
+def logpdf_krylov(y, mean, *, logdet_value, solve):
+    """util/gp_util.py:396-431: -logdet/2 - (y - m)^T solve(y - m)/2 - n/2 log(2 pi); `solve(b) -> (x, info)`."""
+    tmp, info = solve(y - mean)
+    return -logdet_value / 2 - 0.5 * ((y - mean) @ tmp) - len(mean) / 2 * np.log(2 * np.pi), info

@@ -287,3 +287,119 @@ def test_reuse_gradient_is_first_order_approximation():
     assert np.allclose(g2, np.outer(np.linalg.solve(A, v0), v0), atol=1e-8)
     # inexact per probe (Dong et al. 2017): only the probe-average matches the true gradient
     assert not np.allclose(0.5 * (g + g.T), 0.5 * (g2 + g2.T), atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------
+# "next" tier: CG and low-rank restatements against the reference's own tests
+# (tests/test_cg/test_cg.py, tests/test_low_rank/test_low_rank.py)
+# ------------------------------------------------------------------------------------------------
+def test_cg_fixed_and_adaptive_solve_the_system():
+    A = orc.symmetric_matrix_from_eigenvalues(np.arange(1.0, 10.0))
+    b = np.arange(1.0, 10.0)
+    solution = np.linalg.solve(A, b)
+    x, _ = orc.pcg_fixed_step(lambda v: A @ v, b, num_matvecs=len(A))  # test_cg.py:10-18
+    assert np.allclose(x, solution)
+    x, info = orc.pcg_adaptive(lambda v: A @ v, b, atol=1e-5, rtol=1e-5, maxiter=100)  # test_cg.py:21-29
+    assert np.allclose(x, solution) and 0 < info["num_steps"] <= 100
+
+
+def test_cg_more_matvecs_improve_error():  # test_cg.py:87-99
+    A = orc.symmetric_matrix_from_eigenvalues(np.arange(1.0, 10.0))
+    b = np.arange(1.0, 10.0)
+    error = 100.0
+    for n in range(len(A)):
+        _x, info = orc.pcg_fixed_step(lambda v: A @ v, b, num_matvecs=n)
+        now = np.linalg.norm(info["residual_abs"])
+        assert now < error, (n, now)
+        error = now
+
+
+def test_cg_runs_past_convergence_without_nans():  # the purpose of _safe_divide, cg.py:222-231
+    A = orc.symmetric_matrix_from_eigenvalues(np.arange(1.0, 6.0))
+    b = np.arange(1.0, 6.0)
+    x, _ = orc.pcg_fixed_step(lambda v: A @ v, b, num_matvecs=60)
+    assert np.all(np.isfinite(x)) and np.allclose(x, np.linalg.solve(A, b))
+
+
+@pytest.mark.parametrize("factor", [orc.cholesky_partial, orc.cholesky_partial_pivot])
+def test_full_rank_cholesky_reconstructs_matrix(factor, n=5):  # test_low_rank.py:12-25
+    cov = orc.symmetric_matrix_from_eigenvalues(1.0 + np.random.default_rng(2).uniform(size=n))
+    approx, _ = factor(lambda i, j: cov[i, j], n, n)
+    assert approx.shape == (n, n)
+    assert np.allclose(approx @ approx.T, cov, atol=1e-12, rtol=1e-12)
+
+
+def test_full_rank_nopivot_matches_cholesky(n=10):  # test_low_rank.py:28-41
+    cov = orc.symmetric_matrix_from_eigenvalues(0.01 + np.random.default_rng(2).uniform(size=n))
+    chol = np.linalg.cholesky(cov)
+    received, _ = orc.cholesky_partial_pivot(lambda i, j: cov[i, j], n, n)
+    assert not np.allclose(received, chol)
+    received, _ = orc.cholesky_partial(lambda i, j: cov[i, j], n, n)
+    assert np.allclose(received, chol, atol=1e-6)
+
+
+def test_pivoting_improves_the_estimate_and_rank_errors(n=10, rank=5):  # test_low_rank.py:58-73, low_rank.py:67-72
+    cov = orc.symmetric_matrix_from_eigenvalues(0.1 + np.random.default_rng(1).uniform(size=n))
+    el = lambda i, j: cov[i, j]
+    nopivot, _ = orc.cholesky_partial(el, n, rank)
+    pivot, info = orc.cholesky_partial_pivot(el, n, rank)
+    assert info["success"]
+    assert np.linalg.norm(cov - pivot @ pivot.T) < np.linalg.norm(cov - nopivot @ nopivot.T)
+    with pytest.raises(ValueError):
+        orc.cholesky_partial_pivot(el, n, n + 1)
+    with pytest.raises(ValueError):
+        orc.cholesky_partial(el, n, 0)
+
+
+def test_preconditioner_solves_correctly(n=10):  # test_low_rank.py:76-103
+    cov = orc.symmetric_matrix_from_eigenvalues(1.5 ** np.arange(-n // 2, n // 2, 1.0))
+    L, _ = orc.cholesky_partial(lambda i, j: cov[i, j], n, n)
+    assert np.allclose(L @ L.T, cov)
+    b = np.arange(1.0, 1 + n)
+    b /= np.linalg.norm(b)
+    expected = np.linalg.solve(cov + 1e-1 * np.eye(n), b)
+    assert np.allclose(orc.precondition_solve(L, b, 1e-1), expected, rtol=1e-2)
+
+
+def test_pcg_with_pivoted_cholesky_preconditioner_converges_faster():
+    # the use the GP experiments make of it (optim_logml_adjoints_fixed.py:84-99): K + sigma I, rank-r preconditioner
+    rng = np.random.default_rng(0)
+    X = rng.uniform(-1, 1, (60, 2))
+    K = orc.kernel_matrix("rbf", X, X, 0.7, 1.3)
+    sigma = 1e-2
+    A = K + sigma * np.eye(60)
+    b = rng.standard_normal(60)
+    L, info = orc.cholesky_partial_pivot(lambda i, j: K[i, j], 60, 15)
+    assert info["success"]
+    P = lambda v: orc.precondition_solve(L, v, sigma)
+    _x, plain = orc.pcg_fixed_step(lambda v: A @ v, b, num_matvecs=8)
+    _x, pre = orc.pcg_fixed_step(lambda v: A @ v, b, P, num_matvecs=8)
+    assert np.linalg.norm(pre["residual_abs"]) < 1e-2 * np.linalg.norm(plain["residual_abs"])
+
+
+def test_logpdf_krylov_equals_logpdf_cholesky_when_solves_are_exact_and_linear_solve_vjp():
+    rng = np.random.default_rng(1)
+    n = 12
+    X = rng.uniform(-1, 1, (n, 2))
+    op = orc.RbfGramOp(X, noise_minval=1e-3)
+    params = (np.float64(0.3), np.float64(0.1), np.float64(-1.0))
+    cov = np.stack([op.apply(e, *params) for e in np.eye(n)]).T
+    y, mean = rng.standard_normal(n), np.full(n, 0.2)
+    solve = lambda b: orc.pcg_fixed_step(lambda v: op.apply(v, *params), b, num_matvecs=3 * n)
+    got, _ = orc.logpdf_krylov(y, mean, logdet_value=np.linalg.slogdet(cov)[1], solve=solve)
+    assert np.allclose(got, orc.logpdf_cholesky(y, mean, cov), rtol=1e-10)
+    # the implicit-differentiation rule against central differences of b^T A(theta)^{-1} b
+    b = y - mean
+    x, _ = solve(b)
+    solver = lambda A, rhs: orc.pcg_fixed_step(A, rhs, num_matvecs=3 * n)
+    lam, dparams = orc.linear_solve_vjp(op, params, solver, x, b)  # cotangent of x in b^T x is b
+    h = 1e-6
+    for idx in range(3):
+        def f(s):
+            q = list(params)
+            q[idx] = q[idx] + s
+            c = np.stack([op.apply(e, *q) for e in np.eye(n)]).T
+            return b @ np.linalg.solve(c, b)
+        fd = (f(h) - f(-h)) / (2 * h)
+        assert np.allclose(dparams[idx], fd, rtol=1e-5), (idx, dparams[idx], fd)
+    assert np.allclose(lam, x)
