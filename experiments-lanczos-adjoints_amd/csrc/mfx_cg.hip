@@ -602,6 +602,19 @@ int mfx_precond_apply(int dtype, int64_t n, int64_t rank, const void* lt, const 
                                  nullptr);
 }
 
+int64_t mfx_gram_cross_workspace_bytes(const mfx_operator* op, int64_t m) {
+  if (!op || op->kind != MFX_OP_RBF || m <= 0) return -1;
+  return rbf_cross_ws_bytes(op, m) + 256;
+}
+
+int mfx_gram_cross_apply(const mfx_operator* op, const void* xnew, int64_t m, const void* v, int64_t ldv, void* y,
+                         int64_t ldy, int64_t p, void* ws, int64_t ws_bytes, void* stream) {
+  MFX_REQUIRE(op && xnew && v && y, MFX_ERR_INVALID, "mfx_gram_cross_apply: null argument");
+  MFX_REQUIRE(m >= 1 && p >= 1 && ldv >= op->n && ldy >= m, MFX_ERR_INVALID, "mfx_gram_cross_apply: bad sizes");
+  MFX_REQUIRE(p <= 65535 * 8, MFX_ERR_UNSUPPORTED, "too many vectors per call");
+  return op_cross_apply(op, xnew, m, v, ldv, y, ldy, p, ws, ws_bytes, static_cast<hipStream_t>(stream));
+}
+
 int mfx_partial_cholesky(const mfx_operator* op, int64_t rank, int pivot, int with_noise, void* lt, void* pivots,
                          void* success, void* ws, int64_t ws_bytes, void* stream) {
   MFX_REQUIRE(op && lt && pivots && success, MFX_ERR_INVALID, "mfx_partial_cholesky: null argument");

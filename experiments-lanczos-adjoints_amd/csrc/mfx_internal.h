@@ -77,6 +77,10 @@ int op_vjp_params(const mfx_operator* op, const void* L, int64_t ldl, const void
                   int64_t batch, const mfx_op_grads* grads, void* ws, int64_t ws_bytes,
                   hipStream_t stream);
 
+int64_t rbf_cross_ws_bytes(const mfx_operator* op, int64_t m);
+int op_cross_apply(const mfx_operator* op, const void* xnew, int64_t m, const void* v, int64_t ldv, void* y, int64_t ldy,
+                   int64_t p, void* ws, int64_t ws_bytes, hipStream_t stream);
+
 #ifdef __HIPCC__
 // ---- wave64 / workgroup reductions -------------------------------------------------------------
 template <typename T>

@@ -147,18 +147,22 @@ template <typename T, int DPAD, int PB>
 __global__ __launch_bounds__(256) void k_rbf_apply(const T* __restrict__ xs, const T* __restrict__ sq, int64_t n,
                                                    const T* __restrict__ outputscale, const T* __restrict__ noise,
                                                    const T* __restrict__ x, int64_t ldx, T* __restrict__ y,
-                                                   int64_t ldy, int64_t p, int kind) {
+                                                   int64_t ldy, int64_t p, int kind,
+                                                   const T* __restrict__ xrow, const T* __restrict__ sqrow, int64_t m) {
+  // rows i < m come from (xrow, sqrow); xrow == xs is the square Gram operator (self distances exactly 0, noise on
+  // the diagonal), anything else the cross-covariance K(X_new, X) of the posterior mean (util/gp_util.py:299-301)
+  const bool self = xrow == xs;
   __shared__ __attribute__((aligned(16))) T xj[kRbfTJ][DPAD];
   __shared__ T sqj[kRbfTJ];
   __shared__ T vj[PB][kRbfTJ];
   const int tid = threadIdx.x;
   const int64_t i = (int64_t)blockIdx.x * 256 + tid;
   const int64_t b0 = (int64_t)blockIdx.y * PB;
-  const int64_t ic = i < n ? i : n - 1;
+  const int64_t ic = i < m ? i : m - 1;
   T xi[DPAD];
 #pragma unroll
-  for (int c = 0; c < DPAD; ++c) xi[c] = xs[ic * DPAD + c];
-  const T sqi = sq[ic];
+  for (int c = 0; c < DPAD; ++c) xi[c] = xrow[ic * DPAD + c];
+  const T sqi = sqrow[ic];
   T acc[PB];
 #pragma unroll
   for (int q = 0; q < PB; ++q) acc[q] = T(0);
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(256) void k_rbf_apply(const T* __restrict__ xs, con
       if (kind == MFX_KERNEL_RBF) {
         kv = exp_neg_half(dist);
       } else {
-        if (j0 + jj == i) dist = T(0);  // a point's distance to itself is exactly 0 (sqrt amplifies round-off)
+        if (self && j0 + jj == i) dist = T(0);  // a point's distance to itself is exactly 0 (sqrt amplifies round-off)
         kernel_eval<T>(kind, dist, kv, wl);
       }
 #pragma unroll
@@ -192,11 +196,11 @@ __global__ __launch_bounds__(256) void k_rbf_apply(const T* __restrict__ xs, con
     }
     __syncthreads();
   }
-  if (i < n) {
+  if (i < m) {
     const T s = outputscale[0], nz = noise[0];
 #pragma unroll
     for (int q = 0; q < PB; ++q)
-      if (b0 + q < p) y[(b0 + q) * ldy + i] = s * acc[q] + nz * x[(b0 + q) * ldx + i];
+      if (b0 + q < p) y[(b0 + q) * ldy + i] = self ? s * acc[q] + nz * x[(b0 + q) * ldx + i] : s * acc[q];
   }
 }
 
@@ -368,11 +372,17 @@ static int rbf_prep(const mfx_operator* op, const RbfWs& w, int dpad, hipStream_
 
 template <typename T, int DPAD>
 static int rbf_apply_d(const mfx_operator* op, const RbfWs& w, const T* x, int64_t ldx, T* y, int64_t ldy, int64_t p,
-                       hipStream_t stream) {
-  const unsigned gx = (unsigned)((op->n + 255) / 256);
+                       hipStream_t stream, const T* xrow = nullptr, const T* sqrow = nullptr, int64_t m = 0) {
+  if (!xrow) {
+    xrow = (const T*)w.xs;
+    sqrow = (const T*)w.sq;
+    m = op->n;
+  }
+  const unsigned gx = (unsigned)((m + 255) / 256);
 #define MFX_RBF_LAUNCH(PB)                                                                           \
   k_rbf_apply<T, DPAD, PB><<<dim3(gx, (unsigned)((p + PB - 1) / PB)), 256, 0, stream>>>(               \
-      (const T*)w.xs, (const T*)w.sq, op->n, (const T*)op->outputscale, (const T*)op->noise, x, ldx, y, ldy, p, op->kernel_fn)
+      (const T*)w.xs, (const T*)w.sq, op->n, (const T*)op->outputscale, (const T*)op->noise, x, ldx, y, ldy, p, \
+      op->kernel_fn, xrow, sqrow, m)
   if (p == 1) {
     MFX_RBF_LAUNCH(1);
   } else if (p == 2) {
@@ -396,6 +406,10 @@ static int rbf_apply(const mfx_operator* op, const T* x, int64_t ldx, T* y, int6
   MFX_REQUIRE(rbf_carve(op, ws, ws_bytes, &w) <= ws_bytes && ws, MFX_ERR_WORKSPACE, "RBF workspace too small");
   MFX_TRY(rbf_prep<T>(op, w, dpad, stream));
   if constexpr (sizeof(T) == 4) {
+    // 1-3 vectors (the CG solves of the log-marginal likelihood): the VALU kernel below costs 2-2.7x a matrix-core
+    // sweep over one 32-probe block (measured, n = 131072: 12.9 vs 5.9 ms), whose probe guards handle any p >= 1
+    if (p < 4 && op->n >= 2048 && rbf_mfma_supported(op, 4) && rbf_mode(op) >= MFX_RBF_F16X3_MATVEC)
+      return rbf_mfma_apply_h3(op, (const float*)w.xs, (const float*)w.sq, dpad, x, ldx, y, ldy, p, w.vscale, stream);
     if (rbf_mfma_supported(op, p)) {
       if (rbf_mode(op) >= MFX_RBF_F16X3_MATVEC)
         return rbf_mfma_apply_h3(op, (const float*)w.xs, (const float*)w.sq, dpad, x, ldx, y, ldy, p, w.vscale, stream);
@@ -411,6 +425,46 @@ static int rbf_apply(const mfx_operator* op, const T* x, int64_t ldx, T* y, int6
     case 16: return rbf_apply_d<T, 16>(op, w, x, ldx, y, ldy, p, stream);
     default: return rbf_apply_d<T, 32>(op, w, x, ldx, y, ldy, p, stream);
   }
+}
+
+// y (p, m) = K(X_new, X) v: the cross-covariance matvec of the posterior mean (util/gp_util.py:299-305), no noise term
+template <typename T>
+static int rbf_cross_apply(const mfx_operator* op, const T* xnew, int64_t m, const T* v, int64_t ldv, T* y, int64_t ldy,
+                           int64_t p, void* ws, int64_t ws_bytes, hipStream_t stream) {
+  const int dpad = rbf_dpad(op->d);
+  MFX_REQUIRE(dpad > 0, MFX_ERR_UNSUPPORTED, "RBF operator supports d <= 32 (got %d)", op->d);
+  RbfWs w;
+  const int64_t base = rbf_carve(op, ws, ws_bytes, &w);
+  Carver cv(ws ? (char*)ws + base : nullptr, ws_bytes - base);
+  T* xr = (T*)cv.take(m * dpad * sizeof(T));
+  T* sqr = (T*)cv.take(m * sizeof(T));
+  MFX_REQUIRE(ws && base + cv.off <= ws_bytes, MFX_ERR_WORKSPACE, "cross-Gram workspace too small");
+  MFX_TRY(rbf_prep<T>(op, w, dpad, stream));
+  k_rbf_prep<T><<<(unsigned)((m + 255) / 256), 256, 0, stream>>>(xnew, m, op->d, dpad, (const T*)op->lengthscale, op->ard,
+                                                                xr, sqr);
+  MFX_CHECK_LAUNCH();
+  switch (dpad) {
+    case 4: return rbf_apply_d<T, 4>(op, w, v, ldv, y, ldy, p, stream, xr, sqr, m);
+    case 8: return rbf_apply_d<T, 8>(op, w, v, ldv, y, ldy, p, stream, xr, sqr, m);
+    case 12: return rbf_apply_d<T, 12>(op, w, v, ldv, y, ldy, p, stream, xr, sqr, m);
+    case 16: return rbf_apply_d<T, 16>(op, w, v, ldv, y, ldy, p, stream, xr, sqr, m);
+    default: return rbf_apply_d<T, 32>(op, w, v, ldv, y, ldy, p, stream, xr, sqr, m);
+  }
+}
+
+int64_t rbf_cross_ws_bytes(const mfx_operator* op, int64_t m) {
+  const int dpad = rbf_dpad(op->d);
+  return rbf_carve(op, nullptr, 0, nullptr) + align_up(m * (dpad > 0 ? dpad : 1) * dtype_size(op->dtype), 256) +
+         align_up(m * dtype_size(op->dtype), 256);
+}
+
+int op_cross_apply(const mfx_operator* op, const void* xnew, int64_t m, const void* v, int64_t ldv, void* y, int64_t ldy,
+                   int64_t p, void* ws, int64_t ws_bytes, hipStream_t stream) {
+  MFX_REQUIRE(op->kind == MFX_OP_RBF, MFX_ERR_UNSUPPORTED, "cross-covariance matvec needs a kernel-Gram operator");
+  ScopedTimer t(0, stream);
+  if (op->dtype == MFX_F32)
+    return rbf_cross_apply<float>(op, (const float*)xnew, m, (const float*)v, ldv, (float*)y, ldy, p, ws, ws_bytes, stream);
+  return rbf_cross_apply<double>(op, (const double*)xnew, m, (const double*)v, ldv, (double*)y, ldy, p, ws, ws_bytes, stream);
 }
 
 template <typename T>

@@ -42,11 +42,22 @@ __device__ __forceinline__ float dist_factor(int kind) {  // multiplies the squa
   return kind == MFX_KERNEL_RBF ? -0.72134752044448170368f : (kind == MFX_KERNEL_MATERN32 ? 3.f : 1.f) * kLog2e * kLog2e;
 }
 // K / outputscale from t = factor * dist (un-clamped), shift = log2 of an optional power-of-two scale of K
+// sqrt as ONE v_sqrt_f32 (1 ulp): __builtin_sqrtf expands to a 16-instruction correctly-rounded sequence, which made
+// the Matern Gram matvec 2.5x the RBF one (every VALU instruction per kernel entry is paid in full here).
 template <int KIND>
 __device__ __forceinline__ float matern_from_t(float t, float shift) {
-  const float rp = __builtin_sqrtf(fmaxf(t, 0.f) + kEpsF32 * kLog2e * kLog2e);
+  const float rp = __builtin_amdgcn_sqrtf(fmaxf(t, 0.f) + kEpsF32 * kLog2e * kLog2e);
   const float e = __builtin_amdgcn_exp2f(shift - rp);
   return KIND == MFX_KERNEL_MATERN32 ? fmaf(e * rp, kLn2, e) : e;
+}
+// the same from te = t + eps log2(e)^2 (the eps rides in the distance product): max(t, 0) + eps' == max(t + eps', eps'),
+// so clamp and offset are one v_med3; `scale` = 2^shift is folded into the polynomial factor (no v_sub before the exp2)
+constexpr float kEpsC = kEpsF32 * kLog2e * kLog2e;
+template <int KIND>
+__device__ __forceinline__ float matern_from_te(float te, float scale) {
+  const float rp = __builtin_amdgcn_sqrtf(__builtin_amdgcn_fmed3f(te, kEpsC, 3.0e38f));
+  const float e = __builtin_amdgcn_exp2f(-rp);
+  return KIND == MFX_KERNEL_MATERN32 ? e * fmaf(rp, kLn2 * scale, scale) : e * scale;
 }
 
 // epilogue of the gradient GEMMs: K_ij / outputscale and the lengthscale weight from the clamped squared distance
@@ -55,12 +66,12 @@ __device__ __forceinline__ void grad_weights(int kind, float dist, float& kv, fl
     kv = __builtin_amdgcn_exp2f(-0.72134752044448170368f * dist);
     wl = kv;
   } else if (kind == MFX_KERNEL_MATERN32) {
-    const float r = __builtin_sqrtf(3.f * dist + kEpsF32);
+    const float r = __builtin_amdgcn_sqrtf(3.f * dist + kEpsF32);
     const float e = __builtin_amdgcn_exp2f(-kLog2e * r);
     kv = (1.f + r) * e;
     wl = 3.f * e;
   } else {
-    const float r = __builtin_sqrtf(dist + kEpsF32);
+    const float r = __builtin_amdgcn_sqrtf(dist + kEpsF32);
     const float e = __builtin_amdgcn_exp2f(-kLog2e * r);
     kv = e;
     wl = dist > 0.f ? e / r : 0.f;
@@ -678,7 +689,7 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
     }
     if (tid < kTJ) {
       // K' = 2^15 K: lo(K') stays a NORMAL f16 for K >= 4e-6 (RBF: shift folded into the product; Matern: into exp2)
-      tl.aj[DPAD][tid] = cfac * rsq + (KIND == MFX_KERNEL_RBF ? kKShift : 0.f);
+      tl.aj[DPAD][tid] = cfac * rsq + (KIND == MFX_KERNEL_RBF ? kKShift : kEpsC);
       tl.aj[DPAD + 1][tid] = cfac;
     }
   };
@@ -693,10 +704,10 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
     } else {
       // register r <-> column (r & 3) + 8 (r >> 2) + 4 lhi of the block: zero self-distance on the diagonal block
       const int r0 = 8 * s + q, r1 = r0 + 1;
-      const float t0 = (diag_blk && l31 == (r0 & 3) + 8 * (r0 >> 2) + 4 * lhi) ? 0.f : kd[r0];
-      const float t1 = (diag_blk && l31 == (r1 & 3) + 8 * (r1 >> 2) + 4 * lhi) ? 0.f : kd[r1];
-      k0 = matern_from_t<KIND>(t0, kKShift);
-      k1 = matern_from_t<KIND>(t1, kKShift);
+      const float t0 = (diag_blk && l31 == (r0 & 3) + 8 * (r0 >> 2) + 4 * lhi) ? kEpsC : kd[r0];
+      const float t1 = (diag_blk && l31 == (r1 & 3) + 8 * (r1 >> 2) + 4 * lhi) ? kEpsC : kd[r1];
+      k0 = matern_from_te<KIND>(t0, 32768.f);
+      k1 = matern_from_te<KIND>(t1, 32768.f);
     }
     const half2v h = {(_Float16)k0, (_Float16)k1};  // one v_cvt_pk_f16_f32 (round to nearest)
     // lo = k - hi in ONE instruction each: v_fma_mix_f32 reads the f16 half directly (no v_cvt_f32_f16 + v_sub).

@@ -109,6 +109,8 @@ SYMBOLS = {
     ),
     "mfx_precond_apply": (_I, [_I, _I64, _I64, _P, _P, _P, _P, _I64, _P, _I64, _I64, _P, _I64, _P]),
     "mfx_partial_cholesky": (_I, [_OPP, _I64, _I, _I, _P, _P, _P, _P, _I64, _P]),
+    "mfx_gram_cross_workspace_bytes": (_I64, [_OPP, _I64]),
+    "mfx_gram_cross_apply": (_I, [_OPP, _P, _I64, _P, _I64, _P, _I64, _I64, _P, _I64, _P]),
     "mfx_timing_enable": (_I, [_I]),
     "mfx_timing_reset": (_I, []),
     "mfx_timing_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -249,6 +249,25 @@ class RbfGramOp(NativeOp):
         desc.kernel_fn = self._KERNELS[self.kernel]
         desc.lengthscale, desc.outputscale, desc.noise = ls.data_ptr(), s.data_ptr(), nz.data_ptr()
 
+    def cross_apply(self, xnew, v, *params):
+        """K(xnew, X) v (no noise term): the prior cross-covariance matvec of the posterior mean
+        (util/gp_util.py:299-305).  xnew (m, d), v (n,) or (p, n) -> (m,) or (p, m).  Not differentiable."""
+        with torch.no_grad():
+            cparams = self.constrain(*params)
+            _lib.require_device(xnew, v, *cparams)
+            V = (v if v.dim() == 2 else v[None]).contiguous()
+            xnew = xnew.to(self.X.dtype).contiguous()
+            if xnew.dim() != 2 or xnew.shape[1] != self.d or V.shape[1] != self.n:
+                raise ValueError(f"cross_apply: xnew {tuple(xnew.shape)}, v {tuple(v.shape)} do not match X {tuple(self.X.shape)}")
+            m, p = xnew.shape[0], V.shape[0]
+            desc = self.descriptor(cparams, V.dtype, self.n)
+            lib = _lib.get()
+            ws = _lib.scratch(int(lib.mfx_gram_cross_workspace_bytes(C.byref(desc), m)), V.device)
+            y = torch.empty((p, m), dtype=V.dtype, device=V.device)
+            _lib.check(lib.mfx_gram_cross_apply(C.byref(desc), _lib.ptr(xnew), m, _lib.ptr(V), self.n, _lib.ptr(y), m, p,
+                                                _lib.ptr(ws), ws.numel(), _lib.stream_ptr(V.device)))
+        return y if v.dim() == 2 else y[0]
+
     def new_grads(self, ls, s, nz):
         g = (torch.zeros_like(ls), torch.zeros_like(s), torch.zeros_like(nz))
         st = _lib.OpGrads()

@@ -4,8 +4,7 @@ Covers the pieces of the reference's ``util/gp_util.py`` that sit on the hot pat
 kernel parametrisation (:151-184), the softplus constraint (:187-201), the Gram matvec (:434-549,
 here a native matrix-free operator instead of materialised row partitions) and the SLQ log-determinant
 estimators (:552-621); plus the "next" tier: the model / likelihood / logpdf plumbing of the
-log-marginal likelihood (:15-66, 216-276, 367-431) on top of ``cg`` and ``low_rank``.  The posterior-prediction helpers
-(target_posterior, likelihood_condition[_p], :35-45,279-351) are not part of this build.
+log-marginal likelihood and of the posterior mean (:15-66, 216-351, 367-431) on top of ``cg`` and ``low_rank``.
 """
 
 from __future__ import annotations
@@ -309,3 +308,47 @@ def logpdf_krylov_p(solve_p, logdet):
         return -logdet_ - 0.5 * mahalanobis - n / 2 * math.log(2 * math.pi), info
 
     return logpdf
+
+
+def target_posterior(model, likelihood, /):
+    """util/gp_util.py:35-45: -> posterior(inputs, targets, params_mean, params_kernel, params_likelihood) -> (predict, {})
+    with predict(xs) -> (posterior mean at xs, info)."""
+
+    def posterior(inputs, targets, params_mean: dict, params_kernel: dict, params_likelihood: dict):
+        mean, kernel = model(params_mean, params_kernel)
+        condition = likelihood(inputs, mean, kernel, params=params_likelihood)
+        return (lambda xs: condition(xs, targets=targets)), {}
+
+    return posterior
+
+
+def likelihood_condition(matvec, solve, *, constrain):
+    """util/gp_util.py:279-310: weights = solve(K + noise I, y - m);  prediction = m(xs) + K(xs, X) weights."""
+
+    def likelihood(inputs, mean, kernel, params: dict):
+        cov_matvec = _native_cov(matvec, inputs, kernel, constrain, params["raw_noise"])
+
+        def condition_partial(xs, targets):
+            weights, info = solve(cov_matvec, targets - _mean_array(mean, inputs))
+            return _mean_array(mean, xs) + cov_matvec.op.cross_apply(xs, weights, *cov_matvec.params), {"solve": info}
+
+        return condition_partial
+
+    return likelihood, {"raw_noise": torch.empty(())}
+
+
+def likelihood_condition_p(matvec, solve_p, *, precondition, constrain):
+    """util/gp_util.py:313-351: the same with a preconditioned solve."""
+
+    def likelihood(inputs, mean, kernel, params: dict):
+        cov_matvec = _native_cov(matvec, inputs, kernel, constrain, params["raw_noise"])
+        noise = constrain(params["raw_noise"])
+        pre, _info = precondition(low_rank.without_noise(cov_matvec), len(inputs))
+
+        def condition_partial(xs, targets):
+            weights, info = solve_p(cov_matvec, targets - _mean_array(mean, inputs), P=pre.bind(noise))
+            return _mean_array(mean, xs) + cov_matvec.op.cross_apply(xs, weights, *cov_matvec.params), {"solve": info}
+
+        return condition_partial
+
+    return likelihood, {"raw_noise": torch.empty(())}

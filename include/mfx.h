@@ -224,6 +224,13 @@ int mfx_precond_apply(int dtype, int64_t n, int64_t rank, const void* lt, const 
 int mfx_partial_cholesky(const mfx_operator* op, int64_t rank, int pivot, int with_noise, void* lt,
                          void* pivots, void* success, void* ws, int64_t ws_bytes, void* stream);
 
+/* y (p, m) = K(X_new, X) v for a kernel-Gram operator: the cross-covariance matvec of the posterior mean
+ * (likelihood_condition[_p], util/gp_util.py:299-305,338-344: `matvec(kernel)(xs, inputs, weights)`), no noise
+ * term.  xnew (m, d) row-major in the operator's dtype; v (p, n). */
+int64_t mfx_gram_cross_workspace_bytes(const mfx_operator* op, int64_t m);
+int mfx_gram_cross_apply(const mfx_operator* op, const void* xnew, int64_t m, const void* v, int64_t ldv,
+                         void* y, int64_t ldy, int64_t p, void* ws, int64_t ws_bytes, void* stream);
+
 /* Per-kernel-class device timing with hipEvents recorded on the caller's stream (no host syncs
  * while enabled; events are read back in mfx_timing_read, which synchronises the events).
  * classes: 0 = operator apply, 1 = operator parameter-gradient sweep, 2 = Krylov vector kernels. */

@@ -398,3 +398,60 @@ def test_logpdf_cholesky_and_unpreconditioned_likelihood():
     value_k, info = gp_util.target_logml(gp_util.model_gp(m_fun, k_fun), lik)(T(X), T(y), 3, **kw)
     assert abs(float(value_k) - want) <= 0.05 * abs(want)
     assert float(torch.linalg.vector_norm(info["solve"]["residual_abs"])) < 1e-8
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-8), (torch.float32, 2e-3)])
+@pytest.mark.parametrize("kernel_name", ["rbf", "matern32", "matern12"])
+def test_target_posterior_mean(dtype, tol, kernel_name):
+    """util/gp_util.py:35-45,279-351: posterior mean = m(xs) + K(xs, X) (K + noise I)^{-1} (y - m)."""
+    rng = np.random.default_rng(6)
+    n, m, d, rank = 700, 333, 3, 20
+    X, Xs = rng.uniform(-1, 1, (n, d)), rng.uniform(-1, 1, (m, d))
+    y = np.sin(X.sum(-1))
+    raw = (np.array([0.1, 0.3, -0.2]), np.float64(0.3), np.float64(-2.0))
+    make = {"rbf": gp_util.kernel_scaled_rbf, "matern32": gp_util.kernel_scaled_matern_32,
+            "matern12": gp_util.kernel_scaled_matern_12}[kernel_name]
+    k_fun, _ = make(shape_in=(d,), shape_out=())
+    m_fun, _ = gp_util.mean_constant(shape_out=())
+    constrain = gp_util.constraint_greater_than(1e-2)
+    kw = dict(params_mean={"constant_value": T(0.3, dtype)},
+              params_kernel={"raw_lengthscale": T(raw[0], dtype), "raw_outputscale": T(raw[1], dtype)},
+              params_likelihood={"raw_noise": T(raw[2], dtype)})
+    eps = float(torch.finfo(dtype).eps)
+    oop = orc.RbfGramOp(X, noise_minval=1e-2, kernel=kernel_name, eps=eps)
+    ls, s, noise = oop.constrained(*raw)
+    A = lambda v: oop.apply(v, *raw)
+    Kx = orc.kernel_matrix(kernel_name, Xs, X, ls, s, eps=eps)
+
+    # few steps: on these fast-decaying spectra CG loses conjugacy within ~10 steps and two correct implementations then
+    # differ at 1e-3 of the remaining error (the oracle does so against itself under 1e-16 perturbations)
+    steps = 6
+    lik, _ = gp_util.likelihood_condition(gp_util.gram_matvec(), cg.cg_fixed_step(steps), constrain=constrain)
+    post, _ = gp_util.target_posterior(gp_util.model_gp(m_fun, k_fun), lik)(T(X, dtype), T(y, dtype), **kw)
+    got, info = post(T(Xs, dtype))
+    w, _ = orc.pcg_fixed_step(A, y - 0.3, num_matvecs=steps)
+    want = 0.3 + Kx @ w
+    assert got.shape == (m,) and "solve" in info
+    assert np.allclose(N(got), want, rtol=tol, atol=tol * np.abs(want).max())
+
+    K = orc.kernel_matrix(kernel_name, X, X, ls, s, diag_offset=0, eps=eps)
+    L, _ = orc.cholesky_partial_pivot(lambda i, j: K[i, j], n, rank)
+    P = lambda v: orc.precondition_solve(L, v, noise)
+    lik, _ = gp_util.likelihood_condition_p(gp_util.gram_matvec(), cg.pcg_fixed_step(steps),
+                                            precondition=low_rank.preconditioner(low_rank.cholesky_partial_pivot(rank=rank)),
+                                            constrain=constrain)
+    post, _ = gp_util.target_posterior(gp_util.model_gp(m_fun, k_fun), lik)(T(X, dtype), T(y, dtype), **kw)
+    got, _ = post(T(Xs, dtype))
+    w, _ = orc.pcg_fixed_step(A, y - 0.3, P, num_matvecs=steps)
+    want = 0.3 + Kx @ w
+    assert np.allclose(N(got), want, rtol=tol, atol=tol * np.abs(want).max())
+    # converged adaptive solve against the dense posterior mean
+    lik, _ = gp_util.likelihood_condition_p(gp_util.gram_matvec(precision="fp32"),
+                                            cg.pcg_adaptive(atol=1e-6, rtol=0.0, maxiter=2000, miniter=1),
+                                            precondition=low_rank.preconditioner(low_rank.cholesky_partial_pivot(rank=rank)),
+                                            constrain=constrain)
+    post, _ = gp_util.target_posterior(gp_util.model_gp(m_fun, k_fun), lik)(T(X, dtype), T(y, dtype), **kw)
+    got, info = post(T(Xs, dtype))
+    dense = 0.3 + Kx @ np.linalg.solve(K + noise * np.eye(n), y - 0.3)
+    assert int(info["solve"]["num_steps"]) < 2000
+    assert np.allclose(N(got), dense, atol=1e-4 if dtype == torch.float64 else 5e-3)
