@@ -154,7 +154,7 @@ def main():
         achieved = flops_launch / (avg_ms * 1e-3) / 1e12 if apply_cnt else 0.0
         split = args.precision.startswith("f16x3")
         peak = MFMA_F16_PEAK_TFLOPS if split else MFMA_F32_PEAK_TFLOPS
-        kernel = ("k_rbf_mfma_apply_h3 (Gram matvec, fp32 emulated by 3 f16 MFMA products + fp32-MFMA distances)"
+        kernel = ("k_rbf_mfma_apply_h3 (Gram matvec, fp32 emulated by 3 f16 MFMA products, distances included)"
                   if split else "k_rbf_mfma_apply (Gram matvec, exact fp32 MFMA)")
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")

@@ -573,6 +573,20 @@ int rbf_mfma_apply_h(const mfx_operator* op, const float* xs, const float* sq, i
 #undef MFX_H_CASE
 }
 
+// tile of the pipelined kernel: RbfTileH plus the f16 hi/lo image of the distance operand (DH variant)
+template <int DPAD, int NB, int kTJ>
+struct RbfTileH3 {
+  static constexpr int KD = DPAD + 2;
+  static constexpr int NKD = (3 * KD + 15) / 16;  // f16 MFMAs (K = 16) per block for hi.hi + hi.lo + lo.hi
+  static constexpr int AROW = NKD * 16 + 8;       // halves per column, padded: conflict-free ds_read_b128
+  static constexpr int P = NB * 32;
+  static constexpr int ROW = P * 8 + 8;
+  float aj[KD][kTJ];
+  _Float16 ajh[kTJ][AROW];
+  _Float16 vhi[(kTJ / 32) * 4][ROW];
+  _Float16 vlo[(kTJ / 32) * 4][ROW];
+};
+
 // ================================================================================================
 // Pipelined 3 x f16 kernel ("h3"): the production fp32 RBF Gram matvec.
 //
@@ -587,7 +601,7 @@ int rbf_mfma_apply_h(const mfx_operator* op, const float* xs, const float* sq, i
 // truncates its internal sum (tools/mfma_f16_rounding.hip: up to -1.75 ulp, biased), which is harmless in
 // the sign-mixed contraction but showed up as a 5x larger gradient error when used for the exponent.
 // ================================================================================================
-template <int DPAD, int NB, bool VEC4, int KIND>
+template <int DPAD, int NB, bool VEC4, int KIND, bool DH>
 __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __restrict__ xs, const float* __restrict__ sq,
                                                               int64_t n, const float* __restrict__ outputscale,
                                                               const float* __restrict__ noise,
@@ -595,8 +609,8 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
                                                               const float* __restrict__ x, int64_t ldx,
                                                               float* __restrict__ y, int64_t ldy, int64_t p) {
   constexpr int kMI = 2, kTJ = 64;
-  using Tile = RbfTileH<DPAD, NB, kTJ>;
-  constexpr int KD = Tile::KD, KS = KD / 2;
+  using Tile = RbfTileH3<DPAD, NB, kTJ>;
+  constexpr int KD = Tile::KD, KS = KD / 2, NKD = Tile::NKD;
   constexpr float cfac = KIND == MFX_KERNEL_RBF ? kNegHalfLog2e : (KIND == MFX_KERNEL_MATERN32 ? 3.f : 1.f) * kLog2e * kLog2e;
   __shared__ __attribute__((aligned(16))) Tile tile[2];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -604,15 +618,37 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
   const int64_t i_wave = (int64_t)blockIdx.x * (4 * kMI * 32) + (int64_t)wid * (kMI * 32);
   const int64_t b0 = (int64_t)blockIdx.y * (NB * 32);
 
-  float bi[kMI][KS];
+  // B operand of the distance product, resident in registers: [x_i, 1, |x_i|^2].
+  //   fp32 variant: one float per k-step.   DH variant: the f16 image [Bh | Bl | Bh | 0] of the 3-product split
+  //   (slot c*KD + k pairs with [Ah | Ah | Al] of the column operand), NEGATED for the odd row block: together with the
+  //   columns' sign (odd column block negated in store_tile) the distance comes out as (-1)^(jb+mi) t, so the f16 MFMA's
+  //   round-toward-minus-infinity bias enters K with alternating sign over the 32x32 blocks instead of coherently.
+  float bi[kMI][DH ? 1 : KS];
+  half8 bih[kMI][DH ? NKD : 1];
 #pragma unroll
   for (int mi = 0; mi < kMI; ++mi) {
     int64_t i = i_wave + mi * 32 + l31;
     if (i >= n) i = n - 1;
+    if constexpr (DH) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const int k = 2 * s + lhi;
-      bi[mi][s] = (k < DPAD) ? xs[i * DPAD + k] : (k == DPAD ? 1.f : sq[i]);
+      for (int q = 0; q < NKD; ++q)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int slot = q * 16 + lhi * 8 + e;
+          const int comp = slot / KD, kk = slot % KD;
+          float v = 0.f;
+          if (comp < 3) v = (kk < DPAD) ? xs[i * DPAD + kk] : (kk == DPAD ? 1.f : sq[i]);
+          float hi, lo;
+          split_hi_lo(v, hi, lo);
+          const float w = comp == 1 ? lo : hi;
+          bih[mi][q][e] = (_Float16)((mi & 1) ? -w : w);
+        }
+    } else {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int k = 2 * s + lhi;
+        bi[mi][s] = (k < DPAD) ? xs[i * DPAD + k] : (k == DPAD ? 1.f : sq[i]);
+      }
     }
   }
   floatx16 acc[kMI][NB];
@@ -682,30 +718,59 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
         *reinterpret_cast<half4*>(&tl.vlo[row][col]) = ll;
       }
     }
+    auto put_a = [&](int j, int kk, float v) {  // DH: column operand [Ah | Ah | Al], odd column block negated
+      float hi, lo;
+      split_hi_lo(((j >> 5) & 1) ? -v : v, hi, lo);
+      tl.ajh[j][kk] = (_Float16)hi;
+      tl.ajh[j][KD + kk] = (_Float16)hi;
+      tl.ajh[j][2 * KD + kk] = (_Float16)lo;
+    };
 #pragma unroll
     for (int u = 0; u < kXPT; ++u) {
       const int t = tid + 256 * u;
-      if (t < kTJ * DPAD) tl.aj[t % DPAD][t / DPAD] = -2.f * cfac * rx[u];
+      if (t < kTJ * DPAD) {
+        if constexpr (DH) {
+          put_a(t / DPAD, t % DPAD, -2.f * cfac * rx[u]);
+        } else {
+          tl.aj[t % DPAD][t / DPAD] = -2.f * cfac * rx[u];
+        }
+      }
     }
     if (tid < kTJ) {
       // K' = 2^15 K: lo(K') stays a NORMAL f16 for K >= 4e-6 (RBF: shift folded into the product; Matern: into exp2)
-      tl.aj[DPAD][tid] = cfac * rsq + (KIND == MFX_KERNEL_RBF ? kKShift : kEpsC);
-      tl.aj[DPAD + 1][tid] = cfac;
+      const float a_sq = cfac * rsq + (KIND == MFX_KERNEL_RBF ? kKShift : kEpsC);
+      if constexpr (DH) {
+        put_a(tid, DPAD, a_sq);
+        put_a(tid, DPAD + 1, cfac);
+      } else {
+        tl.aj[DPAD][tid] = a_sq;
+        tl.aj[DPAD + 1][tid] = cfac;
+      }
     }
   };
+  if constexpr (DH) {  // the zero padding of the f16 column operand is written once
+    for (int t = tid; t < 2 * kTJ * (Tile::AROW - 3 * KD); t += 256) {
+      const int w = Tile::AROW - 3 * KD;
+      tile[t / (kTJ * w)].ajh[(t / w) % kTJ][3 * KD + t % w] = (_Float16)0.f;
+    }
+  }
   // entries (2 pr, 2 pr + 1): K' = exp2(min(arg, 15)) and its hi/lo f16 pieces.  min as ONE compiler-visible
   // v_med3_f32 (fminf adds a canonicalising v_max; inline asm would hide the MFMA-result hazard from hipcc).
-  auto exp_split_pair = [&](const floatx16& kd, int pr, const bool diag_blk, half8 (&ah)[2], half8 (&al)[2]) {
+  // `neg`: this block's distances were produced negated (DH sign alternation); the sign is a free source modifier
+  auto exp_split_pair = [&](const floatx16& kd, int pr, const bool diag_blk, const bool neg, half8 (&ah)[2],
+                            half8 (&al)[2]) {
     const int s = pr >> 2, q = (pr & 3) * 2;
     float k0, k1;
+    const float d0 = neg ? -kd[8 * s + q] : kd[8 * s + q];
+    const float d1 = neg ? -kd[8 * s + q + 1] : kd[8 * s + q + 1];
     if constexpr (KIND == MFX_KERNEL_RBF) {
-      k0 = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(kd[8 * s + q], -3.0e38f, kKShift));
-      k1 = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(kd[8 * s + q + 1], -3.0e38f, kKShift));
+      k0 = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(d0, -3.0e38f, kKShift));
+      k1 = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(d1, -3.0e38f, kKShift));
     } else {
       // register r <-> column (r & 3) + 8 (r >> 2) + 4 lhi of the block: zero self-distance on the diagonal block
       const int r0 = 8 * s + q, r1 = r0 + 1;
-      const float t0 = (diag_blk && l31 == (r0 & 3) + 8 * (r0 >> 2) + 4 * lhi) ? kEpsC : kd[r0];
-      const float t1 = (diag_blk && l31 == (r1 & 3) + 8 * (r1 >> 2) + 4 * lhi) ? kEpsC : kd[r1];
+      const float t0 = (diag_blk && l31 == (r0 & 3) + 8 * (r0 >> 2) + 4 * lhi) ? kEpsC : d0;
+      const float t1 = (diag_blk && l31 == (r1 & 3) + 8 * (r1 >> 2) + 4 * lhi) ? kEpsC : d1;
       k0 = matern_from_te<KIND>(t0, 32768.f);
       k1 = matern_from_te<KIND>(t1, 32768.f);
     }
@@ -737,10 +802,17 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
       floatx16 kd;
 #pragma unroll
       for (int r = 0; r < 16; ++r) kd[r] = 0.f;
+      if constexpr (DH) {
 #pragma unroll
-      for (int s = 0; s < KS; ++s) kd = __builtin_amdgcn_mfma_f32_32x32x2f32(tl.aj[2 * s + lhi][l31], bi[0][s], kd, 0, 0, 0);
+        for (int q = 0; q < NKD; ++q)
+          kd = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(&tl.ajh[l31][q * 16 + lhi * 8]),
+                                                      bih[0][q], kd, 0, 0, 0);
+      } else {
 #pragma unroll
-      for (int pr = 0; pr < 8; ++pr) exp_split_pair(kd, pr, kDiag, ah, al);  // block (jb 0, mi 0) is diagonal in that tile
+        for (int s = 0; s < KS; ++s) kd = __builtin_amdgcn_mfma_f32_32x32x2f32(tl.aj[2 * s + lhi][l31], bi[0][s], kd, 0, 0, 0);
+      }
+#pragma unroll
+      for (int pr = 0; pr < 8; ++pr) exp_split_pair(kd, pr, kDiag, false, ah, al);  // block (jb 0, mi 0): diagonal in that tile, sign +
     }
 #pragma unroll
     for (int blk = 0; blk < 2 * kMI; ++blk) {
@@ -758,11 +830,18 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
           bh[s][nb] = *reinterpret_cast<const half8*>(&tl.vhi[row][(nb * 32 + l31) * 8]);
           bl[s][nb] = *reinterpret_cast<const half8*>(&tl.vlo[row][(nb * 32 + l31) * 8]);
         }
-      float ajn[KS];
+      float ajn[DH ? 1 : KS];
+      half8 ajhn[DH ? NKD : 1];
       if (has_next) {
+        if constexpr (DH) {
 #pragma unroll
-        for (int s = 0; s < KS; ++s) ajn[s] = tl.aj[2 * s + lhi][jbn * 32 + l31];
+          for (int q = 0; q < NKD; ++q) ajhn[q] = *reinterpret_cast<const half8*>(&tl.ajh[jbn * 32 + l31][q * 16 + lhi * 8]);
+        } else {
+#pragma unroll
+          for (int s = 0; s < KS; ++s) ajn[s] = tl.aj[2 * s + lhi][jbn * 32 + l31];
+        }
       }
+      const bool negn = DH && (((jbn + min_) & 1) != 0);
       floatx16 kdn;
 #pragma unroll
       for (int r = 0; r < 16; ++r) kdn[r] = 0.f;
@@ -779,15 +858,24 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
         __builtin_amdgcn_sched_barrier(0);
         contraction(m);
         if (has_next) {
+          if constexpr (DH) {
+            if (m < NKD) kdn = __builtin_amdgcn_mfma_f32_32x32x16_f16(ajhn[m], bih[min_][m], kdn, 0, 0, 0);
+          } else {
 #pragma unroll
-          for (int s = 0; s < KS; ++s)
-            if (s >= 2 * m && s < 2 * (m + 1))
-              kdn = __builtin_amdgcn_mfma_f32_32x32x2f32(ajn[s], bi[min_][s], kdn, 0, 0, 0);
+            for (int s = 0; s < KS; ++s)
+              if (s >= 2 * m && s < 2 * (m + 1))
+                kdn = __builtin_amdgcn_mfma_f32_32x32x2f32(ajn[s], bi[min_][s], kdn, 0, 0, 0);
+          }
         }
       }
       if (has_next) {  // distance steps that did not fit next to the NM1 contraction MFMAs (d > 8 with one probe block)
+        if constexpr (DH) {
 #pragma unroll
-        for (int s = 2 * NM1; s < KS; ++s) kdn = __builtin_amdgcn_mfma_f32_32x32x2f32(ajn[s], bi[min_][s], kdn, 0, 0, 0);
+          for (int q = NM1; q < NKD; ++q) kdn = __builtin_amdgcn_mfma_f32_32x32x16_f16(ajhn[q], bih[min_][q], kdn, 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int s = 2 * NM1; s < KS; ++s) kdn = __builtin_amdgcn_mfma_f32_32x32x2f32(ajn[s], bi[min_][s], kdn, 0, 0, 0);
+        }
       }
       // ---- phase 2: exp / split of the next block between the remaining contraction MFMAs -------
 #pragma unroll
@@ -799,7 +887,7 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
 #pragma unroll
           for (int pr = 0; pr < 8; ++pr)
             if (pr >= 8 * (m - NM1) / (NM - NM1) && pr < 8 * (m - NM1 + 1) / (NM - NM1))
-              exp_split_pair(kdn, pr, kDiag && jbn == min_, ahn, aln);
+              exp_split_pair(kdn, pr, kDiag && jbn == min_, negn, ahn, aln);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -845,6 +933,17 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
     }
 }
 
+// distances of the pipelined kernel on the f16 matrix pipe (3-product split, alternating block sign: default) or on the
+// fp32 MFMA (MFX_RBF_DIST=0, kept for A/B runs).  Measured, C4 shape: 9.84 -> 8.08 ms per launch at 64 probes, 7.0 -> 4.8 ms
+// at <= 8 probes; SLQ value / gradient errors vs fp64 unchanged (tools/run_dist_ablation.sh, profiles/r01f_*).
+static bool rbf_dist_f16() {
+  static const int v = [] {
+    const char* e = getenv("MFX_RBF_DIST");
+    return e ? atoi(e) : 1;
+  }();
+  return v != 0;
+}
+
 template <int DPAD, int NB, int KIND>
 static int launch_apply_h3k(const mfx_operator* op, const float* xs, const float* sq, const float* x, int64_t ldx,
                             float* y, int64_t ldy, int64_t p, float* vscale, hipStream_t stream) {
@@ -853,13 +952,15 @@ static int launch_apply_h3k(const mfx_operator* op, const float* xs, const float
   const dim3 grid((unsigned)((n + 255) / 256), (unsigned)((p + NB * 32 - 1) / (NB * 32)));
   const bool vec4 = (n % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) &&
                     (reinterpret_cast<uintptr_t>(y) % 16 == 0);
-  if (vec4) {
-    k_rbf_mfma_apply_h3<DPAD, NB, true, KIND><<<grid, 256, 0, stream>>>(xs, sq, n, (const float*)op->outputscale,
-                                                                        (const float*)op->noise, vscale, x, ldx, y, ldy, p);
+#define MFX_H3_LAUNCH(V4, DHV)                                                                            \
+  k_rbf_mfma_apply_h3<DPAD, NB, V4, KIND, DHV><<<grid, 256, 0, stream>>>(xs, sq, n, (const float*)op->outputscale, \
+                                                                          (const float*)op->noise, vscale, x, ldx, y, ldy, p)
+  if (rbf_dist_f16()) {
+    if (vec4) MFX_H3_LAUNCH(true, true); else MFX_H3_LAUNCH(false, true);
   } else {
-    k_rbf_mfma_apply_h3<DPAD, NB, false, KIND><<<grid, 256, 0, stream>>>(xs, sq, n, (const float*)op->outputscale,
-                                                                         (const float*)op->noise, vscale, x, ldx, y, ldy, p);
+    if (vec4) MFX_H3_LAUNCH(true, false); else MFX_H3_LAUNCH(false, false);
   }
+#undef MFX_H3_LAUNCH
   MFX_CHECK_LAUNCH();
   return MFX_OK;
 }
