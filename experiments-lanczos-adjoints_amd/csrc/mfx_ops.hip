@@ -338,7 +338,7 @@ static int64_t rbf_carve(const mfx_operator* op, void* ws, int64_t ws_bytes, Rbf
   r.xs = cv.take(op->n * (dpad > 0 ? dpad : 1) * es);
   r.sq = cv.take(op->n * es);
   // per-workgroup gradient partials: VALU sweep n/256 rows, MFMA sweep 8 * n/128 rows, <= 34 doubles each
-  r.partial = static_cast<double*>(cv.take(((op->n + 127) / 128) * 8 * 34 * sizeof(double)));
+  r.partial = static_cast<double*>(cv.take(((op->n + 127) / 128) * 64 * 34 * sizeof(double)));  // 8 XCDs x 8 sub-ranges
   r.vscale = static_cast<float*>(cv.take(65536 * 3 * sizeof(float)));  // [s, 1/s] per row + |max| bit patterns
   r.hws_bytes = (op->dtype == MFX_F32 && rbf_mode(op) == MFX_RBF_F16X3 && batch_hint > 0) ? rbf_grad_h_ws_bytes(op->n, batch_hint) : 0;
   r.hws = r.hws_bytes ? cv.take(r.hws_bytes) : nullptr;
@@ -479,7 +479,9 @@ static int rbf_grad(const mfx_operator* op, const T* L, int64_t ldl, const T* R,
   bool done = false;
   const float* scales = nullptr;
   if constexpr (sizeof(T) == 4) {
-    if (rbf_mfma_grad_supported(op, batch) && rbf_mode(op) == MFX_RBF_F16X3 && w.hws) {
+    // the split GEMM stages its packed operands through 32-bit byte offsets: 2 B x padded batch x padded n < 4 GiB
+    const bool fits32 = ((batch + 31) / 32 * 32) * ((op->n + 127) / 128 * 128) * 2 < ((int64_t)1 << 32);
+    if (rbf_mfma_grad_supported(op, batch) && rbf_mode(op) == MFX_RBF_F16X3 && w.hws && fits32) {
       MFX_TRY(rbf_mfma_grad_h(op, (const float*)w.xs, (const float*)w.sq, dpad, L, ldl, R, ldr, batch, w.partial, &nblocks,
                               w.hws, &scales, stream));
       done = true;

@@ -14,7 +14,7 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmfx.so")
+LIB_PATH = os.environ.get("MFX_LIBRARY_PATH") or os.path.join(_HERE, "libmfx.so")  # override: A/B builds
 
 MFX_F32, MFX_F64 = 0, 1
 OP_DENSE, OP_CSR, OP_RBF, OP_CALLBACK = 0, 1, 2, 3
