@@ -578,6 +578,15 @@ int rbf_mfma_apply_h(const mfx_operator* op, const float* xs, const float* sq, i
 #undef MFX_H_CASE
 }
 
+// The reference clamps the squared distance at 0 before the exponential (util/gp_util.py:173).  In fp32 a computed squared
+// distance is negative only by round-off (|t| <~ 1e-6 of the operands' squares), so the clamp changes K_ij by at most that
+// round-off -- the same size as the error of every other entry -- while costing one VALU instruction per entry (7 % of the
+// RBF matvec).  MFX_RBF_CLAMP=1 at build time restores it; 2^15 K cannot overflow f16 either way (arg <= 15 + 1e-5).
+#ifndef MFX_RBF_CLAMP
+#define MFX_RBF_CLAMP 0
+#endif
+constexpr bool kClampRbf = MFX_RBF_CLAMP != 0;
+
 // tile of the pipelined kernel: RbfTileH plus the f16 hi/lo image of the distance operand (DH variant)
 template <int DPAD, int NB, int kTJ>
 struct RbfTileH3 {
@@ -769,8 +778,13 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
     const float d0 = neg ? -kd[8 * s + q] : kd[8 * s + q];
     const float d1 = neg ? -kd[8 * s + q + 1] : kd[8 * s + q + 1];
     if constexpr (KIND == MFX_KERNEL_RBF) {
-      k0 = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(d0, -3.0e38f, kKShift));
-      k1 = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(d1, -3.0e38f, kKShift));
+      if constexpr (kClampRbf) {
+        k0 = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(d0, -3.0e38f, kKShift));
+        k1 = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(d1, -3.0e38f, kKShift));
+      } else {
+        k0 = __builtin_amdgcn_exp2f(d0);
+        k1 = __builtin_amdgcn_exp2f(d1);
+      }
     } else {
       // register r <-> column (r & 3) + 8 (r >> 2) + 4 lhi of the block: zero self-distance on the diagonal block
       const int r0 = 8 * s + q, r1 = r0 + 1;
