@@ -54,6 +54,8 @@ struct CgArgs {
   const int* active;  // (p) or null = all active
   T atol, rtol;
   int kmax, nblk, first, has_z;
+  T* qrow;       // re-orthogonalising variant: row i of Q = r_old / sqrt(r_old . z_old)  (cg.py:200), or null
+  int64_t ldq;   // batch stride of Q
 };
 
 template <typename T, int VEC>
@@ -67,12 +69,22 @@ __global__ __launch_bounds__(kBlock) void k_cg_xr(CgArgs<T> a) {
   if (tid == 0) {
     const T pap = reduce_partials(a.part_pap + (int64_t)b * a.kmax * a.nblk, a.nblk);
     alpha_sh = safe_div(a.rz_cur[b], pap);
+    const T rzv = a.rz_cur[b];
+    smn[0] = sqrt(rzv > T(0) ? rzv : T(0));  // _safe_sqrt (cg.py:244-246)
   }
   __syncthreads();
   const T alpha = alpha_sh;
+  const T qden = smn[0];
+  __syncthreads();
   T xr[kEpt], rr[kEpt], pr[kEpt], ar[kEpt];
   load_own<T, VEC>(xr, a.x + (int64_t)b * a.n, slice0, a.n, tid);
   load_own<T, VEC>(rr, a.r + (int64_t)b * a.n, slice0, a.n, tid);
+  if (a.qrow) {
+    T qr[kEpt];
+#pragma unroll
+    for (int e = 0; e < kEpt; ++e) qr[e] = safe_div(rr[e], qden);
+    store_own<T, VEC>(qr, a.qrow + (int64_t)b * a.ldq, slice0, a.n, tid);
+  }
   load_own<T, VEC>(pr, a.pv + (int64_t)b * a.n, slice0, a.n, tid);
   load_own<T, VEC>(ar, a.Ap + (int64_t)b * a.n, slice0, a.n, tid);
   T s_rr = T(0), s_err = T(0);
@@ -300,9 +312,10 @@ static int64_t cg_carve(const mfx_operator* op, int64_t n, int64_t p, int64_t ra
 template <typename T>
 static int pcg_t(const mfx_operator* op, const T* b, int64_t ldb, int64_t n, int64_t p, const Precond* pc,
                  int64_t maxiter, int64_t miniter, double atol, double rtol, int adaptive, T* x, T* r,
-                 int64_t* num_steps, const CgWs& ws, hipStream_t stream) {
+                 int64_t* num_steps, T* Q, const CgWs& ws, hipStream_t stream) {
   const int64_t rank = pc ? pc->rank : 0;
-  Ctx<T> c(n, rank > 0 ? rank : 1, p, pick_vec<T>(n, {x, r, ws.Ap, ws.pv, ws.z, pc ? pc->lt : nullptr}), stream);
+  const int64_t kdim = Q ? (rank > maxiter ? rank : maxiter) : rank;
+  Ctx<T> c(n, kdim > 0 ? kdim : 1, p, pick_vec<T>(n, {x, r, ws.Ap, ws.pv, ws.z, pc ? pc->lt : nullptr, Q}), stream);
   T* Ap = (T*)ws.Ap;
   T* pv = (T*)ws.pv;
   T* z = (T*)ws.z;
@@ -355,9 +368,26 @@ static int pcg_t(const mfx_operator* op, const T* b, int64_t ldb, int64_t n, int
     MFX_TRY(launch_dots<T>(c, Ap, n, 0, 1, pv, n, (T*)ws.part_a));
     a.rz_cur = rz + (it & 1) * p;
     a.rz_next = rz + ((it + 1) & 1) * p;
+    if (Q) {
+      a.qrow = Q + it * n;
+      a.ldq = maxiter * n;
+    }
     MFX_VEC_SWITCH(c.vec, (k_cg_xr<T, VEC><<<c.grid(), c.wg, 0, stream>>>(a)));
     MFX_CHECK_LAUNCH();
     if (pc) MFX_TRY(precond_apply_t<T>(c, *pc, r, n, z, n, (T*)ws.part_a, (T*)ws.u, (T*)ws.part_rz, active));
+    if (Q) {
+      // re-orthogonalise against the stored (normalised) residuals, then precondition again (cg.py:199-205):
+      //   r -= Q (Q^T z);  z = P(r);  r.z
+      const int m = (int)(it + 1);
+      MFX_TRY(launch_dots<T>(c, Q, maxiter * n, n, m, pc ? z : r, n, (T*)ws.part_a));
+      UpdateArgs<T> ua{};
+      ua.rows = Q; ua.rows_ldb = maxiter * n; ua.row_stride = n; ua.m = m;
+      ua.partial_in = (T*)ws.part_a; ua.s1 = T(1);
+      ua.x = r; ua.ldx = n; ua.y = r; ua.ldy = n;
+      ua.partial_norm = (T*)ws.part_rz;
+      MFX_TRY(launch_update<T>(c, ua, false, true));
+      if (pc) MFX_TRY(precond_apply_t<T>(c, *pc, r, n, z, n, (T*)ws.part_a, (T*)ws.u, (T*)ws.part_rz, active));
+    }
     MFX_VEC_SWITCH(c.vec, (k_cg_dir<T, VEC><<<c.grid(), c.wg, 0, stream>>>(a)));
     MFX_CHECK_LAUNCH();
   }
@@ -571,9 +601,32 @@ int mfx_pcg_solve(const mfx_operator* op, const void* b, int64_t ldb, int64_t n,
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (op->dtype == MFX_F32)
     return pcg_t<float>(op, (const float*)b, ldb, n, p, precond_lt ? &pc : nullptr, maxiter, miniter, atol, rtol, adaptive,
-                        (float*)x, (float*)r, (int64_t*)num_steps, w, s);
+                        (float*)x, (float*)r, (int64_t*)num_steps, nullptr, w, s);
   return pcg_t<double>(op, (const double*)b, ldb, n, p, precond_lt ? &pc : nullptr, maxiter, miniter, atol, rtol, adaptive,
-                       (double*)x, (double*)r, (int64_t*)num_steps, w, s);
+                       (double*)x, (double*)r, (int64_t*)num_steps, nullptr, w, s);
+}
+
+int mfx_pcg_solve_reortho(const mfx_operator* op, const void* b, int64_t ldb, int64_t n, int64_t p,
+                          const void* precond_lt, int64_t rank, const void* precond_minv, const void* precond_shift,
+                          int64_t num_matvecs, void* x, void* r, void* q, void* ws, int64_t ws_bytes, void* stream) {
+  MFX_REQUIRE(op && b && x && r && q, MFX_ERR_INVALID, "mfx_pcg_solve_reortho: null argument");
+  MFX_REQUIRE(op->n == n && n >= 1 && p >= 1 && ldb >= n, MFX_ERR_INVALID, "mfx_pcg_solve_reortho: bad sizes");
+  MFX_REQUIRE(p <= 65535, MFX_ERR_UNSUPPORTED, "at most 65535 right-hand sides per call");
+  MFX_REQUIRE(num_matvecs >= 1 && num_matvecs <= 4096, MFX_ERR_INVALID, "num_matvecs %lld outside [1, 4096]",
+              (long long)num_matvecs);
+  MFX_REQUIRE(op->dtype == MFX_F32 || op->dtype == MFX_F64, MFX_ERR_INVALID, "bad dtype");
+  Precond pc{precond_lt, precond_minv, precond_shift, rank};
+  if (precond_lt) MFX_TRY(check_precond(n, rank, precond_lt, precond_minv, precond_shift));
+  const int64_t kdim = (precond_lt && rank > num_matvecs) ? rank : num_matvecs;
+  CgWs w;
+  MFX_REQUIRE(ws && cg_carve(op, n, p, kdim, ws, ws_bytes, &w) <= ws_bytes, MFX_ERR_WORKSPACE,
+              "mfx_pcg_solve_reortho: workspace too small (size it with rank = max(rank, num_matvecs))");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (op->dtype == MFX_F32)
+    return pcg_t<float>(op, (const float*)b, ldb, n, p, precond_lt ? &pc : nullptr, num_matvecs, 0, 1.0, 0.0, 0, (float*)x,
+                        (float*)r, nullptr, (float*)q, w, s);
+  return pcg_t<double>(op, (const double*)b, ldb, n, p, precond_lt ? &pc : nullptr, num_matvecs, 0, 1.0, 0.0, 0, (double*)x,
+                       (double*)r, nullptr, (double*)q, w, s);
 }
 
 int mfx_precond_apply(int dtype, int64_t n, int64_t rank, const void* lt, const void* minv, const void* shift,

@@ -1505,9 +1505,9 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_grad(const float* __restric
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
   const int wm = wid >> 1, wn = wid & 1;  // wave -> 64 x 64 quadrant of the 128 x 128 tile
-  const int64_t i0 = (int64_t)blockIdx.y * kGM;
+  const int64_t i0 = (int64_t)(blockIdx.y / kGSub) * kGM;  // 8 x 8 L2-sharing patches per XCD, see kGSub
   const int64_t ntj = (n + kGN - 1) / kGN;
-  const int64_t tj_begin = (int64_t)blockIdx.x * tiles_per_block;
+  const int64_t tj_begin = ((int64_t)blockIdx.x * kGSub + blockIdx.y % kGSub) * tiles_per_block;
   int64_t tj_end = tj_begin + tiles_per_block;
   if (tj_end > ntj) tj_end = ntj;
 
@@ -1661,8 +1661,8 @@ static int launch_grad(const mfx_operator* op, const float* xs, const float* sq,
                        hipStream_t stream) {
   const int64_t n = op->n;
   const int64_t nti = (n + kGM - 1) / kGM, ntj = (n + kGN - 1) / kGN;
-  const int tiles_per_block = (int)((ntj + kGSplit - 1) / kGSplit);
-  const dim3 grid(kGSplit, (unsigned)nti);
+  const int tiles_per_block = (int)((ntj + kGSplit * kGSub - 1) / (kGSplit * kGSub));
+  const dim3 grid(kGSplit, (unsigned)(nti * kGSub));
   const size_t sh = sizeof(GradSmem<DPAD>);
   const bool vec4 = (n % 4 == 0) && (ldl % 4 == 0) && (ldr % 4 == 0) && (reinterpret_cast<uintptr_t>(L) % 16 == 0) &&
                     (reinterpret_cast<uintptr_t>(R) % 16 == 0);
@@ -1676,7 +1676,7 @@ static int launch_grad(const mfx_operator* op, const float* xs, const float* sq,
     k_rbf_mfma_grad<DPAD, false><<<grid, 256, sh, stream>>>(xs, sq, n, op->ard, op->kernel_fn, L, ldl, R, ldr, batch, tiles_per_block, partial);
   }
   MFX_CHECK_LAUNCH();
-  *nblocks_out = nti * kGSplit;
+  *nblocks_out = nti * kGSub * kGSplit;
   return MFX_OK;
 }
 

@@ -107,6 +107,7 @@ SYMBOLS = {
         _I,
         [_OPP, _P, _I64, _I64, _I64, _P, _I64, _P, _P, _I64, _I64, C.c_double, C.c_double, _I, _P, _P, _P, _P, _I64, _P],
     ),
+    "mfx_pcg_solve_reortho": (_I, [_OPP, _P, _I64, _I64, _I64, _P, _I64, _P, _P, _I64, _P, _P, _P, _P, _I64, _P]),
     "mfx_precond_apply": (_I, [_I, _I64, _I64, _P, _P, _P, _P, _I64, _P, _I64, _I64, _P, _I64, _P]),
     "mfx_partial_cholesky": (_I, [_OPP, _I64, _I, _I, _P, _P, _P, _P, _I64, _P]),
     "mfx_gram_cross_workspace_bytes": (_I64, [_OPP, _I64]),

@@ -13,8 +13,8 @@ preconditioners are not supported inside the HIP loop.
 
 Differentiation is the rule of ``jax.lax.custom_linear_solve(..., symmetric=True)`` (cg.py:23-25): the cotangent of the
 right-hand side is another solve with the same solver, the cotangent of the operator's parameters is the parameter sweep
-with (-lambda, x); nothing flows through the preconditioner or the info dict.  ``cg_fixed_step_reortho`` (cg.py:140-219,
-marked "needs more work" by the reference's own test) is not part of this build.
+with (-lambda, x); nothing flows through the preconditioner or the info dict.  ``cg_fixed_step_reortho`` /
+``pcg_fixed_step_reortho`` (cg.py:140-219; "needs more work" according to the reference's own test) are reproduced as they are.
 """
 
 from __future__ import annotations
@@ -43,6 +43,26 @@ def pcg_fixed_step(num_matvecs: int, /):
     def pcg(A, b, P):
         x, r, _steps = _solve(A, b, P, cfg)
         return x, {"residual_abs": r, "residual_rel": r / x.detach().abs()}
+
+    return pcg
+
+
+def cg_fixed_step_reortho(*args, **kwargs):
+    pcg_solve = pcg_fixed_step_reortho(*args, **kwargs)
+
+    def cg(A, b):
+        return pcg_solve(A, b, None)
+
+    return cg
+
+
+def pcg_fixed_step_reortho(num_matvecs: int, /):
+    """cg.py:151-219: every step re-orthogonalises the residual against the stored normalised residuals Q."""
+    cfg = {"maxiter": int(num_matvecs), "miniter": 0, "atol": 1.0, "rtol": 0.0, "adaptive": False, "reortho": True}
+
+    def pcg(A, b, P):
+        x, r, Q = _solve(A, b, P, cfg)
+        return x, {"residual_abs": r, "Q": Q.transpose(-1, -2)}
 
     return pcg
 
@@ -76,7 +96,7 @@ def _solve(A, b, P, cfg):
     batched = b.dim() == 2
     B = b if batched else b[None]
     cparams = op.constrain(*params)
-    x, r, steps = _PcgFn.apply(op, cfg, P, B, *cparams)
+    x, r, steps = _PcgFn.apply(op, cfg, P, B, *cparams)  # steps: int64 (p,), or the basis Q (p, m, n) when re-orthogonalising
     if not batched:
         return x[0], r[0], steps[0]
     return x, r, steps
@@ -101,12 +121,25 @@ def _run(op, cfg, P, B, cparams):
             raise ValueError(f"preconditioner of size {pre.n} ({pre.lt.dtype}) used for a system of size {n} ({dt})")
         rank, lt = pre.rank, pre.lt
         minv, shift = pre.minv(P.s)
-    ws = _lib.workspace_pcg(desc, n, p, rank, dev)
+    reortho = cfg.get("reortho", False)
+    ws = _lib.workspace_pcg(desc, n, p, max(rank, cfg["maxiter"]) if reortho else rank, dev)
     x = torch.empty_like(B)
     r = torch.empty_like(B)
-    steps = torch.empty((p,), dtype=torch.int64, device=dev)
     if keep is not None:
         reg.add_bytes(ws, dt)
+    if reortho:
+        m = cfg["maxiter"]
+        if m < 1:
+            raise ValueError("pcg_fixed_step_reortho needs num_matvecs >= 1")
+        Q = torch.zeros((p, m, n), dtype=dt, device=dev)
+        rc = lib.mfx_pcg_solve_reortho(C.byref(desc), _lib.ptr(B), n, n, p, _lib.ptr(lt), rank, _lib.ptr(minv),
+                                       _lib.ptr(shift), m, _lib.ptr(x), _lib.ptr(r), _lib.ptr(Q), _lib.ptr(ws), ws.numel(),
+                                       _lib.stream_ptr(dev))
+        if keep is not None and keep[1]:
+            raise keep[1][0]
+        _lib.check(rc)
+        return x, r, Q
+    steps = torch.empty((p,), dtype=torch.int64, device=dev)
     rc = lib.mfx_pcg_solve(C.byref(desc), _lib.ptr(B), n, n, p, _lib.ptr(lt), rank, _lib.ptr(minv), _lib.ptr(shift),
                            cfg["maxiter"], cfg["miniter"], cfg["atol"], cfg["rtol"], int(cfg["adaptive"]),
                            _lib.ptr(x), _lib.ptr(r), _lib.ptr(steps), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))

@@ -210,6 +210,14 @@ int mfx_pcg_solve(const mfx_operator* op, const void* b, int64_t ldb, int64_t n,
                   int adaptive, void* x, void* r, void* num_steps, void* ws, int64_t ws_bytes,
                   void* stream);
 
+/* Fixed-step PCG that re-orthogonalises the residual against the stored, normalised earlier residuals each step
+ * (cg.pcg_fixed_step_reortho, cg.py:140-219): q (p, num_matvecs, n) receives the rows r_i / sqrt(r_i . z_i), the
+ * transpose of the reference's info["Q"].  Workspace: mfx_pcg_workspace_bytes with rank = max(rank, num_matvecs). */
+int mfx_pcg_solve_reortho(const mfx_operator* op, const void* b, int64_t ldb, int64_t n, int64_t p,
+                          const void* precond_lt, int64_t rank, const void* precond_minv,
+                          const void* precond_shift, int64_t num_matvecs, void* x, void* r, void* q,
+                          void* ws, int64_t ws_bytes, void* stream);
+
 /* z = (v - L (s I + L^T L)^{-1} L^T v) / s on a (p, n) batch: the `solve(v, s)` of low_rank.py:31-43.
  * Workspace: mfx_pcg_workspace_bytes of any operator of this n and dtype. */
 int mfx_precond_apply(int dtype, int64_t n, int64_t rank, const void* lt, const void* minv,

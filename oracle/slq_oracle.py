@@ -617,6 +617,32 @@ def pcg_adaptive(A, b, P=None, *, atol, rtol, maxiter, miniter=0):
         return x, {"residual_abs": r, "residual_rel": r / np.abs(x), "num_steps": nsteps}
 
 
+def pcg_fixed_step_reortho(A, b, P=None, *, num_matvecs):
+    """cg.py:151-219.  -> (x, {"residual_abs", "Q" (n, num_matvecs)})"""
+    P = (lambda v: v) if P is None else P
+    x = np.zeros_like(b)
+    r = b - A(x)
+    z = P(r)
+    p = z
+    Q = np.zeros((len(b), num_matvecs), dtype=b.dtype)
+    rzdot = r @ z
+    for i in range(num_matvecs):
+        Ap = A(p)
+        a = safe_divide(rzdot, p @ Ap)
+        x = x + a * p
+        r, rold = r - a * Ap, r
+        z, zold = P(r), z
+        den = np.sqrt(rzdot) if rzdot > 0.0 else 0.0  # _safe_sqrt, cg.py:244-246
+        eps = np.finfo(b.dtype).eps ** 2
+        Q[:, i] = rold / den if abs(den) > eps else rold
+        r = r - Q @ (Q.T @ z)
+        z = P(r)
+        rzdot = r @ z
+        bb = safe_divide(rzdot, rold @ zold)
+        p = z + bb * p
+    return x, {"residual_abs": r, "Q": Q}
+
+
 def linear_solve_vjp(op, params, solver, x, dx):
     """The rule of jax.lax.custom_linear_solve(..., symmetric=True) (cg.py:23-25) for x = solver(A(theta), b):
     db = solver(A, dx) (the transpose solve IS the solve), dtheta = vjp of theta -> A(theta) x with cotangent -db."""

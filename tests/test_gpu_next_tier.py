@@ -455,3 +455,43 @@ def test_target_posterior_mean(dtype, tol, kernel_name):
     dense = 0.3 + Kx @ np.linalg.solve(K + noise * np.eye(n), y - 0.3)
     assert int(info["solve"]["num_steps"]) < 2000
     assert np.allclose(N(got), dense, atol=1e-4 if dtype == torch.float64 else 5e-3)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-9), (torch.float32, 2e-3)])
+def test_cg_fixed_step_reortho_matches_oracle(dtype, tol):
+    A = orc.symmetric_matrix_from_eigenvalues(np.arange(1.0, 10.0))
+    b = np.arange(1.0, 10.0)
+    x, info = cg.cg_fixed_step_reortho(len(A))(DenseOp().bind(T(A, dtype)), T(b, dtype))  # test_cg.py:32-40
+    assert np.allclose(N(x), np.linalg.solve(A, b), rtol=max(tol, 1e-8), atol=max(tol, 1e-8))
+    m = len(A) // 2
+    want, winfo = orc.pcg_fixed_step_reortho(lambda v: A @ v, b, num_matvecs=m)
+    x, info = cg.cg_fixed_step_reortho(m)(DenseOp().bind(T(A, dtype)), T(b, dtype))
+    assert info["Q"].shape == (len(A), m)
+    assert np.allclose(N(x), want, rtol=tol, atol=tol * np.abs(want).max())
+    assert np.allclose(N(info["Q"]), winfo["Q"], atol=10 * tol)
+    assert np.allclose(N(info["Q"].T @ info["Q"]), np.eye(m), atol=max(10 * tol, 1e-8))
+    # re-orthogonalisation helps on an ill-conditioned matrix (test_cg.py:102-116)
+    A = orc.symmetric_matrix_from_eigenvalues(1.5 ** np.arange(-20.0, 20.0))
+    b = np.arange(1.0, 1.0 + len(A))
+    if dtype == torch.float64:
+        _x, i0 = cg.cg_fixed_step(len(A) // 2)(DenseOp().bind(T(A)), T(b))
+        _x, i1 = cg.cg_fixed_step_reortho(len(A) // 2)(DenseOp().bind(T(A)), T(b))
+        assert float(torch.linalg.vector_norm(i1["residual_abs"])) < 0.9 * float(torch.linalg.vector_norm(i0["residual_abs"]))
+    # with the low-rank preconditioner, against the oracle (short run: see the note on CG parity in DESIGN.md)
+    rng = np.random.default_rng(8)
+    n, rank = 300, 10
+    X = rng.uniform(-1, 1, (n, 2))
+    raw = (np.float64(0.3), np.float64(0.2), np.float64(-2.0))
+    oop = orc.RbfGramOp(X, noise_minval=1e-3)
+    ls, s, noise = oop.constrained(*raw)
+    K = orc.kernel_matrix("rbf", X, X, ls, s, diag_offset=0)
+    L, _ = orc.cholesky_partial_pivot(lambda i, j: K[i, j], n, rank)
+    bound = RbfGramOp(T(X, dtype), noise_minval=1e-3).bind(*(T(q, dtype) for q in raw))
+    pre, _ = low_rank.preconditioner(low_rank.cholesky_partial_pivot(rank=rank))(low_rank.without_noise(bound), n)
+    bb = rng.standard_normal((2, n))
+    x, info = cg.pcg_fixed_step_reortho(5)(bound, T(bb, dtype), pre.bind(noise))
+    for i in range(2):
+        want, winfo = orc.pcg_fixed_step_reortho(lambda v: K @ v + noise * v, bb[i], lambda v: orc.precondition_solve(L, v, noise),
+                                                 num_matvecs=5)
+        assert np.allclose(N(x[i]), want, rtol=max(tol, 1e-7), atol=max(tol, 1e-7) * np.abs(want).max())
+        assert np.allclose(N(info["Q"][i]), winfo["Q"], atol=max(10 * tol, 1e-7) * np.abs(winfo["Q"]).max())

@@ -403,3 +403,18 @@ def test_logpdf_krylov_equals_logpdf_cholesky_when_solves_are_exact_and_linear_s
         fd = (f(h) - f(-h)) / (2 * h)
         assert np.allclose(dparams[idx], fd, rtol=1e-5), (idx, dparams[idx], fd)
     assert np.allclose(lam, x)
+
+
+def test_cg_fixed_reortho_and_reortho_improves_error():  # test_cg.py:32-48, 102-116
+    A = orc.symmetric_matrix_from_eigenvalues(np.arange(1.0, 10.0))
+    b = np.arange(1.0, 10.0)
+    x, info = orc.pcg_fixed_step_reortho(lambda v: A @ v, b, num_matvecs=len(A))
+    assert np.allclose(x, np.linalg.solve(A, b))
+    _x, info = orc.pcg_fixed_step_reortho(lambda v: A @ v, b, num_matvecs=len(A) // 2)
+    Q = info["Q"]
+    assert np.allclose(Q.T @ Q, np.eye(Q.shape[1]), atol=1e-8)
+    A = orc.symmetric_matrix_from_eigenvalues(1.5 ** np.arange(-20.0, 20.0))
+    b = np.arange(1.0, 1.0 + len(A))
+    _x, i0 = orc.pcg_fixed_step(lambda v: A @ v, b, num_matvecs=len(A) // 2)
+    _x, i1 = orc.pcg_fixed_step_reortho(lambda v: A @ v, b, num_matvecs=len(A) // 2)
+    assert np.linalg.norm(i1["residual_abs"]) < 0.9 * np.linalg.norm(i0["residual_abs"])
