@@ -300,7 +300,7 @@ static int64_t cg_carve(const mfx_operator* op, int64_t n, int64_t p, int64_t ra
   r.active = cv.take(p * sizeof(int));
   r.nsteps = cv.take(p * sizeof(int64_t));
   r.flag = cv.take(256);
-  r.opws_bytes = op ? op_workspace_bytes(op, p) : 0;
+  r.opws_bytes = op ? op_workspace_bytes(op, p, p) : 0;
   r.opws = cv.take(r.opws_bytes);
   if (out) *out = r;
   return cv.off;

@@ -68,7 +68,7 @@ struct Carver {
 };
 
 // operator layer (mfx_ops.hip)
-int64_t op_workspace_bytes(const mfx_operator* op, int64_t batch_hint);
+int64_t op_workspace_bytes(const mfx_operator* op, int64_t batch_hint, int64_t p_apply);
 int op_apply(const mfx_operator* op, const void* x, int64_t ldx, void* y, int64_t ldy, int64_t p,
              int transpose, void* ws, int64_t ws_bytes, hipStream_t stream);
 int op_apply_cb(const mfx_operator* op, int mode, const void* x, int64_t ldx, const void* aux,

@@ -336,7 +336,7 @@ static int64_t carve_ws(const mfx_operator* op, int64_t n, int64_t k, int64_t p,
   r.p2 = cv.take(p * kmax * nblk * es);         // second-pass partials
   r.pn = cv.take(p * 3 * nblk * es);            // norm / 3-dot partials
   r.small = cv.take((2 * p * k * k + 4 * p * k + 8 * p) * es);  // Gamma, Pi_gamma, eta, coefficients
-  r.opws_bytes = op_workspace_bytes(op, p * (k + 1));  // the deferred gradient sweep batches all (probe, step) pairs
+  r.opws_bytes = op_workspace_bytes(op, p * (k + 1), p);  // the deferred gradient sweep batches all (probe, step) pairs
   r.opws = cv.take(r.opws_bytes);
   if (out) *out = r;
   return cv.off;

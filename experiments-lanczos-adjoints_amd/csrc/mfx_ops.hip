@@ -325,12 +325,16 @@ struct RbfWs {
   float* vscale;  // (rows, 2) power-of-two scales of the f16-split path
   void* hws;      // f16 hi/lo packs of the split gradient sweep (sized for `batch_hint` rows)
   int64_t hws_bytes;
+  void* pk;       // pre-packed f16 tile images of the pipelined matvec (sized for `p_apply` vectors)
+  int64_t pk_bytes;
 };
 
 int64_t rbf_grad_h_ws_bytes(int64_t n, int64_t batch);
+int64_t rbf_pack_ws_bytes(const mfx_operator* op, int64_t p);
 int rbf_mode(const mfx_operator* op);
 
-static int64_t rbf_carve(const mfx_operator* op, void* ws, int64_t ws_bytes, RbfWs* out, int64_t batch_hint = 0) {
+static int64_t rbf_carve(const mfx_operator* op, void* ws, int64_t ws_bytes, RbfWs* out, int64_t batch_hint = 0,
+                         int64_t p_apply = 0) {
   const size_t es = dtype_size(op->dtype);
   const int dpad = rbf_dpad(op->d);
   Carver cv(ws, ws_bytes);
@@ -342,6 +346,8 @@ static int64_t rbf_carve(const mfx_operator* op, void* ws, int64_t ws_bytes, Rbf
   r.vscale = static_cast<float*>(cv.take(65536 * 3 * sizeof(float)));  // [s, 1/s] per row + |max| bit patterns
   r.hws_bytes = (op->dtype == MFX_F32 && rbf_mode(op) == MFX_RBF_F16X3 && batch_hint > 0) ? rbf_grad_h_ws_bytes(op->n, batch_hint) : 0;
   r.hws = r.hws_bytes ? cv.take(r.hws_bytes) : nullptr;
+  r.pk_bytes = (op->dtype == MFX_F32 && p_apply > 0) ? rbf_pack_ws_bytes(op, p_apply) : 0;
+  r.pk = r.pk_bytes ? cv.take(r.pk_bytes) : nullptr;
   if (out) *out = r;
   return cv.off;
 }
@@ -353,7 +359,7 @@ int rbf_mfma_apply(const mfx_operator* op, const float* xs, const float* sq, int
 int rbf_mfma_apply_h(const mfx_operator* op, const float* xs, const float* sq, int dpad, const float* x, int64_t ldx,
                      float* y, int64_t ldy, int64_t p, float* vscale, hipStream_t stream);
 int rbf_mfma_apply_h3(const mfx_operator* op, const float* xs, const float* sq, int dpad, const float* x, int64_t ldx,
-                      float* y, int64_t ldy, int64_t p, float* vscale, hipStream_t stream);
+                      float* y, int64_t ldy, int64_t p, float* vscale, void* pk, hipStream_t stream);
 int rbf_mfma_grad_h(const mfx_operator* op, const float* xs, const float* sq, int dpad, const float* L, int64_t ldl,
                     const float* R, int64_t ldr, int64_t batch, double* partial, int64_t* nblocks_out, void* hws,
                     const float** scales_out, hipStream_t stream);
@@ -403,16 +409,16 @@ static int rbf_apply(const mfx_operator* op, const T* x, int64_t ldx, T* y, int6
   const int dpad = rbf_dpad(op->d);
   MFX_REQUIRE(dpad > 0, MFX_ERR_UNSUPPORTED, "RBF operator supports d <= 32 (got %d)", op->d);
   RbfWs w;
-  MFX_REQUIRE(rbf_carve(op, ws, ws_bytes, &w) <= ws_bytes && ws, MFX_ERR_WORKSPACE, "RBF workspace too small");
+  MFX_REQUIRE(rbf_carve(op, ws, ws_bytes, &w, 0, p) <= ws_bytes && ws, MFX_ERR_WORKSPACE, "RBF workspace too small");
   MFX_TRY(rbf_prep<T>(op, w, dpad, stream));
   if constexpr (sizeof(T) == 4) {
     // 1-3 vectors (the CG solves of the log-marginal likelihood): the VALU kernel below costs 2-2.7x a matrix-core
     // sweep over one 32-probe block (measured, n = 131072: 12.9 vs 5.9 ms), whose probe guards handle any p >= 1
     if (p < 4 && op->n >= 2048 && rbf_mfma_supported(op, 4) && rbf_mode(op) >= MFX_RBF_F16X3_MATVEC)
-      return rbf_mfma_apply_h3(op, (const float*)w.xs, (const float*)w.sq, dpad, x, ldx, y, ldy, p, w.vscale, stream);
+      return rbf_mfma_apply_h3(op, (const float*)w.xs, (const float*)w.sq, dpad, x, ldx, y, ldy, p, w.vscale, w.pk, stream);
     if (rbf_mfma_supported(op, p)) {
       if (rbf_mode(op) >= MFX_RBF_F16X3_MATVEC)
-        return rbf_mfma_apply_h3(op, (const float*)w.xs, (const float*)w.sq, dpad, x, ldx, y, ldy, p, w.vscale, stream);
+        return rbf_mfma_apply_h3(op, (const float*)w.xs, (const float*)w.sq, dpad, x, ldx, y, ldy, p, w.vscale, w.pk, stream);
       if (rbf_mode(op) == -1 && op->kernel_fn == MFX_KERNEL_RBF)
         return rbf_mfma_apply_h(op, (const float*)w.xs, (const float*)w.sq, dpad, x, ldx, y, ldy, p, w.vscale, stream);
       return rbf_mfma_apply(op, (const float*)w.xs, (const float*)w.sq, dpad, x, ldx, y, ldy, p, stream);
@@ -515,8 +521,8 @@ static int rbf_grad(const mfx_operator* op, const T* L, int64_t ldl, const T* R,
 // ================================================================================================
 // dispatch
 // ================================================================================================
-int64_t op_workspace_bytes(const mfx_operator* op, int64_t batch_hint) {
-  if (op->kind == MFX_OP_RBF) return rbf_carve(op, nullptr, 0, nullptr, batch_hint);
+int64_t op_workspace_bytes(const mfx_operator* op, int64_t batch_hint, int64_t p_apply) {
+  if (op->kind == MFX_OP_RBF) return rbf_carve(op, nullptr, 0, nullptr, batch_hint, p_apply);
   return 256;
 }
 

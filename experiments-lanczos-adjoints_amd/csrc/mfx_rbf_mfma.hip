@@ -292,6 +292,7 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply(const float* __restri
 // ================================================================================================
 constexpr float kKShift = 15.f;
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));  // 16-B pack as a native vector (HIP's uint4 struct went to scratch)
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 
@@ -615,13 +616,15 @@ struct RbfTileH3 {
 // truncates its internal sum (tools/mfma_f16_rounding.hip: up to -1.75 ulp, biased), which is harmless in
 // the sign-mixed contraction but showed up as a 5x larger gradient error when used for the exponent.
 // ================================================================================================
-template <int DPAD, int NB, bool VEC4, int KIND, bool DH>
+template <int DPAD, int NB, bool VEC4, int KIND, bool DH, bool PK>
 __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __restrict__ xs, const float* __restrict__ sq,
                                                               int64_t n, const float* __restrict__ outputscale,
                                                               const float* __restrict__ noise,
                                                               const float* __restrict__ vscale,
                                                               const float* __restrict__ x, int64_t ldx,
-                                                              float* __restrict__ y, int64_t ldy, int64_t p) {
+                                                              float* __restrict__ y, int64_t ldy, int64_t p,
+                                                              const uintx4* __restrict__ pkv, const uintx4* __restrict__ pka) {
+  static_assert(!PK || DH, "pre-packed operands exist for the f16-distance variant only");
   constexpr int kMI = 2, kTJ = 64;
   using Tile = RbfTileH3<DPAD, NB, kTJ>;
   constexpr int KD = Tile::KD, KS = KD / 2, NKD = Tile::NKD;
@@ -672,6 +675,47 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][nb][r] = 0.f;
+
+  // ---- PK: both LDS images come PRE-PACKED from k_pack_tiles (once per matvec instead of once per workgroup and tile: the
+  //      hi/lo split of the probe tile was 40 of the ~93 VALU instructions per 32x32 block, and VALU time adds to MFMA time).
+  //      A tile's probe image is 2 x 8 rows x P packs of 16 B (hi rows, then lo rows), its column operand 64 x AROW halves;
+  //      staging = plain 16-B copies global -> registers -> LDS, no arithmetic.
+  constexpr int kVPK = 2 * 8 * Tile::P;                 // 16-B packs of the probe image per tile
+  constexpr int kVU = (kVPK + 255) / 256;
+  constexpr int kAPK = kTJ * Tile::AROW * 2 / 16;       // 16-B packs of the column operand per tile
+  constexpr int kAU = (kAPK + 255) / 256;
+  uintx4 pv[PK ? kVU : 1], pa[PK ? kAU : 1];
+  const int64_t ntile_all = (n + kTJ - 1) / kTJ;
+  auto load_tile_pk = [&](int64_t t) {
+    const uintx4* vsrc = pkv + ((int64_t)blockIdx.y * ntile_all + t) * kVPK;
+    const uintx4* asrc = pka + t * kAPK;
+#pragma unroll
+    for (int u = 0; u < kVU; ++u) {
+      const int f = tid + 256 * u;
+      if (f < kVPK) pv[u] = vsrc[f];
+    }
+#pragma unroll
+    for (int u = 0; u < kAU; ++u) {
+      const int f = tid + 256 * u;
+      if (f < kAPK) pa[u] = asrc[f];
+    }
+  };
+  auto store_tile_pk = [&](Tile& tl) {
+#pragma unroll
+    for (int u = 0; u < kVU; ++u) {
+      const int f = tid + 256 * u;
+      if (f < kVPK) {
+        const int lo_half = f / (8 * Tile::P), rowp = f % (8 * Tile::P);
+        _Float16* dst = lo_half ? &tl.vlo[rowp / Tile::P][(rowp % Tile::P) * 8] : &tl.vhi[rowp / Tile::P][(rowp % Tile::P) * 8];
+        *reinterpret_cast<uintx4*>(dst) = pv[u];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kAU; ++u) {
+      const int f = tid + 256 * u;
+      if (f < kAPK) reinterpret_cast<uintx4*>(&tl.ajh[0][0])[f] = pa[u];
+    }
+  };
 
   constexpr int kF4 = NB * 32 * (kTJ / 4);
   constexpr int kVPT = (kF4 + 255) / 256;
@@ -762,7 +806,7 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
       }
     }
   };
-  if constexpr (DH) {  // the zero padding of the f16 column operand is written once
+  if constexpr (DH && !PK) {  // the zero padding of the f16 column operand is written once
     for (int t = tid; t < 2 * kTJ * (Tile::AROW - 3 * KD); t += 256) {
       const int w = Tile::AROW - 3 * KD;
       tile[t / (kTJ * w)].ajh[(t / w) % kTJ][3 * KD + t % w] = (_Float16)0.f;
@@ -805,13 +849,20 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
     al[s][q] = l[0]; al[s][q + 1] = l[1];
   };
 
-  load_tile(0);
-  store_tile(tile[0]);
+  if constexpr (PK) {
+    load_tile_pk(0);
+    store_tile_pk(tile[0]);
+  } else {
+    load_tile(0);
+    store_tile(tile[0]);
+  }
   __syncthreads();
   const int64_t ntile = (n + kTJ - 1) / kTJ;
   for (int64_t t = 0; t < ntile; ++t) {
     const Tile& tl = tile[t & 1];
-    if (t + 1 < ntile) load_tile((t + 1) * kTJ);
+    if (t + 1 < ntile) {
+      if constexpr (PK) load_tile_pk(t + 1); else load_tile((t + 1) * kTJ);
+    }
     // the one tile whose 64 columns are this wave's 64 rows holds the diagonal: only there (and only for the Matern
     // kernels) the per-entry self-distance fix is compiled in -- two copies of the tile body, chosen wave-uniformly
     auto do_tile = [&](auto diag_tag) {
@@ -921,7 +972,9 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
     } else {
       do_tile(std::false_type{});
     }
-    if (t + 1 < ntile) store_tile(tile[(t + 1) & 1]);
+    if (t + 1 < ntile) {
+      if constexpr (PK) store_tile_pk(tile[(t + 1) & 1]); else store_tile(tile[(t + 1) & 1]);
+    }
     __syncthreads();
   }
   const float s = outputscale[0], nz = noise[0];
@@ -963,21 +1016,120 @@ static bool rbf_dist_f16() {
   return v != 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pre-pass of the pipelined matvec: the LDS images of every 64-column tile, written ONCE per matvec.
+//   probe image   pkv[chunk][tile][lo?][row (jb, s, h)][probe][8]  : 16-B packs = the MFMA B fragments (hi / lo f16 of the scaled
+//                 probe values of columns j = 32 jb + 16 s + 8 (e >> 2) + 4 h + (e & 3), e = 0..7)
+//   column operand pka[tile][j][AROW] : [Ah | Ah | Al | 0] of c [-2 x_j, |x_j|^2 (+ shift or eps), 1], odd 32-column block negated
+// grid (ntile, chunks + 1): blockIdx.y < chunks packs that probe chunk, the last one the column operand.
+// ------------------------------------------------------------------------------------------------
+template <int DPAD, int NB, int KIND>
+__global__ __launch_bounds__(256) void k_pack_tiles(const float* __restrict__ xs, const float* __restrict__ sq, int64_t n,
+                                                    const float* __restrict__ vscale, const float* __restrict__ x,
+                                                    int64_t ldx, int64_t p, uintx4* __restrict__ pkv,
+                                                    uintx4* __restrict__ pka) {
+  constexpr int kTJ = 64;
+  using Tile = RbfTileH3<DPAD, NB, kTJ>;
+  constexpr int KD = Tile::KD, P = Tile::P, AROW = Tile::AROW;
+  constexpr float cfac = KIND == MFX_KERNEL_RBF ? kNegHalfLog2e : (KIND == MFX_KERNEL_MATERN32 ? 3.f : 1.f) * kLog2e * kLog2e;
+  const int tid = threadIdx.x;
+  const int64_t t = blockIdx.x, j0 = t * kTJ, ntile = gridDim.x;
+  if ((int)blockIdx.y < (int)gridDim.y - 1) {
+    const int64_t b0 = (int64_t)blockIdx.y * P;
+    uintx4* dst = pkv + ((int64_t)blockIdx.y * ntile + t) * (2 * 8 * P);
+    for (int f0 = tid; f0 < 8 * P; f0 += 256) {
+      // 8 consecutive lanes read the 64 consecutive columns (256 B) of ONE probe row; the 16-B stores of a lane group land in
+      // 8 different image rows, 8 consecutive probes each (a first version with lanes along the probes read 4 B per 512-KB
+      // stride and cost a millisecond)
+      const int row = f0 & 7, bq = f0 >> 3, f = row * P + bq;
+      const int jb = row >> 2, s = (row >> 1) & 1, h = row & 1;
+      const int64_t b = b0 + bq;
+      half8 hh, ll;
+      const float vs = b < p ? vscale[2 * b] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int64_t j = j0 + 32 * jb + 16 * s + 8 * (e >> 2) + 4 * h + (e & 3);
+        const float v = (b < p && j < n) ? x[b * ldx + j] * vs : 0.f;
+        float fh, fl;
+        split_hi_lo(v, fh, fl);
+        hh[e] = (_Float16)fh;
+        ll[e] = (_Float16)fl;
+      }
+      dst[f] = __builtin_bit_cast(uintx4, hh);
+      dst[8 * P + f] = __builtin_bit_cast(uintx4, ll);
+    }
+  } else {
+    __shared__ __attribute__((aligned(16))) _Float16 img[kTJ][AROW];
+    for (int e = tid; e < kTJ * AROW; e += 256) (&img[0][0])[e] = (_Float16)0.f;
+    __syncthreads();
+    for (int e = tid; e < kTJ * KD; e += 256) {
+      const int j = e / KD, kk = e % KD;
+      const int64_t jg = j0 + j;
+      float v;
+      if (kk < DPAD) v = jg < n ? -2.f * cfac * xs[jg * DPAD + kk] : 0.f;
+      else if (kk == DPAD) v = cfac * (jg < n ? sq[jg] : 0.f) + (KIND == MFX_KERNEL_RBF ? kKShift : kEpsC);
+      else v = cfac;
+      float hi, lo;
+      split_hi_lo(((j >> 5) & 1) ? -v : v, hi, lo);
+      img[j][kk] = (_Float16)hi;
+      img[j][KD + kk] = (_Float16)hi;
+      img[j][2 * KD + kk] = (_Float16)lo;
+    }
+    __syncthreads();
+    uintx4* dst = pka + t * (kTJ * AROW * 2 / 16);
+    for (int f = tid; f < kTJ * AROW * 2 / 16; f += 256) dst[f] = reinterpret_cast<const uintx4*>(&img[0][0])[f];
+  }
+}
+
+static int64_t rbf_pack_bytes_v(int64_t n, int64_t p) {
+  const int64_t P = p <= 32 ? 32 : 64, chunks = (p + P - 1) / P, ntile = (n + 63) / 64;
+  return chunks * ntile * 2 * 8 * P * 16;
+}
+int64_t rbf_pack_ws_bytes(const mfx_operator* op, int64_t p) {
+  if (op->dtype != MFX_F32 || op->d > 16 || p < 1) return 0;
+  const int64_t ntile = (op->n + 63) / 64;
+  const int dpad = op->d <= 4 ? 4 : op->d <= 8 ? 8 : op->d <= 12 ? 12 : 16;
+  const int64_t arow = ((3 * (dpad + 2) + 15) / 16) * 16 + 8;
+  return align_up(rbf_pack_bytes_v(op->n, p), 256) + align_up(ntile * 64 * arow * 2, 256);
+}
+
+// MFX_RBF_PACK=0 keeps the in-kernel split of the probe tiles (A/B runs)
+static bool rbf_prepack() {
+  static const int v = [] {
+    const char* e = getenv("MFX_RBF_PACK");
+    return e ? atoi(e) : 1;
+  }();
+  return v != 0;
+}
+
 template <int DPAD, int NB, int KIND>
 static int launch_apply_h3k(const mfx_operator* op, const float* xs, const float* sq, const float* x, int64_t ldx,
-                            float* y, int64_t ldy, int64_t p, float* vscale, hipStream_t stream) {
+                            float* y, int64_t ldy, int64_t p, float* vscale, void* pk, hipStream_t stream) {
   const int64_t n = op->n;
   MFX_TRY(row_scales(x, ldx, n, p, vscale, stream));
-  const dim3 grid((unsigned)((n + 255) / 256), (unsigned)((p + NB * 32 - 1) / (NB * 32)));
+  const unsigned chunks = (unsigned)((p + NB * 32 - 1) / (NB * 32));
+  const dim3 grid((unsigned)((n + 255) / 256), chunks);
   const bool vec4 = (n % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) &&
                     (reinterpret_cast<uintptr_t>(y) % 16 == 0);
-#define MFX_H3_LAUNCH(V4, DHV)                                                                            \
-  k_rbf_mfma_apply_h3<DPAD, NB, V4, KIND, DHV><<<grid, 256, 0, stream>>>(xs, sq, n, (const float*)op->outputscale, \
-                                                                          (const float*)op->noise, vscale, x, ldx, y, ldy, p)
-  if (rbf_dist_f16()) {
-    if (vec4) MFX_H3_LAUNCH(true, true); else MFX_H3_LAUNCH(false, true);
+  const bool pack = rbf_dist_f16() && rbf_prepack() && pk != nullptr;
+  uintx4* pkv = nullptr;
+  uintx4* pka = nullptr;
+  if (pack) {
+    const int64_t ntile = (n + 63) / 64;
+    pkv = static_cast<uintx4*>(pk);
+    pka = reinterpret_cast<uintx4*>(static_cast<char*>(pk) + align_up((int64_t)chunks * ntile * 2 * 8 * NB * 32 * 16, 256));
+    k_pack_tiles<DPAD, NB, KIND><<<dim3((unsigned)ntile, chunks + 1), 256, 0, stream>>>(xs, sq, n, vscale, x, ldx, p, pkv, pka);
+    MFX_CHECK_LAUNCH();
+  }
+#define MFX_H3_LAUNCH(V4, DHV, PKV)                                                                                  \
+  k_rbf_mfma_apply_h3<DPAD, NB, V4, KIND, DHV, PKV><<<grid, 256, 0, stream>>>(xs, sq, n, (const float*)op->outputscale, \
+                                                                               (const float*)op->noise, vscale, x, ldx, y, ldy, p, pkv, pka)
+  if (pack) {
+    if (vec4) MFX_H3_LAUNCH(true, true, true); else MFX_H3_LAUNCH(false, true, true);
+  } else if (rbf_dist_f16()) {
+    if (vec4) MFX_H3_LAUNCH(true, true, false); else MFX_H3_LAUNCH(false, true, false);
   } else {
-    if (vec4) MFX_H3_LAUNCH(true, false); else MFX_H3_LAUNCH(false, false);
+    if (vec4) MFX_H3_LAUNCH(true, false, false); else MFX_H3_LAUNCH(false, false, false);
   }
 #undef MFX_H3_LAUNCH
   MFX_CHECK_LAUNCH();
@@ -986,21 +1138,21 @@ static int launch_apply_h3k(const mfx_operator* op, const float* xs, const float
 
 template <int DPAD, int NB>
 static int launch_apply_h3(const mfx_operator* op, const float* xs, const float* sq, const float* x, int64_t ldx,
-                           float* y, int64_t ldy, int64_t p, float* vscale, hipStream_t stream) {
+                           float* y, int64_t ldy, int64_t p, float* vscale, void* pk, hipStream_t stream) {
   switch (op->kernel_fn) {
-    case MFX_KERNEL_RBF: return launch_apply_h3k<DPAD, NB, MFX_KERNEL_RBF>(op, xs, sq, x, ldx, y, ldy, p, vscale, stream);
-    case MFX_KERNEL_MATERN12: return launch_apply_h3k<DPAD, NB, MFX_KERNEL_MATERN12>(op, xs, sq, x, ldx, y, ldy, p, vscale, stream);
-    case MFX_KERNEL_MATERN32: return launch_apply_h3k<DPAD, NB, MFX_KERNEL_MATERN32>(op, xs, sq, x, ldx, y, ldy, p, vscale, stream);
+    case MFX_KERNEL_RBF: return launch_apply_h3k<DPAD, NB, MFX_KERNEL_RBF>(op, xs, sq, x, ldx, y, ldy, p, vscale, pk, stream);
+    case MFX_KERNEL_MATERN12: return launch_apply_h3k<DPAD, NB, MFX_KERNEL_MATERN12>(op, xs, sq, x, ldx, y, ldy, p, vscale, pk, stream);
+    case MFX_KERNEL_MATERN32: return launch_apply_h3k<DPAD, NB, MFX_KERNEL_MATERN32>(op, xs, sq, x, ldx, y, ldy, p, vscale, pk, stream);
     default: set_error("unknown kernel_fn %d", op->kernel_fn); return MFX_ERR_INVALID;
   }
 }
 
 int rbf_mfma_apply_h3(const mfx_operator* op, const float* xs, const float* sq, int dpad, const float* x, int64_t ldx,
-                      float* y, int64_t ldy, int64_t p, float* vscale, hipStream_t stream) {
+                      float* y, int64_t ldy, int64_t p, float* vscale, void* pk, hipStream_t stream) {
 #define MFX_H3_CASE(D)                                                                             \
   case D:                                                                                          \
-    return p <= 32 ? launch_apply_h3<D, 1>(op, xs, sq, x, ldx, y, ldy, p, vscale, stream)          \
-                   : launch_apply_h3<D, 2>(op, xs, sq, x, ldx, y, ldy, p, vscale, stream)
+    return p <= 32 ? launch_apply_h3<D, 1>(op, xs, sq, x, ldx, y, ldy, p, vscale, pk, stream)      \
+                   : launch_apply_h3<D, 2>(op, xs, sq, x, ldx, y, ldy, p, vscale, pk, stream)
   switch (dpad) {
     MFX_H3_CASE(4);
     MFX_H3_CASE(8);
