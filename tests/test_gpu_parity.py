@@ -477,3 +477,71 @@ def test_pytree_start_vector_and_matfuns():
         rv, _, (rg,) = orc.integrand_spd_value_and_grad(orc.DenseOp(), k, flat, (A,), matfun=name)
         assert close(val, rv, 1e-9), name
         assert close(g, rg, 1e-7, atol_rel=1e-7), name
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE config 4 at FULL size (n = 131072, d = 8, k = 40): size-independent properties, since the
+# oracle cannot run at this size.  fp32, default precision mode.
+# ------------------------------------------------------------------------------------------------
+def _c4_operator(n=131072, d=8):
+    g = torch.Generator(device=DEV).manual_seed(4)
+    X = torch.randn((n, d), generator=g, device=DEV, dtype=torch.float32)
+    inv = lambda v: float(np.log(np.expm1(v)))
+    raw = [torch.tensor(inv(v), device=DEV, dtype=torch.float32) for v in (2.0, 1.0, 0.1)]
+    return X, raw
+
+
+def test_c4_full_size_matvec_is_linear_and_symmetric():
+    X, raw = _c4_operator()
+    n = X.shape[0]
+    op = gp_util.gram_operator(X)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    U = torch.randn((8, n), generator=g, device=DEV)
+    V = torch.randn((8, n), generator=g, device=DEV)
+    with torch.no_grad():
+        KU, KV = op(U, *raw), op(V, *raw)
+        # symmetry: u^T K v = v^T K u (each side a sum of 131072 products of O(1e2) numbers)
+        a, b = (U.double() * KV.double()).sum(-1), (V.double() * KU.double()).sum(-1)
+        assert torch.allclose(a, b, rtol=0, atol=1e-4 * float(KU.double().norm(dim=-1).max() * V.double().norm(dim=-1).max()))
+        # linearity: K (2u - 3v) = 2 K u - 3 K v
+        lin = op(2 * U - 3 * V, *raw)
+        ref = 2 * KU - 3 * KV
+        assert float((lin - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
+        # the noise term: K e_i has noise + outputscale on the diagonal (self-distance 0)
+        e = torch.zeros((1, n), device=DEV)
+        e[0, 77] = 1.0
+        col = op(e, *raw)[0]
+        assert abs(float(col[77]) - (1.0 + 0.1)) < 1e-5
+        # single right-hand side and 64 right-hand sides go through the same kernel family: row 0 agrees
+        one = op(U[:1], *raw)
+        assert float((one[0] - KU[0]).abs().max()) <= 1e-5 * float(KU[0].abs().max())
+
+
+def test_c4_full_size_lanczos_identities_and_gradient_direction():
+    X, raw = _c4_operator()
+    n, k, p = X.shape[0], 40, 4
+    op = gp_util.gram_operator(X)
+    probes = hutchinson.sampler_rademacher(X[:, 0], num=p)(3)
+    with torch.no_grad():
+        (Q, (alpha, beta)), (q_rem, b_rem) = lanczos.tridiag(op, k, reortho="full")(probes, *raw)
+        # orthonormal basis (lanczos.py:152-169 with full re-orthogonalisation): Q Q^T = I_k per probe
+        G = Q.double() @ Q.double().transpose(-1, -2)
+        assert float((G - torch.eye(k, device=DEV, dtype=torch.float64)).abs().max()) < 5e-5
+        # three-term recurrence on the last column: A q_k = beta_{k-1} q_{k-1} + alpha_k q_k + b_rem q_rem
+        AQ = op(Q[:, -1], *raw).double()
+        rec = beta[:, -1, None].double() * Q[:, -2].double() + alpha[:, -1, None].double() * Q[:, -1].double() \
+            + b_rem[:, None].double() * q_rem.double()
+        assert float((AQ - rec).norm(dim=-1).max()) <= 1e-3 * float(AQ.norm(dim=-1).max())
+    # gradient of the SLQ estimate along a direction in (raw_l, raw_s, raw_noise) vs a central difference of the value
+    params = [q.clone().requires_grad_(True) for q in raw]
+    integrand = lanczos.integrand_spd(torch.log, k, op)
+    val = integrand(probes, *params).double().mean()
+    val.backward()
+    direction = [0.3, -0.5, 0.8]
+    got = sum(float(q.grad) * dd for q, dd in zip(params, direction))
+    h = 2e-2  # fp32 values of size 3e5 with ~1e-6 relative noise: the step must be large
+    with torch.no_grad():
+        up = integrand(probes, *[q + h * dd for q, dd in zip(raw, direction)]).double().mean()
+        dn = integrand(probes, *[q - h * dd for q, dd in zip(raw, direction)]).double().mean()
+    fd = float(up - dn) / (2 * h)
+    assert abs(got - fd) <= 2e-2 * abs(fd), (got, fd)
