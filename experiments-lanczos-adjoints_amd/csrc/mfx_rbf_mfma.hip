@@ -587,6 +587,11 @@ int rbf_mfma_apply_h(const mfx_operator* op, const float* xs, const float* sq, i
 #define MFX_RBF_CLAMP 0
 #endif
 constexpr bool kClampRbf = MFX_RBF_CLAMP != 0;
+// schedule of the pipelined kernel's block loop (see do_tile): 1 = exp/split spread over the whole block, 0 = two-phase
+#ifndef MFX_RBF_WIDE
+#define MFX_RBF_WIDE 1
+#endif
+constexpr bool kWideSched = MFX_RBF_WIDE != 0;
 
 // tile of the pipelined kernel: RbfTileH plus the f16 hi/lo image of the distance operand (DH variant)
 template <int DPAD, int NB, int kTJ>
@@ -867,6 +872,78 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
     // kernels) the per-entry self-distance fix is compiled in -- two copies of the tile body, chosen wave-uniformly
     auto do_tile = [&](auto diag_tag) {
     constexpr bool kDiag = decltype(diag_tag)::value;
+    if constexpr (DH && kWideSched) {
+      // ---- wide schedule: the exp / split of block b+1 is spread over ALL contraction MFMAs of block b (its distances were
+      //      issued during block b-1), so the VALU stream runs beside the matrix pipe for the whole block instead of half of it
+      //      (PMC: 29 % of the MFMA-busy cycles co-executed with VALU under the two-phase schedule) ----------------------
+      half8 ah[2], al[2];
+      floatx16 kdn;
+      auto dist = [&](floatx16& kd, int jbx, int mix) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) kd[r] = 0.f;
+#pragma unroll
+        for (int q = 0; q < NKD; ++q)
+          kd = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(&tl.ajh[jbx * 32 + l31][q * 16 + lhi * 8]),
+                                                      bih[mix][q], kd, 0, 0, 0);
+      };
+      {
+        floatx16 kd;
+        dist(kd, 0, 0);
+        dist(kdn, 1 / kMI, 1 % kMI);
+#pragma unroll
+        for (int pr = 0; pr < 8; ++pr) exp_split_pair(kd, pr, kDiag, false, ah, al);
+      }
+#pragma unroll
+      for (int blk = 0; blk < 2 * kMI; ++blk) {
+        const int jb = blk / kMI, mi = blk % kMI;
+        constexpr int NM = 6 * NB;
+        constexpr int MD = NM - NKD - 1;  // the distance MFMAs of block b+2 go behind contraction MFMAs MD .. MD+NKD-1
+        const bool has_next = blk + 1 < 2 * kMI, has_next2 = blk + 2 < 2 * kMI;
+        const int jbn = (blk + 1) / kMI, min_ = (blk + 1) % kMI;
+        const int jb2 = (blk + 2) / kMI, mi2 = (blk + 2) % kMI;
+        half8 bh[2][NB], bl[2][NB];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            const int row = (jb * 2 + s) * 2 + lhi;
+            bh[s][nb] = *reinterpret_cast<const half8*>(&tl.vhi[row][(nb * 32 + l31) * 8]);
+            bl[s][nb] = *reinterpret_cast<const half8*>(&tl.vlo[row][(nb * 32 + l31) * 8]);
+          }
+        half8 aj2[NKD];
+        if (has_next2) {
+#pragma unroll
+          for (int q = 0; q < NKD; ++q) aj2[q] = *reinterpret_cast<const half8*>(&tl.ajh[jb2 * 32 + l31][q * 16 + lhi * 8]);
+        }
+        const bool negn = ((jbn + min_) & 1) != 0;
+        floatx16 kdn2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) kdn2[r] = 0.f;
+        half8 ahn[2], aln[2];
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+          const int s = m / (3 * NB), nb = (m / 3) % NB, w = m % 3;
+          __builtin_amdgcn_sched_barrier(0);
+          acc[mi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w == 2 ? al[s] : ah[s], w == 1 ? bl[s][nb] : bh[s][nb],
+                                                               acc[mi][nb], 0, 0, 0);
+          if (has_next2 && m >= MD && m - MD < NKD)
+            kdn2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aj2[m - MD], bih[mi2][m - MD], kdn2, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (has_next) {
+#pragma unroll
+            for (int pr = 0; pr < 8; ++pr)
+              if (pr >= 8 * m / NM && pr < 8 * (m + 1) / NM) exp_split_pair(kdn, pr, kDiag && jbn == min_, negn, ahn, aln);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_next) {
+          ah[0] = ahn[0]; ah[1] = ahn[1];
+          al[0] = aln[0]; al[1] = aln[1];
+          kdn = kdn2;
+        }
+      }
+      return;
+    }
     half8 ah[2], al[2];
     {  // pipeline prologue: fragments of block 0 of this tile
       floatx16 kd;

@@ -1,0 +1,21 @@
+#!/bin/bash
+set -e
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/prof_coexec
+rm -rf $OUT && mkdir -p $OUT
+for grp in "SQ_VALU_MFMA_COEXEC_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES" "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INSTS_VALU_TRANS"; do
+  i=$((i+1))
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/p$i -- python3 $R/tools/bench_matvec_one.py 64 4 > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -3 $OUT/p$i.log; continue; }
+  f=$(find $OUT/p$i -name "*counter_collection.csv" | head -1)
+  python3 - "$f" <<'PY'
+import csv, sys, collections
+acc = collections.defaultdict(lambda: [0.0, 0])
+for row in csv.DictReader(open(sys.argv[1])):
+    if "apply_h3" in row["Kernel_Name"]:
+        a = acc[row["Counter_Name"]]
+        a[0] += float(row["Counter_Value"]); a[1] += 1
+for k, (v, c) in acc.items():
+    print(f"  {k}: per launch {v / c:.4g} ({c} launches)")
+PY
+done
