@@ -26,6 +26,13 @@ import torch
 from . import _lib
 
 
+def _check_dtype(desc, t, what):
+    """The descriptor's dtype is the dtype of the VECTORS; operator data of another dtype would be misread by the kernels."""
+    if _lib.dtype_code(t.dtype) != desc.dtype:
+        want = "float32" if desc.dtype == _lib.MFX_F32 else "float64"
+        raise TypeError(f"{what} must have the dtype of the vectors it is applied to ({want}), got {t.dtype}")
+
+
 class NativeOp:
     kind = None
 
@@ -124,6 +131,7 @@ class DenseOp(NativeOp):
         return A.shape[0]
 
     def fill(self, desc, A):
+        _check_dtype(desc, A, "DenseOp: the matrix")
         if A.dim() != 2 or A.shape[0] != A.shape[1]:
             raise ValueError(f"DenseOp expects a square matrix, got {tuple(A.shape)}")
         desc.dense_a = A.data_ptr()
@@ -175,6 +183,7 @@ class CsrOp(NativeOp):
         return self.n
 
     def fill(self, desc, vals):
+        _check_dtype(desc, vals, "CsrOp: the stored values")
         if vals.numel() != self.nnz:
             raise ValueError(f"CsrOp expects {self.nnz} values, got {vals.numel()}")
         desc.crow, desc.col, desc.row = self.crow.data_ptr(), self.col.data_ptr(), self.row.data_ptr()
@@ -243,6 +252,7 @@ class RbfGramOp(NativeOp):
     def fill(self, desc, ls, s, nz):
         if self.X.dtype != ls.dtype:
             raise TypeError("RbfGramOp: X and the hyper-parameters must share a dtype")
+        _check_dtype(desc, self.X, "RbfGramOp: the inputs X")
         desc.x, desc.d = self.X.data_ptr(), self.d
         desc.ard = int(ls.numel() == self.d)
         desc.rbf_mode = self._MODES[self.precision]

@@ -496,8 +496,8 @@ def test_c4_full_size_matvec_is_linear_and_symmetric():
     n = X.shape[0]
     op = gp_util.gram_operator(X)
     g = torch.Generator(device=DEV).manual_seed(1)
-    U = torch.randn((8, n), generator=g, device=DEV)
-    V = torch.randn((8, n), generator=g, device=DEV)
+    U = torch.randn((8, n), generator=g, device=DEV, dtype=torch.float32)
+    V = torch.randn((8, n), generator=g, device=DEV, dtype=torch.float32)
     with torch.no_grad():
         KU, KV = op(U, *raw), op(V, *raw)
         # symmetry: u^T K v = v^T K u (each side a sum of 131072 products of O(1e2) numbers)
@@ -508,7 +508,7 @@ def test_c4_full_size_matvec_is_linear_and_symmetric():
         ref = 2 * KU - 3 * KV
         assert float((lin - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
         # the noise term: K e_i has noise + outputscale on the diagonal (self-distance 0)
-        e = torch.zeros((1, n), device=DEV)
+        e = torch.zeros((1, n), device=DEV, dtype=torch.float32)
         e[0, 77] = 1.0
         col = op(e, *raw)[0]
         assert abs(float(col[77]) - (1.0 + 0.1)) < 1e-5
@@ -545,3 +545,16 @@ def test_c4_full_size_lanczos_identities_and_gradient_direction():
         dn = integrand(probes, *[q - h * dd for q, dd in zip(raw, direction)]).double().mean()
     fd = float(up - dn) / (2 * h)
     assert abs(got - fd) <= 2e-2 * abs(fd), (got, fd)
+
+
+def test_operator_and_vector_dtypes_must_agree():
+    """A float64 vector on float32 operator data would make the kernels misread the operator (and read out of bounds)."""
+    X = torch.randn((64, 3), device=DEV, dtype=torch.float32)
+    raw = [torch.zeros((), device=DEV, dtype=torch.float32) for _ in range(3)]
+    v64 = torch.randn(64, device=DEV, dtype=torch.float64)
+    with pytest.raises(TypeError, match="dtype of the vectors"):
+        RbfGramOp(X)(v64, *raw)
+    with pytest.raises(TypeError, match="dtype of the vectors"):
+        DenseOp()(v64, torch.eye(64, device=DEV, dtype=torch.float32))
+    with pytest.raises(TypeError, match="dtype of the vectors"):
+        lanczos.tridiag(DenseOp(), 4, reortho="full")(v64, torch.eye(64, device=DEV, dtype=torch.float32))

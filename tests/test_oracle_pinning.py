@@ -12,7 +12,17 @@ import torch
 import _torch_forward as tf
 from oracle import slq_oracle as orc
 
-torch.set_default_dtype(torch.float64)
+
+@pytest.fixture(autouse=True)
+def _float64_torch_default():
+    """The independent torch restatements run in float64 -- for the tests of THIS module only: a module-level
+    torch.set_default_dtype leaks into every other test module of the session."""
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    yield
+    torch.set_default_dtype(old)
+
+
 
 
 def _matrix12():
@@ -256,7 +266,7 @@ def test_rbf_param_vjp_matches_autodiff(ard, kind):
     tl, ts, tn = (torch.tensor(a, requires_grad=True) for a in (raw_l, raw_s, raw_n))
     sp = torch.nn.functional.softplus
     xs = Xt / sp(tl)
-    K = _torch_kernel(kind, xs, sp(ts)) + (1e-4 + sp(tn)) * torch.eye(n)
+    K = _torch_kernel(kind, xs, sp(ts)) + (1e-4 + sp(tn)) * torch.eye(n, dtype=torch.float64)
     val = (torch.tensor(cot) * (torch.tensor(v) @ K.T)).sum()
     ref = torch.autograd.grad(val, (tl, ts, tn))
     for a, b in zip(g, ref):
