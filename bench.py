@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--k", type=int, default=40)
     ap.add_argument("--probes-per-gpu", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-n", type=int, default=3072)
+    ap.add_argument("--cpu-sample-n", type=int, default=4608)
     ap.add_argument("--kernel", default="rbf", choices=["rbf", "matern32", "matern12"],
                     help="kernel family (BASELINE config 4 is the RBF kernel; the reference's UCI runs use matern32)")
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f16x3-matvec", "fp32"],
