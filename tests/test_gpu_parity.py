@@ -103,6 +103,30 @@ def test_rbf_op_apply_and_param_sweep(dtype, tol, precision, ard, n, d, p, kerne
         assert close(g.reshape(np.shape(rr)), rr, gtol, atol_rel=gtol * np.sqrt(n))
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-11), (torch.float32, 5e-5)])
+@pytest.mark.parametrize("kernel", ["rbf", "matern32"])
+@pytest.mark.parametrize("n,d,p", [(2100, 14, 2), (2050, 16, 33), (600, 20, 6), (4097, 3, 1), (2304, 12, 65)])
+def test_rbf_op_dispatch_corners(dtype, tol, kernel, n, d, p):
+    """Corners of the Gram-kernel dispatch: d = 13..16 (four f16 distance MFMAs per block), 1-3 right-hand sides on the matrix-core
+    kernel (n >= 2048), d > 16 (VALU kernel), two probe chunks (p > 64), ragged n."""
+    rng = np.random.default_rng(7)
+    X = rng.standard_normal((n, d))
+    raw = (rng.standard_normal(d) * 0.2 + 1.0, np.array(0.4), np.array(-1.0))
+    V, Cc = rng.standard_normal((p, n)), rng.standard_normal((p, n))
+    o = orc.RbfGramOp(X, noise_minval=1e-4, kernel=kernel, eps=float(torch.finfo(dtype).eps))
+    op = RbfGramOp(T(X, dtype), noise_minval=1e-4, kernel=kernel)
+    params = [T(r, dtype, True) for r in raw]
+    Vt = T(V, dtype, True)
+    y = op(Vt, *params)
+    assert close(y, o.apply(V, *raw), tol)
+    grads = torch.autograd.grad(y, (Vt, *params), T(Cc, dtype))
+    assert close(grads[0], o.apply(Cc, *raw), tol)
+    ref = o.param_vjp(V, Cc, *raw)
+    gtol = tol * (50 if dtype == torch.float32 else 10)
+    for g, rr in zip(grads[1:], ref):
+        assert close(g.reshape(np.shape(rr)), rr, gtol, atol_rel=gtol * np.sqrt(n))
+
+
 # ------------------------------------------------------------------------------------------------
 # small dense pieces
 # ------------------------------------------------------------------------------------------------
