@@ -495,3 +495,30 @@ def test_cg_fixed_step_reortho_matches_oracle(dtype, tol):
                                                  num_matvecs=5)
         assert np.allclose(N(x[i]), want, rtol=max(tol, 1e-7), atol=max(tol, 1e-7) * np.abs(want).max())
         assert np.allclose(N(info["Q"][i]), winfo["Q"], atol=max(10 * tol, 1e-7) * np.abs(winfo["Q"]).max())
+
+
+def test_bnn_lanczos_samplers():
+    """util/bnn_util.py:372-409 against a numpy restatement on the oracle's Lanczos."""
+    from matfree_extensions.util import bnn_util
+
+    rng = np.random.default_rng(9)
+    n, num, k = 30, 4, 8
+    ggn = orc.symmetric_matrix_from_eigenvalues(rng.uniform(0.5, 3.0, n), seed=3)
+    variables = rng.standard_normal(n)
+    eps = rng.standard_normal((num, n))
+    sample = bnn_util.sampler_lanczos(ggn_fun=lambda *_a: T(ggn), num=num, lanczos_rank=k)
+    got = N(sample(T(eps), None, T(variables), None, None))
+    got2 = N(bnn_util.lanczos_sampler(ggn_vp=DenseOp().bind(T(ggn)), num_samples=num, lanczos_rank=k, key=T(eps), params_vec=T(variables)))
+    for b in range(num):
+        (Q, (dg, off)), _ = orc.tridiag_full(orc.DenseOp(), k, eps[b], ggn)
+        Tm = np.diag(dg) + np.diag(off, 1) + np.diag(off, -1)
+        want = Q.T @ (np.linalg.cholesky(np.linalg.inv(Tm)) @ (Q @ eps[b])) + variables
+        assert np.allclose(got[b], want, rtol=1e-8, atol=1e-8)
+        w, v = np.linalg.eigh(Tm)
+        want2 = variables + (Q.T @ v) @ (np.sqrt(1 / w) * eps[b][:k])
+        # eigenvector signs are arbitrary: compare through the sign-invariant form
+        got_sign = N(T(got2[b] - variables))
+        proj = (Q.T @ v).T @ got_sign  # coefficients in the Ritz basis, up to sign
+        assert np.allclose(np.abs(proj), np.abs(np.sqrt(1 / w) * eps[b][:k]), rtol=1e-7, atol=1e-9)
+    full = bnn_util.sampler_cholesky(ggn_fun=lambda *_a: T(ggn), num=num)
+    assert N(full(T(eps), None, T(variables), None, None)).shape == (num, n)
