@@ -628,8 +628,11 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
                                                               const float* __restrict__ vscale,
                                                               const float* __restrict__ x, int64_t ldx,
                                                               float* __restrict__ y, int64_t ldy, int64_t p,
-                                                              const uintx4* __restrict__ pkv, const uintx4* __restrict__ pka) {
+                                                              const uintx4* __restrict__ pkv, const uintx4* __restrict__ pka,
+                                                              float* __restrict__ part) {
   static_assert(!PK || DH, "pre-packed operands exist for the f16-distance variant only");
+  // gridDim.z > 1: column split for small n (too few 256-row blocks to fill 256 CUs): workgroup z sweeps its share of the
+  // 64-column tiles and writes a partial result to part[z][probe][row]; k_split_reduce adds them in a fixed order.
   constexpr int kMI = 2, kTJ = 64;
   using Tile = RbfTileH3<DPAD, NB, kTJ>;
   constexpr int KD = Tile::KD, KS = KD / 2, NKD = Tile::NKD;
@@ -854,16 +857,17 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
     al[s][q] = l[0]; al[s][q + 1] = l[1];
   };
 
+  const int64_t ntile_tot = (n + kTJ - 1) / kTJ;
+  const int64_t t_first = ntile_tot * blockIdx.z / gridDim.z, ntile = ntile_tot * (blockIdx.z + 1) / gridDim.z;
   if constexpr (PK) {
-    load_tile_pk(0);
-    store_tile_pk(tile[0]);
+    load_tile_pk(t_first);
+    store_tile_pk(tile[t_first & 1]);
   } else {
-    load_tile(0);
-    store_tile(tile[0]);
+    load_tile(t_first * kTJ);
+    store_tile(tile[t_first & 1]);
   }
   __syncthreads();
-  const int64_t ntile = (n + kTJ - 1) / kTJ;
-  for (int64_t t = 0; t < ntile; ++t) {
+  for (int64_t t = t_first; t < ntile; ++t) {
     const Tile& tl = tile[t & 1];
     if (t + 1 < ntile) {
       if constexpr (PK) load_tile_pk(t + 1); else load_tile((t + 1) * kTJ);
@@ -1054,7 +1058,8 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
     }
     __syncthreads();
   }
-  const float s = outputscale[0], nz = noise[0];
+  const float s = outputscale[0], nz = gridDim.z > 1 ? 0.f : noise[0];
+  float* yout = gridDim.z > 1 ? part + (int64_t)blockIdx.z * p * ldy : y;
 #pragma unroll
   for (int mi = 0; mi < kMI; ++mi)
 #pragma unroll
@@ -1072,25 +1077,25 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
           o.y = fmaf(sb, acc[mi][nb][4 * g + 1], nz * xv.y);
           o.z = fmaf(sb, acc[mi][nb][4 * g + 2], nz * xv.z);
           o.w = fmaf(sb, acc[mi][nb][4 * g + 3], nz * xv.w);
-          *reinterpret_cast<float4*>(y + b * ldy + i) = o;
+          *reinterpret_cast<float4*>(yout + b * ldy + i) = o;
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            if (i + e < n) y[b * ldy + i + e] = fmaf(sb, acc[mi][nb][4 * g + e], nz * x[b * ldx + i + e]);
+            if (i + e < n) yout[b * ldy + i + e] = fmaf(sb, acc[mi][nb][4 * g + e], nz * x[b * ldx + i + e]);
         }
       }
     }
 }
 
-// distances of the pipelined kernel on the f16 matrix pipe (3-product split, alternating block sign: default) or on the
-// fp32 MFMA (MFX_RBF_DIST=0, kept for A/B runs).  Measured, C4 shape: 9.84 -> 8.08 ms per launch at 64 probes, 7.0 -> 4.8 ms
-// at <= 8 probes; SLQ value / gradient errors vs fp64 unchanged (tools/run_dist_ablation.sh, profiles/r01f_*).
-static bool rbf_dist_f16() {
-  static const int v = [] {
-    const char* e = getenv("MFX_RBF_DIST");
-    return e ? atoi(e) : 1;
-  }();
-  return v != 0;
+// y = sum_z part[z] + noise x   (fixed summation order: deterministic)
+__global__ __launch_bounds__(256) void k_split_reduce(const float* __restrict__ part, int nsplit, int64_t p, int64_t n,
+                                                      int64_t ldy, const float* __restrict__ noise,
+                                                      const float* __restrict__ x, int64_t ldx, float* __restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (i >= n) return;
+  float acc = 0.f;
+  for (int z = 0; z < nsplit; ++z) acc += part[((int64_t)z * p + b) * ldy + i];
+  y[b * ldy + i] = fmaf(noise[0], x[b * ldx + i], acc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1158,6 +1163,17 @@ __global__ __launch_bounds__(256) void k_pack_tiles(const float* __restrict__ xs
   }
 }
 
+// column splits of the pipelined matvec: enough workgroups for two per CU, at least 8 tiles each, at most 8 splits
+static int rbf_split_count(int64_t n, int64_t p) {
+  const int64_t wgs = ((n + 255) / 256) * ((p + (p <= 32 ? 32 : 64) - 1) / (p <= 32 ? 32 : 64));
+  if (wgs >= 384) return 1;
+  int64_t s = (512 + wgs - 1) / wgs;
+  const int64_t max_by_tiles = ((n + 63) / 64) / 8;
+  if (s > max_by_tiles) s = max_by_tiles;
+  if (s > 8) s = 8;
+  return s < 1 ? 1 : (int)s;
+}
+
 static int64_t rbf_pack_bytes_v(int64_t n, int64_t p) {
   const int64_t P = p <= 32 ? 32 : 64, chunks = (p + P - 1) / P, ntile = (n + 63) / 64;
   return chunks * ntile * 2 * 8 * P * 16;
@@ -1167,7 +1183,19 @@ int64_t rbf_pack_ws_bytes(const mfx_operator* op, int64_t p) {
   const int64_t ntile = (op->n + 63) / 64;
   const int dpad = op->d <= 4 ? 4 : op->d <= 8 ? 8 : op->d <= 12 ? 12 : 16;
   const int64_t arow = ((3 * (dpad + 2) + 15) / 16) * 16 + 8;
-  return align_up(rbf_pack_bytes_v(op->n, p), 256) + align_up(ntile * 64 * arow * 2, 256);
+  return align_up(rbf_pack_bytes_v(op->n, p), 256) + align_up(ntile * 64 * arow * 2, 256) +
+         align_up((int64_t)rbf_split_count(op->n, p) * p * align_up(op->n, 4) * 4, 256);
+}
+
+// distances of the pipelined kernel on the f16 matrix pipe (3-product split, alternating block sign: default) or on the
+// fp32 MFMA (MFX_RBF_DIST=0, kept for A/B runs).  Measured, C4 shape: 9.84 -> 8.08 ms per launch at 64 probes, 7.0 -> 4.8 ms
+// at <= 8 probes; SLQ value / gradient errors vs fp64 unchanged (tools/run_dist_ablation.sh, profiles/r01f_*).
+static bool rbf_dist_f16() {
+  static const int v = [] {
+    const char* e = getenv("MFX_RBF_DIST");
+    return e ? atoi(e) : 1;
+  }();
+  return v != 0;
 }
 
 // MFX_RBF_PACK=0 keeps the in-kernel split of the probe tiles (A/B runs)
@@ -1191,16 +1219,21 @@ static int launch_apply_h3k(const mfx_operator* op, const float* xs, const float
   const bool pack = rbf_dist_f16() && rbf_prepack() && pk != nullptr;
   uintx4* pkv = nullptr;
   uintx4* pka = nullptr;
+  const int64_t ntile = (n + 63) / 64;
+  const int64_t off_a = align_up((int64_t)chunks * ntile * 2 * 8 * NB * 32 * 16, 256);
+  const int64_t arow = ((3 * (DPAD + 2) + 15) / 16) * 16 + 8;
+  float* part = pk ? reinterpret_cast<float*>(static_cast<char*>(pk) + off_a + align_up(ntile * 64 * arow * 2, 256)) : nullptr;
+  const int nsplit = (part && ldy % 4 == 0 && ldy == align_up(n, 4)) ? rbf_split_count(n, p) : 1;
+  const dim3 grid3(grid.x, grid.y, (unsigned)nsplit);
   if (pack) {
-    const int64_t ntile = (n + 63) / 64;
     pkv = static_cast<uintx4*>(pk);
-    pka = reinterpret_cast<uintx4*>(static_cast<char*>(pk) + align_up((int64_t)chunks * ntile * 2 * 8 * NB * 32 * 16, 256));
+    pka = reinterpret_cast<uintx4*>(static_cast<char*>(pk) + off_a);
     k_pack_tiles<DPAD, NB, KIND><<<dim3((unsigned)ntile, chunks + 1), 256, 0, stream>>>(xs, sq, n, vscale, x, ldx, p, pkv, pka);
     MFX_CHECK_LAUNCH();
   }
 #define MFX_H3_LAUNCH(V4, DHV, PKV)                                                                                  \
-  k_rbf_mfma_apply_h3<DPAD, NB, V4, KIND, DHV, PKV><<<grid, 256, 0, stream>>>(xs, sq, n, (const float*)op->outputscale, \
-                                                                               (const float*)op->noise, vscale, x, ldx, y, ldy, p, pkv, pka)
+  k_rbf_mfma_apply_h3<DPAD, NB, V4, KIND, DHV, PKV><<<grid3, 256, 0, stream>>>(xs, sq, n, (const float*)op->outputscale, \
+                                                                                (const float*)op->noise, vscale, x, ldx, y, ldy, p, pkv, pka, part)
   if (pack) {
     if (vec4) MFX_H3_LAUNCH(true, true, true); else MFX_H3_LAUNCH(false, true, true);
   } else if (rbf_dist_f16()) {
@@ -1210,6 +1243,11 @@ static int launch_apply_h3k(const mfx_operator* op, const float* xs, const float
   }
 #undef MFX_H3_LAUNCH
   MFX_CHECK_LAUNCH();
+  if (nsplit > 1) {
+    k_split_reduce<<<dim3((unsigned)((n + 255) / 256), (unsigned)p), 256, 0, stream>>>(part, nsplit, p, n, ldy, (const float*)op->noise,
+                                                                                     x, ldx, y);
+    MFX_CHECK_LAUNCH();
+  }
   return MFX_OK;
 }
 
@@ -1879,7 +1917,9 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_grad(const float* __restric
 }
 
 bool rbf_mfma_grad_supported(const mfx_operator* op, int64_t batch) {
-  return op->dtype == MFX_F32 && batch >= 16 && op->d <= 16 && op->n >= 256;
+  // from n = 2048 on even ONE (lambda, x) pair (the PCG backward of the log-marginal likelihood) is cheaper here: the cost is
+  // the n^2 epilogue, which the VALU sweep pays at a quarter of the rate (16.8 vs ~4 ms at n = 36 584)
+  return op->dtype == MFX_F32 && (batch >= 16 || op->n >= 2048) && op->d <= 16 && op->n >= 256;
 }
 
 int64_t rbf_mfma_grad_partial_rows(int64_t n) { return ((n + kGM - 1) / kGM) * kGSplit * kGSub; }
