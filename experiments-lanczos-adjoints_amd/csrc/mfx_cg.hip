@@ -174,6 +174,8 @@ __global__ void k_cg_cond(const T* __restrict__ part_err, int nblk, int64_t n, i
   }
 }
 
+__global__ void k_set_i32(int* dst, int v) { *dst = v; }
+
 template <typename T>
 __global__ void k_fill_i64(int64_t* dst, int64_t p, int64_t v) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -545,11 +547,8 @@ static int pchol_t(const mfx_operator* op, int64_t rank, int pivot, int with_noi
   ea.X = (const T*)op->x; ea.d = op->d; ea.ard = op->ard; ea.kernel_fn = op->kernel_fn;
   ea.ls = (const T*)op->lengthscale; ea.os = (const T*)op->outputscale; ea.noise = (const T*)op->noise;
   ea.with_noise = with_noise;
-  {
-    const int one = 1;
-    MFX_CHECK_HIP(hipMemcpyAsync(success, &one, sizeof(int), hipMemcpyHostToDevice, stream));
-    MFX_CHECK_HIP(hipStreamSynchronize(stream));  // `one` lives on this stack frame
-  }
+  k_set_i32<<<1, 1, 0, stream>>>(success, 1);
+  MFX_CHECK_LAUNCH();
   for (int step = 0; step < (int)rank; ++step) {
     if (pivot) {
       k_pchol_diag<T><<<nparts, 256, 0, stream>>>(ea, lt, n, step, pval, pidx);
