@@ -66,11 +66,13 @@ __global__ __launch_bounds__(kBlock) void k_cg_xr(CgArgs<T> a) {
   const int b = blockIdx.y, blk = blockIdx.x;
   if (a.active && !a.active[b]) return;
   const int64_t slice0 = (int64_t)blk * ((int64_t)blockDim.x * kEpt);
-  if (tid == 0) {
-    const T pap = reduce_partials(a.part_pap + (int64_t)b * a.kmax * a.nblk, a.nblk);
-    alpha_sh = safe_div(a.rz_cur[b], pap);
-    const T rzv = a.rz_cur[b];
-    smn[0] = sqrt(rzv > T(0) ? rzv : T(0));  // _safe_sqrt (cg.py:244-246)
+  if (tid < 64) {
+    const T pap = reduce_partials_group<T, 64>(a.part_pap + (int64_t)b * a.kmax * a.nblk, a.nblk, tid);
+    if (tid == 0) {
+      alpha_sh = safe_div(a.rz_cur[b], pap);
+      const T rzv = a.rz_cur[b];
+      smn[0] = sqrt(rzv > T(0) ? rzv : T(0));  // _safe_sqrt (cg.py:244-246)
+    }
   }
   __syncthreads();
   const T alpha = alpha_sh;
@@ -117,10 +119,12 @@ __global__ __launch_bounds__(kBlock) void k_cg_dir(CgArgs<T> a) {
   const int b = blockIdx.y, blk = blockIdx.x;
   if (a.active && !a.active[b]) return;
   const int64_t slice0 = (int64_t)blk * ((int64_t)blockDim.x * kEpt);
-  if (tid == 0) {
-    const T rz_new = reduce_partials(a.part_rz + (int64_t)b * a.nblk, a.nblk);
-    beta_sh = a.first ? T(0) : safe_div(rz_new, a.rz_cur[b]);
-    if (blk == 0) a.rz_next[b] = rz_new;
+  if (tid < 64) {
+    const T rz_new = reduce_partials_group<T, 64>(a.part_rz + (int64_t)b * a.nblk, a.nblk, tid);
+    if (tid == 0) {
+      beta_sh = a.first ? T(0) : safe_div(rz_new, a.rz_cur[b]);
+      if (blk == 0) a.rz_next[b] = rz_new;
+    }
   }
   __syncthreads();
   const T beta = beta_sh;

@@ -25,10 +25,11 @@ __global__ void k_adj_setup(const T* __restrict__ H, const T* __restrict__ dH, c
   const int b = blockIdx.x;
   const T* Hb = H + (int64_t)b * k * k;
   const T* dHb = dH + (int64_t)b * k * k;
-  for (int j = threadIdx.x; j < k; j += blockDim.x) {
+  for (int idx = threadIdx.x; idx < k * kRedG; idx += blockDim.x) {
+    const int j = idx / kRedG, g = idx % kRedG;
     T e = dHb[(int64_t)j * k + (k - 1)];
-    if (part_qtdr) e -= reduce_partials(part_qtdr + ((int64_t)b * kmax + j) * nblk, nblk);
-    eta[(int64_t)b * k + j] = e;
+    if (part_qtdr) e -= reduce_partials_group<T, kRedG>(part_qtdr + ((int64_t)b * kmax + j) * nblk, nblk, g);
+    if (g == 0) eta[(int64_t)b * k + j] = e;
   }
   for (int ij = threadIdx.x; ij < k * k; ij += blockDim.x) {
     const int i = ij / k, j = ij % k;
@@ -44,8 +45,11 @@ template <typename T>
 __global__ void k_pig_sub(T* __restrict__ pig, int k, int col, const T* __restrict__ partial, int kmax,
                           int nblk) {
   const int b = blockIdx.x;
-  for (int j = threadIdx.x; j < k; j += blockDim.x)
-    pig[((int64_t)b * k + col) * k + j] -= reduce_partials(partial + ((int64_t)b * kmax + j) * nblk, nblk);
+  for (int idx = threadIdx.x; idx < k * kRedG; idx += blockDim.x) {
+    const int j = idx / kRedG, g = idx % kRedG;
+    const T v = reduce_partials_group<T, kRedG>(partial + ((int64_t)b * kmax + j) * nblk, nblk, g);
+    if (g == 0) pig[((int64_t)b * k + col) * k + j] -= v;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -74,16 +78,19 @@ __global__ __launch_bounds__(kBlock) void k_adj_combine(CombineArgs<T> a) {
   const int64_t kk = (int64_t)k * k;
   const T* Hb = a.H + (int64_t)b * kk;
   T* Gb = a.Gam + (int64_t)b * kk;
-  for (int j = tid; j < k; j += (int)blockDim.x) {
+  for (int jx = tid; jx < k * kRedG; jx += (int)blockDim.x) {
+    const int j = jx / kRedG, gl = jx % kRedG;
     T gj;
     if (j <= idx) {
-      const T zq = reduce_partials(a.partial + ((int64_t)b * a.kmax + j) * a.nblk, a.nblk);
+      const T zq = reduce_partials_group<T, kRedG>(a.partial + ((int64_t)b * a.kmax + j) * a.nblk, a.nblk, gl);
+      if (gl != 0) continue;
       const T low = (j < idx) ? T(1) : T(0.5);
       const T gam = low * (a.pig[(int64_t)b * kk + (int64_t)idx * k + j] - zq);
       if (blk == 0) Gb[(int64_t)idx * k + j] = gam;
       gj = (j < idx) ? gam : T(2) * gam;
       hp[j] = T(0);
     } else {
+      if (gl != 0) continue;
       gj = Gb[(int64_t)j * k + idx];  // written by the combine kernel of step j (earlier launch)
       hp[j] = Hb[(int64_t)idx * k + j];
     }
@@ -214,11 +221,11 @@ __global__ __launch_bounds__(kBlock) void k_lz_adj_lambda(const T* __restrict__ 
   __shared__ T sc[3];
   const int tid = threadIdx.x;
   const int b = blockIdx.y, blk = blockIdx.x;
-  if (tid == 0) {
+  if (tid < 64) {
+    const T d0 = reduce_partials_group<T, 64>(partial + ((int64_t)b * 3 + 0) * nblk, nblk, tid);
+    const T d1 = reduce_partials_group<T, 64>(partial + ((int64_t)b * 3 + 1) * nblk, nblk, tid);
+    const T d2 = reduce_partials_group<T, 64>(partial + ((int64_t)b * 3 + 2) * nblk, nblk, tid);
     const T bj = beta[(int64_t)b * k + j];
-    const T d0 = reduce_partials(partial + ((int64_t)b * 3 + 0) * nblk, nblk);
-    const T d1 = reduce_partials(partial + ((int64_t)b * 3 + 1) * nblk, nblk);
-    const T d2 = reduce_partials(partial + ((int64_t)b * 3 + 2) * nblk, nblk);
     const T mu = dbeta[(int64_t)b * k + j] - d0 + d1 / bj;
     const T nu = dalpha[(int64_t)b * k + j] + d2 / bj;
     sc[0] = mu;
@@ -303,9 +310,12 @@ __global__ __launch_bounds__(kBlock) void k_lz_adj_dvec(const T* __restrict__ x0
   __shared__ T sc[2];
   const int tid = threadIdx.x;
   const int b = blockIdx.y, blk = blockIdx.x;
-  if (tid == 0) {
-    sc[0] = reduce_partials(partial + ((int64_t)b * kmax) * nblk, nblk);
-    sc[1] = T(1) / vnorm[b];
+  if (tid < 64) {
+    const T d = reduce_partials_group<T, 64>(partial + ((int64_t)b * kmax) * nblk, nblk, tid);
+    if (tid == 0) {
+      sc[0] = d;
+      sc[1] = T(1) / vnorm[b];
+    }
   }
   __syncthreads();
   const T d = sc[0], inv = sc[1];

@@ -52,6 +52,20 @@ __device__ __forceinline__ T reduce_partials(const T* __restrict__ part, int nbl
   return (T)acc;
 }
 
+// The same sum by an aligned group of G consecutive lanes (G a power of two <= 64, every lane of the group calls, `g` = lane
+// within the group); result in every lane of the group.  The consumers' prologues run in EVERY slice workgroup, so with one
+// lane per coefficient they cost nblk serial reads each -- 977 at n = 2e6 (BASELINE config 5), where they dominated the
+// vector kernels.  Fixed lane-strided order + xor tree: deterministic.
+template <typename T, int G>
+__device__ __forceinline__ T reduce_partials_group(const T* __restrict__ part, int nblk, int g) {
+  double acc = 0.0;
+  for (int q = g; q < nblk; q += G) acc += (double)part[q];
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, G);
+  return (T)acc;
+}
+constexpr int kRedG = 8;  // lanes per coefficient in the multi-coefficient prologues
+
 // ------------------------------------------------------------------------------------------------
 // K-dots: partial[b][j][blk] = sum_{i in slice} rows[b][j][i] * x[b][i],  j < m
 //   forward  h = Q^T w            (arnoldi.py:87)      adjoint  P lam, z^T Q   (arnoldi.py:204,212)
@@ -140,12 +154,16 @@ __global__ __launch_bounds__(kBlock) void k_update(UpdateArgs<T> a) {
   const int b = blockIdx.y, blk = blockIdx.x;
   const int64_t slice0 = (int64_t)blk * ((int64_t)blockDim.x * kEpt);
   const int m = a.m;
-  for (int j = tid; j < m; j += (int)blockDim.x) {
+  for (int idx = tid; idx < m * kRedG; idx += (int)blockDim.x) {  // kRedG lanes per coefficient
+    const int j = idx / kRedG, g = idx % kRedG;
     T c = T(0);
-    if (a.partial_in) c = a.s1 * reduce_partials(a.partial_in + ((int64_t)b * a.kmax + j) * a.nblk, a.nblk);
-    if (a.extra) c += a.s2 * a.extra[(int64_t)b * a.extra_ldb + (int64_t)j * a.extra_stride];
-    coef[j] = c;
-    if (a.hout && blk == 0) a.hout[(int64_t)b * a.hout_ldb + (int64_t)j * a.hout_stride] = c;
+    if (a.partial_in)
+      c = a.s1 * reduce_partials_group<T, kRedG>(a.partial_in + ((int64_t)b * a.kmax + j) * a.nblk, a.nblk, g);
+    if (g == 0) {
+      if (a.extra) c += a.s2 * a.extra[(int64_t)b * a.extra_ldb + (int64_t)j * a.extra_stride];
+      coef[j] = c;
+      if (a.hout && blk == 0) a.hout[(int64_t)b * a.hout_ldb + (int64_t)j * a.hout_stride] = c;
+    }
   }
   __syncthreads();
   T xr[kEpt];
@@ -267,12 +285,12 @@ __global__ __launch_bounds__(kBlock) void k_scale(const T* __restrict__ x, int64
   __shared__ T f_sh;
   const int tid = threadIdx.x;
   const int b = blockIdx.y, blk = blockIdx.x;
-  if (tid == 0) {
+  if (tid < 64) {  // wave 0
     T f;
     if (mode == 0) {
-      const T len = sqrt(reduce_partials(partial_norm + (int64_t)b * nblk, nblk));
+      const T len = sqrt(reduce_partials_group<T, 64>(partial_norm + (int64_t)b * nblk, nblk, tid));
       f = T(1) / len;
-      if (blk == 0) {
+      if (blk == 0 && tid == 0) {
         if (len_out) len_out[(int64_t)b * len_ld] = len;
         if (inv_out) inv_out[b] = f;
       }
@@ -281,7 +299,7 @@ __global__ __launch_bounds__(kBlock) void k_scale(const T* __restrict__ x, int64
     } else {
       f = T(-1);
     }
-    f_sh = f;
+    if (tid == 0) f_sh = f;
   }
   __syncthreads();
   if (!y) return;

@@ -23,7 +23,10 @@ def expm_arnoldi(krylov_depth, *, max_squarings: int = 32, reortho="full", custo
         algorithm = arnoldi.hessenberg(matvec, krylov_depth, reortho=reortho, custom_vjp=custom_vjp)
         Q, H, _r, c = algorithm(y0_flat, *p)
         expmat = torch.linalg.matrix_exp(dt * H)
-        out = (Q @ expmat[..., :, 0:1])[..., 0] / (c[..., None] if c.dim() else c)
+        # Q expm(dt H) e1 as a weighted sum over the (k, n) storage of the basis: elementwise kernels in both directions (as a
+        # matmul on the transposed view the backward went to a 41 ms skinny rocBLAS GEMM at n = 2e6)
+        Qkn = Q.transpose(-1, -2)
+        out = (Qkn * expmat[..., :, 0:1]).sum(dim=-2) / (c[..., None] if c.dim() else c)
         return out, {"num_matvecs": krylov_depth}
 
     return expm
@@ -74,38 +77,61 @@ def wave_operator(res: int, dx: float, *, boundary: str = "neumann", device=None
     boundary_neumann :153-157 or boundary_dirichlet :146-150) as a NON-symmetric sparse operator on the flattened
     state (2 res^2,).  Returns (CsrOp, values_fn): ``values_fn(scale)`` maps the (res, res) positive coefficient field
     to the stored CSR values (differentiable), so  op(v, values_fn(scale))  is the matvec."""
+    import scipy.sparse
+
+    if boundary not in ("neumann", "dirichlet"):
+        raise ValueError(boundary)
     n2 = res * res
     idx = np.arange(n2).reshape(res, res)
-    rows, cols, w, coef = [], [], [], []  # value = w * (scale[coef] if coef >= 0 else 1)
-    for a in range(n2):  # upper-right identity block: d/dt u = du
-        rows.append(a); cols.append(n2 + a); w.append(1.0); coef.append(-1)
-    # assemble explicitly: convolve2d(stencil, pad(u)) with the reference's stencil [[0,1,0],[1,-2,1],[0,1,0]]/dx^2
-    st = np.array([[0.0, 1.0, 0.0], [1.0, -2.0, 1.0], [0.0, 1.0, 0.0]]) / dx**2
-    for i in range(res):
-        for j in range(res):
-            acc = {}
-            for di in (-1, 0, 1):
-                for dj in (-1, 0, 1):
-                    sw = st[di + 1, dj + 1]
-                    if sw == 0.0:
-                        continue
-                    ii, jj = i + di, j + dj
-                    if 0 <= ii < res and 0 <= jj < res:
-                        acc[idx[ii, jj]] = acc.get(idx[ii, jj], 0.0) + sw
-                    elif boundary == "neumann":  # jnp.pad(mode="edge"): the padded value is the nearest interior cell
-                        ic, jc = min(max(ii, 0), res - 1), min(max(jj, 0), res - 1)
-                        acc[idx[ic, jc]] = acc.get(idx[ic, jc], 0.0) + sw
-                    elif boundary != "dirichlet":
-                        raise ValueError(boundary)
-            for col, val in acc.items():
-                rows.append(n2 + idx[i, j]); cols.append(col); w.append(val); coef.append(idx[i, j])
-    rows, cols = np.asarray(rows), np.asarray(cols)
-    op, wv, order = CsrOp.from_coo(rows, cols, np.asarray(w), 2 * n2, device)
+    ii, jj = np.meshgrid(np.arange(res), np.arange(res), indexing="ij")
+    st = np.array([[0.0, 1.0, 0.0], [1.0, -2.0, 1.0], [0.0, 1.0, 0.0]]) / dx**2  # stencil_laplacian (util/pde_util.py:18-20)
+    r_l, c_l, w_l = [], [], []
+    for di in (-1, 0, 1):
+        for dj in (-1, 0, 1):
+            sw = st[di + 1, dj + 1]
+            if sw == 0.0:
+                continue
+            ni, nj = ii + di, jj + dj
+            inside = (ni >= 0) & (ni < res) & (nj >= 0) & (nj < res)
+            if boundary == "neumann":  # jnp.pad(mode="edge"): the padded value is the nearest interior cell
+                ni, nj, keep = np.clip(ni, 0, res - 1), np.clip(nj, 0, res - 1), np.ones_like(inside)
+            else:                      # zero padding: the term drops out
+                keep = inside
+            r_l.append(idx[keep])
+            c_l.append(idx[ni[keep], nj[keep]])
+            w_l.append(np.full(int(keep.sum()), sw))
+    lap = scipy.sparse.coo_matrix((np.concatenate(w_l), (np.concatenate(r_l), np.concatenate(c_l))), shape=(n2, n2)).tocsr()
+    lap.sum_duplicates()
+    lap = lap.tocoo()
+    # state (u, du): d/dt u = du (identity block), d/dt du = scale o Lap u;  value = w * (scale[coef] if coef >= 0 else 1)
+    rows = np.concatenate([np.arange(n2), n2 + lap.row])
+    cols = np.concatenate([n2 + np.arange(n2), lap.col])
+    w = np.concatenate([np.ones(n2), lap.data])
+    coef = np.concatenate([np.full(n2, -1), lap.row])
+    op, wv, order = CsrOp.from_coo(rows, cols, w, 2 * n2, device)
     wv = wv.to(dtype)
     coef_t = torch.as_tensor(np.asarray(coef)[order.numpy()], device=device)
+    # CSR order: rows 0 .. n2-1 hold the identity block (one entry each), rows n2 .. 2 n2 - 1 the Laplacian block, so the
+    # entries that depend on scale[r] are the contiguous range crow[n2 + r] .. crow[n2 + r + 1]
+    seg = (op.crow[n2:].to(torch.int64) - n2).contiguous()
+    gather = torch.clamp_min(coef_t, 0)
+    is_lap = coef_t >= 0
+
+    class _Values(torch.autograd.Function):
+        """values = w * scale[row] on the Laplacian block.  The backward is a per-row segment sum via a cumulative sum
+        (torch's generic gather backward sorts all 6e6 indices: 50 ms at res = 1000)."""
+
+        @staticmethod
+        def forward(ctx, s):
+            return torch.where(is_lap, wv * s[gather], wv)
+
+        @staticmethod
+        def backward(ctx, g):
+            gw = (g * wv)[n2:].double()
+            cs = torch.cat([gw.new_zeros(1), torch.cumsum(gw, 0)])
+            return (cs[seg[1:]] - cs[seg[:-1]]).to(g.dtype)
 
     def values_fn(scale):
-        s = scale.reshape(-1)
-        return torch.where(coef_t >= 0, wv * s[torch.clamp_min(coef_t, 0)], wv)
+        return _Values.apply(scale.reshape(-1))
 
     return op, values_fn
