@@ -339,7 +339,7 @@ __global__ void k_row_scale_from_bits(const unsigned* __restrict__ amax_bits, in
 // scale (rows, 2) = [s, 1/s]; the amax bit patterns live right behind it in the caller's buffer
 static int row_scales(const float* x, int64_t ldx, int64_t n, int64_t rows, float* scale, hipStream_t stream) {
   unsigned* bits = reinterpret_cast<unsigned*>(scale + 2 * rows);
-  MFX_CHECK_HIP(hipMemsetAsync(bits, 0, sizeof(unsigned) * rows, stream));
+  MFX_CHECK_HIP(hipMemsetAsync(bits, 0, sizeof(unsigned) * (rows + 1), stream));  // + the f16 range flag behind them
   int64_t gx = (n + 8191) / 8192;
   if (gx > 64) gx = 64;
   k_row_amax_bits<<<dim3((unsigned)gx, (unsigned)rows), 256, 0, stream>>>(x, ldx, n, bits);
@@ -629,8 +629,12 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
                                                               const float* __restrict__ x, int64_t ldx,
                                                               float* __restrict__ y, int64_t ldy, int64_t p,
                                                               const uintx4* __restrict__ pkv, const uintx4* __restrict__ pka,
-                                                              float* __restrict__ part) {
+                                                              float* __restrict__ part, const int* __restrict__ rangeflag) {
   static_assert(!PK || DH, "pre-packed operands exist for the f16-distance variant only");
+  // f16 range guard: when a scaled input is too large for the f16 image of the distance operands (|x/l|^2 beyond ~6e4 / |c|),
+  // k_pack_tiles raises the flag; the f16-distance launch then returns at once and the fp32-distance launch behind it does
+  // the work (and vice versa) -- correct for any input, no host round trip, one empty launch per matvec.
+  if (rangeflag && (*rangeflag != 0) == DH) return;
   // gridDim.z > 1: column split for small n (too few 256-row blocks to fill 256 CUs): workgroup z sweeps its share of the
   // 64-column tiles and writes a partial result to part[z][probe][row]; k_split_reduce adds them in a fixed order.
   constexpr int kMI = 2, kTJ = 64;
@@ -1109,7 +1113,7 @@ template <int DPAD, int NB, int KIND>
 __global__ __launch_bounds__(256) void k_pack_tiles(const float* __restrict__ xs, const float* __restrict__ sq, int64_t n,
                                                     const float* __restrict__ vscale, const float* __restrict__ x,
                                                     int64_t ldx, int64_t p, uintx4* __restrict__ pkv,
-                                                    uintx4* __restrict__ pka) {
+                                                    uintx4* __restrict__ pka, int* __restrict__ rangeflag) {
   constexpr int kTJ = 64;
   using Tile = RbfTileH3<DPAD, NB, kTJ>;
   constexpr int KD = Tile::KD, P = Tile::P, AROW = Tile::AROW;
@@ -1151,6 +1155,8 @@ __global__ __launch_bounds__(256) void k_pack_tiles(const float* __restrict__ xs
       if (kk < DPAD) v = jg < n ? -2.f * cfac * xs[jg * DPAD + kk] : 0.f;
       else if (kk == DPAD) v = cfac * (jg < n ? sq[jg] : 0.f) + (KIND == MFX_KERNEL_RBF ? kKShift : kEpsC);
       else v = cfac;
+      // largest magnitudes of the f16 images: this column-operand entry, and |x_j|^2 itself as a row-operand entry
+      if (fabsf(v) > 6.0e4f || (kk == DPAD && jg < n && sq[jg] > 6.0e4f)) atomicOr(rangeflag, 1);
       float hi, lo;
       split_hi_lo(((j >> 5) & 1) ? -v : v, hi, lo);
       img[j][kk] = (_Float16)hi;
@@ -1225,21 +1231,23 @@ static int launch_apply_h3k(const mfx_operator* op, const float* xs, const float
   float* part = pk ? reinterpret_cast<float*>(static_cast<char*>(pk) + off_a + align_up(ntile * 64 * arow * 2, 256)) : nullptr;
   const int nsplit = (part && ldy % 4 == 0 && ldy == align_up(n, 4)) ? rbf_split_count(n, p) : 1;
   const dim3 grid3(grid.x, grid.y, (unsigned)nsplit);
+  int* rangeflag = reinterpret_cast<int*>(vscale + 3 * p);  // zeroed by row_scales
   if (pack) {
     pkv = static_cast<uintx4*>(pk);
     pka = reinterpret_cast<uintx4*>(static_cast<char*>(pk) + off_a);
-    k_pack_tiles<DPAD, NB, KIND><<<dim3((unsigned)ntile, chunks + 1), 256, 0, stream>>>(xs, sq, n, vscale, x, ldx, p, pkv, pka);
+    k_pack_tiles<DPAD, NB, KIND><<<dim3((unsigned)ntile, chunks + 1), 256, 0, stream>>>(xs, sq, n, vscale, x, ldx, p, pkv, pka, rangeflag);
     MFX_CHECK_LAUNCH();
   }
-#define MFX_H3_LAUNCH(V4, DHV, PKV)                                                                                  \
+#define MFX_H3_LAUNCH(V4, DHV, PKV, FLAG)                                                                            \
   k_rbf_mfma_apply_h3<DPAD, NB, V4, KIND, DHV, PKV><<<grid3, 256, 0, stream>>>(xs, sq, n, (const float*)op->outputscale, \
-                                                                                (const float*)op->noise, vscale, x, ldx, y, ldy, p, pkv, pka, part)
+                                                                                (const float*)op->noise, vscale, x, ldx, y, ldy, p, pkv, pka, part, FLAG)
   if (pack) {
-    if (vec4) MFX_H3_LAUNCH(true, true, true); else MFX_H3_LAUNCH(false, true, true);
+    if (vec4) MFX_H3_LAUNCH(true, true, true, rangeflag); else MFX_H3_LAUNCH(false, true, true, rangeflag);
+    if (vec4) MFX_H3_LAUNCH(true, false, false, rangeflag); else MFX_H3_LAUNCH(false, false, false, rangeflag);  // runs only if flagged
   } else if (rbf_dist_f16()) {
-    if (vec4) MFX_H3_LAUNCH(true, true, false); else MFX_H3_LAUNCH(false, true, false);
+    if (vec4) MFX_H3_LAUNCH(true, true, false, nullptr); else MFX_H3_LAUNCH(false, true, false, nullptr);
   } else {
-    if (vec4) MFX_H3_LAUNCH(true, false, false); else MFX_H3_LAUNCH(false, false, false);
+    if (vec4) MFX_H3_LAUNCH(true, false, false, nullptr); else MFX_H3_LAUNCH(false, false, false, nullptr);
   }
 #undef MFX_H3_LAUNCH
   MFX_CHECK_LAUNCH();
