@@ -894,6 +894,21 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
           kd = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(&tl.ajh[jbx * 32 + l31][q * 16 + lhi * 8]),
                                                       bih[mix][q], kd, 0, 0, 0);
       };
+      // B fragments (probe tile) of a block are fetched from LDS one block ahead: the ds_read latency in front of the first MFMA
+      // of every block was ~10 % of the tile
+      half8 bhb[2][2][NB], blb[2][2][NB];
+      auto load_b = [&](int buf, int jbx) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            const int row = (jbx * 2 + s) * 2 + lhi;
+            bhb[buf][s][nb] = *reinterpret_cast<const half8*>(&tl.vhi[row][(nb * 32 + l31) * 8]);
+            blb[buf][s][nb] = *reinterpret_cast<const half8*>(&tl.vlo[row][(nb * 32 + l31) * 8]);
+          }
+      };
+      constexpr bool kPrefB = PK && (NB == 1 || DPAD <= 8);  // elsewhere the second fragment set does not fit in 256 VGPRs
+      if (kPrefB) load_b(0, 0);
       {
         floatx16 kd;
         dist(kd, 0, 0);
@@ -909,15 +924,8 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
         const bool has_next = blk + 1 < 2 * kMI, has_next2 = blk + 2 < 2 * kMI;
         const int jbn = (blk + 1) / kMI, min_ = (blk + 1) % kMI;
         const int jb2 = (blk + 2) / kMI, mi2 = (blk + 2) % kMI;
-        half8 bh[2][NB], bl[2][NB];
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb) {
-            const int row = (jb * 2 + s) * 2 + lhi;
-            bh[s][nb] = *reinterpret_cast<const half8*>(&tl.vhi[row][(nb * 32 + l31) * 8]);
-            bl[s][nb] = *reinterpret_cast<const half8*>(&tl.vlo[row][(nb * 32 + l31) * 8]);
-          }
+        const int cur = kPrefB ? (blk & 1) : 0;
+        if (!kPrefB) load_b(0, jb);
         half8 aj2[NKD];
         if (has_next2) {
 #pragma unroll
@@ -932,10 +940,11 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
         for (int m = 0; m < NM; ++m) {
           const int s = m / (3 * NB), nb = (m / 3) % NB, w = m % 3;
           __builtin_amdgcn_sched_barrier(0);
-          acc[mi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w == 2 ? al[s] : ah[s], w == 1 ? bl[s][nb] : bh[s][nb],
+          acc[mi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w == 2 ? al[s] : ah[s], w == 1 ? blb[cur][s][nb] : bhb[cur][s][nb],
                                                                acc[mi][nb], 0, 0, 0);
           if (has_next2 && m >= MD && m - MD < NKD)
             kdn2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aj2[m - MD], bih[mi2][m - MD], kdn2, 0, 0, 0);
+          if (kPrefB && m == 0 && has_next) load_b(cur ^ 1, jbn);  // next block's fragments: a whole block of latency cover
           __builtin_amdgcn_sched_barrier(0);
           if (has_next) {
 #pragma unroll

@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_c5
 rm -rf $OUT && mkdir -p $OUT
 cd $R
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 tools/bench_configs.py c5 > $OUT/log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 tools/bench_configs.py ${CFG:-c5} > $OUT/log 2>&1
 f=$(find $OUT -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys
