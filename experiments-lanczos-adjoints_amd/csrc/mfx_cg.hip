@@ -572,7 +572,8 @@ using namespace mfx;
 static int check_precond(int64_t n, int64_t rank, const void* lt, const void* minv, const void* shift) {
   MFX_REQUIRE(rank >= 1 && rank <= n, MFX_ERR_INVALID, "preconditioner rank %lld outside [1, n = %lld]", (long long)rank,
               (long long)n);
-  MFX_REQUIRE(rank <= 4096, MFX_ERR_UNSUPPORTED, "preconditioner rank %lld > 4096", (long long)rank);
+  // L^T v runs through k_dots with m = rank rows: 4 * rank * 8 B of LDS for its per-wave partials
+  MFX_REQUIRE(rank <= 1024, MFX_ERR_UNSUPPORTED, "preconditioner rank %lld > 1024", (long long)rank);
   MFX_REQUIRE(lt && minv && shift, MFX_ERR_INVALID, "preconditioner needs lt, minv and shift");
   return MFX_OK;
 }
@@ -615,7 +616,7 @@ int mfx_pcg_solve_reortho(const mfx_operator* op, const void* b, int64_t ldb, in
   MFX_REQUIRE(op && b && x && r && q, MFX_ERR_INVALID, "mfx_pcg_solve_reortho: null argument");
   MFX_REQUIRE(op->n == n && n >= 1 && p >= 1 && ldb >= n, MFX_ERR_INVALID, "mfx_pcg_solve_reortho: bad sizes");
   MFX_REQUIRE(p <= 65535, MFX_ERR_UNSUPPORTED, "at most 65535 right-hand sides per call");
-  MFX_REQUIRE(num_matvecs >= 1 && num_matvecs <= 4096, MFX_ERR_INVALID, "num_matvecs %lld outside [1, 4096]",
+  MFX_REQUIRE(num_matvecs >= 1 && num_matvecs <= 1024, MFX_ERR_INVALID, "num_matvecs %lld outside [1, 1024]",
               (long long)num_matvecs);
   MFX_REQUIRE(op->dtype == MFX_F32 || op->dtype == MFX_F64, MFX_ERR_INVALID, "bad dtype");
   Precond pc{precond_lt, precond_minv, precond_shift, rank};
@@ -678,7 +679,7 @@ int mfx_partial_cholesky(const mfx_operator* op, int64_t rank, int pivot, int wi
               "partial Cholesky needs element access: dense or kernel-Gram operators only");
   MFX_REQUIRE(rank <= op->n, MFX_ERR_INVALID, "Rank exceeds n: %lld >= %lld.", (long long)rank, (long long)op->n);
   MFX_REQUIRE(rank >= 1, MFX_ERR_INVALID, "Rank must be positive, but %lld < 1.", (long long)rank);
-  MFX_REQUIRE(rank <= 4096, MFX_ERR_UNSUPPORTED, "rank %lld > 4096", (long long)rank);
+  MFX_REQUIRE(rank <= 1024, MFX_ERR_UNSUPPORTED, "rank %lld > 1024 (the preconditioner applies at most 1024 columns)", (long long)rank);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (op->dtype == MFX_F32)
     return pchol_t<float>(op, rank, pivot, with_noise, (float*)lt, (int64_t*)pivots, (int*)success, ws, ws_bytes, s);
