@@ -24,6 +24,7 @@
 namespace mfx {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
 
 // geometry of the parameter-gradient GEMM (both the fp32 and the 3 x f16 variant)
 constexpr int kGM = 128, kGN = 128, kGK = 32, kGSplit = 8;
@@ -1568,9 +1569,13 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_grad_h(const float* __restr
         const float w = s_ij * wl;
         if (ard) {
 #pragma unroll
-          for (int c = 0; c < DPAD; ++c) {
-            const float df = xiv[c] - xjv[c];
-            gt[c] = fmaf(w * df, df, gt[c]);
+          for (int c = 0; c < DPAD; c += 2) {  // packed fp32 (v_pk_add / v_pk_mul / v_pk_fma): two dimensions per instruction
+            const floatx2 xi2 = {xiv[c], xiv[c + 1]}, xj2 = {xjv[c], xjv[c + 1]};
+            const floatx2 df = xi2 - xj2;
+            floatx2 g2 = {gt[c], gt[c + 1]};
+            g2 = __builtin_elementwise_fma(df * w, df, g2);
+            gt[c] = g2[0];
+            gt[c + 1] = g2[1];
           }
         } else {
           gt[0] = fmaf(w, dist, gt[0]);
@@ -1907,9 +1912,13 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_grad(const float* __restric
         const float w = s_ij * wl;
         if (ard) {
 #pragma unroll
-          for (int c = 0; c < DPAD; ++c) {
-            const float df = xiv[c] - xjv[c];
-            gt[c] = fmaf(w * df, df, gt[c]);
+          for (int c = 0; c < DPAD; c += 2) {  // packed fp32 (v_pk_add / v_pk_mul / v_pk_fma): two dimensions per instruction
+            const floatx2 xi2 = {xiv[c], xiv[c + 1]}, xj2 = {xjv[c], xjv[c + 1]};
+            const floatx2 df = xi2 - xj2;
+            floatx2 g2 = {gt[c], gt[c + 1]};
+            g2 = __builtin_elementwise_fma(df * w, df, g2);
+            gt[c] = g2[0];
+            gt[c + 1] = g2[1];
           }
         } else {
           gt[0] = fmaf(w, dist, gt[0]);
