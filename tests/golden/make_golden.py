@@ -139,10 +139,52 @@ def csr_1138_bus():
     save("csr_1138_bus.npz", **out)
 
 
+def gp_logml():
+    """The "next" tier: short PCG runs (<= 8 steps: deterministic across implementations),
+    pivoted partial Cholesky, Woodbury preconditioner and the composed log-marginal likelihood with its gradient."""
+    rng = np.random.default_rng(21)
+    n, d, rank, steps, k, nprobes, seed = 256, 3, 12, 8, 8, 4, 7
+    X = rng.uniform(-1, 1, (n, d))
+    y = np.sin(X.sum(-1)) + 0.1 * rng.standard_normal(n)
+    raw = (np.array([0.2, -0.1, 0.4]), np.float64(0.3), np.float64(-2.0))
+    minval, cval = 1e-3, 0.2
+    out = {"X": X, "y": y, "raw_l": raw[0], "raw_s": raw[1], "raw_n": raw[2], "minval": np.array(minval), "cval": np.array(cval),
+           "rank": np.array(rank), "steps": np.array(steps), "k": np.array(k), "nprobes": np.array(nprobes), "seed": np.array(seed)}
+    for kind in ("rbf", "matern32"):
+        op = orc.RbfGramOp(X, noise_minval=minval, kernel=kind)
+        ls, s, noise = op.constrained(*raw)
+        K = orc.kernel_matrix(kind, X, X, ls, s, diag_offset=0)
+        L, info = orc.cholesky_partial_pivot(lambda i, j: K[i, j], n, rank)
+        assert info["success"]
+        P = lambda v: orc.precondition_solve(L, v, noise)
+        A = lambda v: op.apply(v, *raw)
+        b = y - cval
+        solver = lambda Af, rhs: orc.pcg_fixed_step(Af, rhs, P, num_matvecs=steps)
+        x, sinfo = solver(A, b)
+        x_plain, _ = orc.pcg_fixed_step(A, b, None, num_matvecs=steps)
+        xa, ainfo = orc.pcg_adaptive(A, b, P, atol=1e-3, rtol=0.0, maxiter=100, miniter=2)
+        probes = orc.rademacher(seed, nprobes, n)
+        ld, ld_grads, _ = orc.hutchinson_value_and_grad(op, k, probes, raw)
+        value, _ = orc.logpdf_krylov(y, np.full(n, cval), logdet_value=ld, solve=lambda rhs: solver(A, rhs))
+        lam, dp = orc.linear_solve_vjp(op, raw, solver, x, -0.5 * b)
+        db = -0.5 * x + lam
+        grads = [-0.5 * g + q for g, q in zip(ld_grads, dp)]
+        pre = kind + "_"
+        out.update({pre + "L": L, pre + "pivots": info["pivots"], pre + "x_pcg": x, pre + "r_pcg": sinfo["residual_abs"],
+                    pre + "x_cg": x_plain, pre + "x_adaptive": xa, pre + "steps_adaptive": np.array(ainfo["num_steps"]),
+                    pre + "precond_b": P(b), pre + "logml": np.array(value), pre + "g_l": grads[0], pre + "g_s": np.array(grads[1]),
+                    pre + "g_n": np.array(grads[2]), pre + "g_y": db, pre + "g_c": np.array(-db.sum())})
+    save("gp_logml_n256.npz", **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "gp_logml":
+        gp_logml()
+        sys.exit(0)
     tridiag_forward()
     arnoldi_adjoint()
     tridiag_adjoint()
     slq_dense()
     slq_rbf()
     csr_1138_bus()
+    gp_logml()

@@ -66,3 +66,49 @@ def test_csr_fixture_is_symmetric_expansion_of_1138_bus():
     D = np.zeros((n, n))
     np.add.at(D, (g["row"], g["col"]), g["vals"])
     assert np.allclose(D, D.T)
+
+
+@pytest.mark.parametrize("kind", ["rbf", "matern32"])
+def test_gp_logml_fixture_is_self_consistent(kind):
+    """Independent re-validation of tests/golden/gp_logml_n256.npz (the "next" tier): defining properties of the
+    pivoted Cholesky factor, the Woodbury solve and the PCG output, and the gradient against central differences of the value."""
+    g = np.load(os.path.join(GOLD, "gp_logml_n256.npz"))
+    X, y = g["X"], g["y"]
+    raw = (g["raw_l"], g["raw_s"][()], g["raw_n"][()])
+    n, rank, steps, k = len(y), int(g["rank"]), int(g["steps"]), int(g["k"])
+    op = orc.RbfGramOp(X, noise_minval=float(g["minval"]), kernel=kind)
+    ls, s, noise = op.constrained(*raw)
+    K = orc.kernel_matrix(kind, X, X, ls, s, diag_offset=0)
+    L, piv = g[kind + "_L"], g[kind + "_pivots"]
+    # pivoted partial Cholesky: exact on the pivot rows/columns, residual PSD and smaller than without the factor
+    R = K - L @ L.T
+    assert np.abs(R[piv]).max() < 1e-10 and len(set(piv.tolist())) == rank
+    assert np.linalg.eigvalsh(R).min() > -1e-10 and np.trace(R) < 0.5 * np.trace(K)
+    # Woodbury solve: (noise I + L L^T) z = b
+    b = y - float(g["cval"])
+    z = g[kind + "_precond_b"]
+    assert np.allclose(noise * z + L @ (L.T @ z), b, rtol=1e-10, atol=1e-10)
+    # PCG: residual output is b - A x; preconditioning helps; the adaptive run met its tolerance
+    A = K + noise * np.eye(n)
+    assert np.allclose(b - A @ g[kind + "_x_pcg"], g[kind + "_r_pcg"], atol=1e-9)
+    exact = np.linalg.solve(A, b)
+    assert np.linalg.norm(g[kind + "_x_pcg"] - exact) < np.linalg.norm(g[kind + "_x_cg"] - exact)
+    ra = b - A @ g[kind + "_x_adaptive"]
+    assert np.sqrt(np.mean((ra / 1e-3) ** 2)) <= 1.0 and 2 <= int(g[kind + "_steps_adaptive"]) < 100
+    # gradient of the composed log-marginal likelihood (fixed probes, fixed preconditioner) vs central differences
+    probes = orc.rademacher(int(g["seed"]), int(g["nprobes"]), n)
+    P = lambda v: orc.precondition_solve(L, v, noise)
+
+    def value(raw_, cval):
+        ld, _, _ = orc.hutchinson_value_and_grad(op, k, probes, raw_)
+        sol = lambda rhs: orc.pcg_fixed_step(lambda v: op.apply(v, *raw_), rhs, P, num_matvecs=steps)
+        return orc.logpdf_krylov(y, np.full(n, cval), logdet_value=ld, solve=sol)[0]
+
+    assert np.isclose(value(raw, float(g["cval"])), float(g[kind + "_logml"]), rtol=1e-12)
+    h = 1e-5
+    # the fixture's gradient follows custom_linear_solve (the solver output is treated as an exact solve): after `steps` PCG
+    # steps it agrees with differentiating the truncated iteration only up to the remaining solve error -> loose tolerance
+    fd_s = (value((raw[0], raw[1] + h, raw[2]), float(g["cval"])) - value((raw[0], raw[1] - h, raw[2]), float(g["cval"]))) / (2 * h)
+    assert abs(fd_s - float(g[kind + "_g_s"])) <= 5e-2 * abs(fd_s) + 1e-3
+    fd_c = (value(raw, float(g["cval"]) + h) - value(raw, float(g["cval"]) - h)) / (2 * h)
+    assert abs(fd_c - float(g[kind + "_g_c"])) <= 5e-2 * abs(fd_c) + 1e-3

@@ -522,3 +522,50 @@ def test_bnn_lanczos_samplers():
         assert np.allclose(np.abs(proj), np.abs(np.sqrt(1 / w) * eps[b][:k]), rtol=1e-7, atol=1e-9)
     full = bnn_util.sampler_cholesky(ggn_fun=lambda *_a: T(ggn), num=num)
     assert N(full(T(eps), None, T(variables), None, None)).shape == (num, n)
+
+
+@pytest.mark.parametrize("kind", ["rbf", "matern32"])
+def test_gp_logml_golden_fixture(kind):
+    """fp64 build against the committed fixture tests/golden/gp_logml_n256.npz: partial Cholesky, preconditioner, PCG (fixed and
+    adaptive) and value + gradient of the composed log-marginal likelihood."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gp_logml_n256.npz"))
+    X, y = g["X"], g["y"]
+    n, rank, steps, k, nprobes, seed = len(y), int(g["rank"]), int(g["steps"]), int(g["k"]), int(g["nprobes"]), int(g["seed"])
+    minval, cval = float(g["minval"]), float(g["cval"])
+    tl, ts, tn = T(g["raw_l"], grad=True), T(g["raw_s"], grad=True), T(g["raw_n"], grad=True)
+    tc, ty = T(cval, grad=True), T(y, grad=True)
+    bound = RbfGramOp(T(X), noise_minval=minval, kernel=kind).bind(tl.detach(), ts.detach(), tn.detach())
+    noise = minval + float(torch.nn.functional.softplus(tn.detach()))
+    chol, info = low_rank.cholesky_partial_pivot(rank=rank)(low_rank.without_noise(bound), n)
+    assert np.array_equal(N(info["pivots"]).astype(int), g[kind + "_pivots"])
+    assert np.allclose(N(chol), g[kind + "_L"], rtol=1e-8, atol=1e-10)
+    pre, _ = low_rank.preconditioner(low_rank.cholesky_partial_pivot(rank=rank))(low_rank.without_noise(bound), n)
+    b = T(y - cval)
+    assert np.allclose(N(pre(b, noise)), g[kind + "_precond_b"], rtol=1e-8, atol=1e-10)
+    x, sinfo = cg.pcg_fixed_step(steps)(bound, b, pre.bind(noise))
+    assert np.allclose(N(x), g[kind + "_x_pcg"], rtol=1e-7, atol=1e-9)
+    assert np.allclose(N(sinfo["residual_abs"]), g[kind + "_r_pcg"], atol=1e-8)
+    x, _ = cg.cg_fixed_step(steps)(bound, b)
+    assert np.allclose(N(x), g[kind + "_x_cg"], rtol=1e-7, atol=1e-9)
+    x, ainfo = cg.pcg_adaptive(atol=1e-3, rtol=0.0, maxiter=100, miniter=2)(bound, b, pre.bind(noise))
+    assert int(ainfo["num_steps"]) == int(g[kind + "_steps_adaptive"])
+    assert np.allclose(N(x), g[kind + "_x_adaptive"], rtol=1e-6, atol=1e-8)
+
+    make_kernel = {"rbf": gp_util.kernel_scaled_rbf, "matern32": gp_util.kernel_scaled_matern_32}[kind]
+    k_fun, _ = make_kernel(shape_in=(X.shape[1],), shape_out=())
+    m_fun, _ = gp_util.mean_constant(shape_out=())
+    sample = hutchinson.sampler_rademacher(torch.empty(n, dtype=torch.float64, device=DEV), num=nprobes)
+    logpdf_p = gp_util.logpdf_krylov_p(solve_p=cg.pcg_fixed_step(steps), logdet=gp_util.krylov_logdet_slq(k, sample=sample, num_batches=1))
+    likelihood, _ = gp_util.likelihood_pdf_p(gp_util.gram_matvec(), logpdf_p,
+                                             low_rank.preconditioner(low_rank.cholesky_partial_pivot(rank=rank)),
+                                             constrain=gp_util.constraint_greater_than(minval))
+    value, _ = gp_util.target_logml(gp_util.model_gp(m_fun, k_fun), likelihood)(
+        T(X), ty, seed, params_mean={"constant_value": tc}, params_kernel={"raw_lengthscale": tl, "raw_outputscale": ts},
+        params_likelihood={"raw_noise": tn})
+    value.backward()
+    assert abs(float(value.detach()) - float(g[kind + "_logml"])) <= 1e-8 * abs(float(g[kind + "_logml"]))
+    for got, key in ((tl, "_g_l"), (ts, "_g_s"), (tn, "_g_n"), (ty, "_g_y"), (tc, "_g_c")):
+        want = g[kind + key]
+        assert np.allclose(N(got.grad), want, rtol=1e-6, atol=1e-7 * max(1.0, float(np.abs(want).max()))), key
