@@ -202,6 +202,13 @@ def main():
                 "param_grad_sweep": grad_ms / args.steps,
                 "krylov_vector_kernels": vec_ms / args.steps,
             },
+            "param_grad_gemm": {
+                # S = L^T R over all (probe, step) pairs, batch = p (k + 1): algorithmic flops 2 n^2 batch, once per step
+                "algorithmic_flops": 2.0 * n * n * p * (k + 1),
+                "achieved_TFLOPs": 2.0 * n * n * p * (k + 1) / max(grad_ms / max(grad_cnt, 1) * 1e-3, 1e-12) / 1e12,
+                "peak_TFLOPs": peak,
+                "executed_mfma_flops_factor": 3.0 if args.precision == "f16x3" else 1.0,
+            },
             "krylov_vector_hbm": {
                 # B_fwd + B_bwd = p n s [2k(k+1)+3k] + p n s [3k^2+9k] algorithmic bytes
                 "algorithmic_GB_per_step": p * n * 4 * (2 * k * (k + 1) + 3 * k + 3 * k * k + 9 * k) / 1e9,
