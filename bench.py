@@ -206,7 +206,7 @@ def main():
                 # S = L^T R over all (probe, step) pairs, batch = p (k + 1): algorithmic flops 2 n^2 batch, once per step
                 "algorithmic_flops": 2.0 * n * n * p * (k + 1),
                 "achieved_TFLOPs": 2.0 * n * n * p * (k + 1) / max(grad_ms / max(grad_cnt, 1) * 1e-3, 1e-12) / 1e12,
-                "peak_TFLOPs": peak,
+                "peak_TFLOPs": MFMA_F16_PEAK_TFLOPS if args.precision == "f16x3" else MFMA_F32_PEAK_TFLOPS,
                 "executed_mfma_flops_factor": 3.0 if args.precision == "f16x3" else 1.0,
             },
             "krylov_vector_hbm": {
