@@ -71,6 +71,12 @@ def test_product_path_has_no_cpu_fallback():
         lanczos.integrand_spd(torch.log, 2, DenseOp())(torch.ones(4), torch.eye(4))
     with pytest.raises(_lib.MfxError, match="no CPU fallback"):
         hutchinson.sampler_rademacher(torch.ones(4), num=2)(0)
+    from matfree_extensions import cg, low_rank
+
+    with pytest.raises(_lib.MfxError, match="no CPU fallback"):
+        cg.cg_fixed_step(2)(DenseOp().bind(torch.eye(4)), torch.ones(4))
+    with pytest.raises(_lib.MfxError, match="no CPU fallback"):
+        low_rank.cholesky_partial_pivot(rank=2)(torch.eye(4), 4)
     src = ""
     pkg = os.path.join(ROOT, "experiments-lanczos-adjoints_amd", "matfree_extensions")
     for dirpath, _, files in os.walk(pkg):
