@@ -618,3 +618,23 @@ def test_c_abi_standalone_consumer(tmp_path):
     run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0, run.stdout + run.stderr
     assert "cabi smoke ok" in run.stdout
+
+
+def test_slq_value_and_gradient_are_bit_reproducible():
+    """No data-path atomics anywhere (per-slice partials, fixed-order reductions, column-split partials summed in order): two runs of
+    the same SLQ value-and-gradient give identical bits, on the matrix-core path (fp32) and on the VALU path (fp64)."""
+    for dtype, n in ((torch.float32, 4096), (torch.float64, 1500)):
+        g = torch.Generator(device=DEV).manual_seed(3)
+        X = torch.randn((n, 5), generator=g, device=DEV, dtype=dtype)
+        op = gp_util.gram_operator(X, noise_minval=1e-4)
+        integrand = lanczos.integrand_spd(torch.log, 12, op)
+        probes = hutchinson.sampler_rademacher(X[:, 0], num=16)(5)
+        outs = []
+        for _ in range(2):
+            params = [torch.tensor(v, device=DEV, dtype=dtype, requires_grad=True) for v in (0.3, 0.1, -1.0)]
+            vals = integrand(probes, *params)
+            grads = torch.autograd.grad(vals.sum(), params)
+            outs.append((vals.detach().clone(), [t.clone() for t in grads]))
+        assert torch.equal(outs[0][0], outs[1][0])
+        for a, b in zip(outs[0][1], outs[1][1]):
+            assert torch.equal(a, b)
