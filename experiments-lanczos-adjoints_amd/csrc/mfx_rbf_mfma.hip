@@ -887,13 +887,17 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
       //      (PMC: 29 % of the MFMA-busy cycles co-executed with VALU under the two-phase schedule) ----------------------
       half8 ah[2], al[2];
       floatx16 kdn;
-      auto dist = [&](floatx16& kd, int jbx, int mix) {
+      // column-operand fragments of one 32-column block (shared by its two row blocks: one LDS read per column block)
+      half8 ajs[NKD];
+      auto load_a = [&](int jbx) {
+#pragma unroll
+        for (int q = 0; q < NKD; ++q) ajs[q] = *reinterpret_cast<const half8*>(&tl.ajh[jbx * 32 + l31][q * 16 + lhi * 8]);
+      };
+      auto dist = [&](floatx16& kd, int mix) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) kd[r] = 0.f;
 #pragma unroll
-        for (int q = 0; q < NKD; ++q)
-          kd = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(&tl.ajh[jbx * 32 + l31][q * 16 + lhi * 8]),
-                                                      bih[mix][q], kd, 0, 0, 0);
+        for (int q = 0; q < NKD; ++q) kd = __builtin_amdgcn_mfma_f32_32x32x16_f16(ajs[q], bih[mix][q], kd, 0, 0, 0);
       };
       // B fragments (probe tile) of a block are fetched from LDS one block ahead: the ds_read latency in front of the first MFMA
       // of every block was ~10 % of the tile
@@ -911,9 +915,11 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
       constexpr bool kPrefB = PK && (NB == 1 || DPAD <= 8);  // elsewhere the second fragment set does not fit in 256 VGPRs
       if (kPrefB) load_b(0, 0);
       {
+        static_assert(kMI == 2, "block order (jb, mi) = (0,0), (0,1), (1,0), (1,1)");
         floatx16 kd;
-        dist(kd, 0, 0);
-        dist(kdn, 1 / kMI, 1 % kMI);
+        load_a(0);
+        dist(kd, 0);
+        dist(kdn, 1);
 #pragma unroll
         for (int pr = 0; pr < 8; ++pr) exp_split_pair(kd, pr, kDiag, false, ah, al);
       }
@@ -925,13 +931,10 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
         const bool has_next = blk + 1 < 2 * kMI, has_next2 = blk + 2 < 2 * kMI;
         const int jbn = (blk + 1) / kMI, min_ = (blk + 1) % kMI;
         const int jb2 = (blk + 2) / kMI, mi2 = (blk + 2) % kMI;
-        const int cur = kPrefB ? (blk & 1) : 0;
-        if (!kPrefB) load_b(0, jb);
-        half8 aj2[NKD];
-        if (has_next2) {
-#pragma unroll
-          for (int q = 0; q < NKD; ++q) aj2[q] = *reinterpret_cast<const half8*>(&tl.ajh[jb2 * 32 + l31][q * 16 + lhi * 8]);
-        }
+        // the two row blocks of a column block share its probe fragments: one LDS read per column block, not per block
+        const int cur = kPrefB ? (jb & 1) : 0;
+        if (!kPrefB && (mi == 0 || !PK)) load_b(0, jb);  // (the in-kernel-split variants have no registers to keep them)
+        if (has_next2 && mi2 == 0) load_a(jb2);  // blocks (jb2, 0) and (jb2, 1) are issued from blocks blk and blk + 1
         const bool negn = ((jbn + min_) & 1) != 0;
         floatx16 kdn2;
 #pragma unroll
@@ -944,8 +947,8 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
           acc[mi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w == 2 ? al[s] : ah[s], w == 1 ? blb[cur][s][nb] : bhb[cur][s][nb],
                                                                acc[mi][nb], 0, 0, 0);
           if (has_next2 && m >= MD && m - MD < NKD)
-            kdn2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aj2[m - MD], bih[mi2][m - MD], kdn2, 0, 0, 0);
-          if (kPrefB && m == 0 && has_next) load_b(cur ^ 1, jbn);  // next block's fragments: a whole block of latency cover
+            kdn2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ajs[m - MD], bih[mi2][m - MD], kdn2, 0, 0, 0);
+          if (kPrefB && m == 0 && blk == 0 && 2 * kMI > kMI) load_b(1, 1);  // the second column block's fragments, two blocks ahead
           __builtin_amdgcn_sched_barrier(0);
           if (has_next) {
 #pragma unroll
