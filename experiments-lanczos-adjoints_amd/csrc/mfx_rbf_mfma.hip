@@ -594,14 +594,23 @@ constexpr bool kClampRbf = MFX_RBF_CLAMP != 0;
 #endif
 constexpr bool kWideSched = MFX_RBF_WIDE != 0;
 
-// tile of the pipelined kernel: RbfTileH plus the f16 hi/lo image of the distance operand (DH variant)
-template <int DPAD, int NB, int kTJ>
+// async global -> LDS copy of 16 bytes per lane (global_load_lds_dwordx4): the destination is
+// wave-uniform base + lane * 16 (1 KiB per wave-instruction), no staging registers
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// tile of the pipelined kernel: RbfTileH plus the f16 hi/lo image of the distance operand (DH variant).
+// PADROW: the in-kernel split stores 8-byte pieces from many rows at once and needs the row pad; the pre-packed path copies the image
+// by LDS-DMA in 1 KiB pieces and wants [ajh | vhi | vlo] contiguous (the b128 fragment reads are conflict-free either way).
+template <int DPAD, int NB, int kTJ, bool PADROW = true>
 struct RbfTileH3 {
   static constexpr int KD = DPAD + 2;
   static constexpr int NKD = (3 * KD + 15) / 16;  // f16 MFMAs (K = 16) per block for hi.hi + hi.lo + lo.hi
   static constexpr int AROW = NKD * 16 + 8;       // halves per column, padded: conflict-free ds_read_b128
   static constexpr int P = NB * 32;
-  static constexpr int ROW = P * 8 + 8;
+  static constexpr int ROW = P * 8 + (PADROW ? 8 : 0);
   float aj[KD][kTJ];
   _Float16 ajh[kTJ][AROW];
   _Float16 vhi[(kTJ / 32) * 4][ROW];
@@ -639,7 +648,7 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
   // gridDim.z > 1: column split for small n (too few 256-row blocks to fill 256 CUs): workgroup z sweeps its share of the
   // 64-column tiles and writes a partial result to part[z][probe][row]; k_split_reduce adds them in a fixed order.
   constexpr int kMI = 2, kTJ = 64;
-  using Tile = RbfTileH3<DPAD, NB, kTJ>;
+  using Tile = RbfTileH3<DPAD, NB, kTJ, !PK>;
   constexpr int KD = Tile::KD, KS = KD / 2, NKD = Tile::NKD;
   constexpr float cfac = KIND == MFX_KERNEL_RBF ? kNegHalfLog2e : (KIND == MFX_KERNEL_MATERN32 ? 3.f : 1.f) * kLog2e * kLog2e;
   __shared__ __attribute__((aligned(16))) Tile tile[2];
@@ -694,39 +703,26 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
   //      A tile's probe image is 2 x 8 rows x P packs of 16 B (hi rows, then lo rows), its column operand 64 x AROW halves;
   //      staging = plain 16-B copies global -> registers -> LDS, no arithmetic.
   constexpr int kVPK = 2 * 8 * Tile::P;                 // 16-B packs of the probe image per tile
-  constexpr int kVU = (kVPK + 255) / 256;
   constexpr int kAPK = kTJ * Tile::AROW * 2 / 16;       // 16-B packs of the column operand per tile
-  constexpr int kAU = (kAPK + 255) / 256;
-  uintx4 pv[PK ? kVU : 1], pa[PK ? kAU : 1];
+  static_assert(!PK || (kVPK % 64 == 0 && kAPK % 64 == 0), "tile images are whole 1-KiB DMA pieces");
   const int64_t ntile_all = (n + kTJ - 1) / kTJ;
-  auto load_tile_pk = [&](int64_t t) {
-    const uintx4* vsrc = pkv + ((int64_t)blockIdx.y * ntile_all + t) * kVPK;
-    const uintx4* asrc = pka + t * kAPK;
+  // LDS-DMA of tile t's two images straight into the tile buffer: wave w copies the 1-KiB pieces w, w + 4, ...; no staging
+  // registers, no ds_write (less data movement is what still buys time on this power-limited kernel)
+  auto issue_tile_dma = [&](int64_t t, Tile& tl) {
+    const char* vsrc = reinterpret_cast<const char*>(pkv + ((int64_t)blockIdx.y * ntile_all + t) * kVPK);
+    const char* asrc = reinterpret_cast<const char*>(pka + t * kAPK);
+    char* vdst = reinterpret_cast<char*>(&tl.vhi[0][0]);  // vhi and vlo are contiguous (no row pad in this layout)
+    char* adst = reinterpret_cast<char*>(&tl.ajh[0][0]);
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
-    for (int u = 0; u < kVU; ++u) {
-      const int f = tid + 256 * u;
-      if (f < kVPK) pv[u] = vsrc[f];
+    for (int c = 0; c < (kVPK / 64 + 3) / 4; ++c) {
+      const int piece = w + 4 * c;
+      if (piece < kVPK / 64) glds16(vsrc + piece * 1024 + lane * 16, vdst + piece * 1024);
     }
 #pragma unroll
-    for (int u = 0; u < kAU; ++u) {
-      const int f = tid + 256 * u;
-      if (f < kAPK) pa[u] = asrc[f];
-    }
-  };
-  auto store_tile_pk = [&](Tile& tl) {
-#pragma unroll
-    for (int u = 0; u < kVU; ++u) {
-      const int f = tid + 256 * u;
-      if (f < kVPK) {
-        const int lo_half = f / (8 * Tile::P), rowp = f % (8 * Tile::P);
-        _Float16* dst = lo_half ? &tl.vlo[rowp / Tile::P][(rowp % Tile::P) * 8] : &tl.vhi[rowp / Tile::P][(rowp % Tile::P) * 8];
-        *reinterpret_cast<uintx4*>(dst) = pv[u];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < kAU; ++u) {
-      const int f = tid + 256 * u;
-      if (f < kAPK) reinterpret_cast<uintx4*>(&tl.ajh[0][0])[f] = pa[u];
+    for (int c = 0; c < (kAPK / 64 + 3) / 4; ++c) {
+      const int piece = w + 4 * c;
+      if (piece < kAPK / 64) glds16(asrc + piece * 1024 + lane * 16, adst + piece * 1024);
     }
   };
 
@@ -865,8 +861,7 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
   const int64_t ntile_tot = (n + kTJ - 1) / kTJ;
   const int64_t t_first = ntile_tot * blockIdx.z / gridDim.z, ntile = ntile_tot * (blockIdx.z + 1) / gridDim.z;
   if constexpr (PK) {
-    load_tile_pk(t_first);
-    store_tile_pk(tile[t_first & 1]);
+    issue_tile_dma(t_first, tile[t_first & 1]);
   } else {
     load_tile(t_first * kTJ);
     store_tile(tile[t_first & 1]);
@@ -875,7 +870,8 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
   for (int64_t t = t_first; t < ntile; ++t) {
     const Tile& tl = tile[t & 1];
     if (t + 1 < ntile) {
-      if constexpr (PK) load_tile_pk(t + 1); else load_tile((t + 1) * kTJ);
+      // (PK) the other buffer was last read during tile t - 1, and every wave has passed the barrier that ended it
+      if constexpr (PK) issue_tile_dma(t + 1, tile[(t + 1) & 1]); else load_tile((t + 1) * kTJ);
     }
     // the one tile whose 64 columns are this wave's 64 rows holds the diagonal: only there (and only for the Matern
     // kernels) the per-entry self-distance fix is compiled in -- two copies of the tile body, chosen wave-uniformly
@@ -1071,9 +1067,9 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
       do_tile(std::false_type{});
     }
     if (t + 1 < ntile) {
-      if constexpr (PK) store_tile_pk(tile[(t + 1) & 1]); else store_tile(tile[(t + 1) & 1]);
+      if constexpr (!PK) store_tile(tile[(t + 1) & 1]);
     }
-    __syncthreads();
+    __syncthreads();  // (also drains the LDS-DMA: vmcnt(0))
   }
   const float s = outputscale[0], nz = gridDim.z > 1 ? 0.f : noise[0];
   float* yout = gridDim.z > 1 ? part + (int64_t)blockIdx.z * p * ldy : y;
@@ -1386,12 +1382,6 @@ struct GradSmemH {
   double red[4][DPAD + 2];
 };
 
-// async global -> LDS copy of 16 bytes per lane (global_load_lds_dwordx4): the destination is
-// wave-uniform base + lane * 16, which is exactly the [kb][column][8 halves] stage layout
-__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
 
 // The f16 MFMA truncates its internal sum towards -infinity: a bias of a fraction of an ulp per MFMA, invisible in
 // any single accumulator but COHERENT across all n^2 accumulators of S, and the gradient sum_ij S_ij dK_ij/dtheta
