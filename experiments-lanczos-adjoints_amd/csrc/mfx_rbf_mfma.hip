@@ -631,8 +631,15 @@ struct RbfTileH3 {
 // truncates its internal sum (tools/mfma_f16_rounding.hip: up to -1.75 ulp, biased), which is harmless in
 // the sign-mixed contraction but showed up as a 5x larger gradient error when used for the exponent.
 // ================================================================================================
+// waves per workgroup: the pre-packed variant runs 8 waves (512 rows) on ONE staged tile -- the same two waves per SIMD as two
+// 4-wave workgroups, but half the L2 -> LDS traffic and half the LDS tile copies
+template <bool PK>
+struct H3Waves {
+  static constexpr int value = PK ? 8 : 4;
+};
+
 template <int DPAD, int NB, bool VEC4, int KIND, bool DH, bool PK>
-__global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __restrict__ xs, const float* __restrict__ sq,
+__global__ __launch_bounds__(64 * H3Waves<PK>::value, PK ? 1 : 2) void k_rbf_mfma_apply_h3(const float* __restrict__ xs, const float* __restrict__ sq,
                                                               int64_t n, const float* __restrict__ outputscale,
                                                               const float* __restrict__ noise,
                                                               const float* __restrict__ vscale,
@@ -654,7 +661,8 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
   __shared__ __attribute__((aligned(16))) Tile tile[2];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
-  const int64_t i_wave = (int64_t)blockIdx.x * (4 * kMI * 32) + (int64_t)wid * (kMI * 32);
+  constexpr int WV = H3Waves<PK>::value;
+  const int64_t i_wave = (int64_t)blockIdx.x * (WV * kMI * 32) + (int64_t)wid * (kMI * 32);
   const int64_t b0 = (int64_t)blockIdx.y * (NB * 32);
 
   // B operand of the distance product, resident in registers: [x_i, 1, |x_i|^2].
@@ -706,7 +714,7 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
   constexpr int kAPK = kTJ * Tile::AROW * 2 / 16;       // 16-B packs of the column operand per tile
   static_assert(!PK || (kVPK % 64 == 0 && kAPK % 64 == 0), "tile images are whole 1-KiB DMA pieces");
   const int64_t ntile_all = (n + kTJ - 1) / kTJ;
-  // LDS-DMA of tile t's two images straight into the tile buffer: wave w copies the 1-KiB pieces w, w + 4, ...; no staging
+  // LDS-DMA of tile t's two images straight into the tile buffer: wave w copies the 1-KiB pieces w, w + WV, ...; no staging
   // registers, no ds_write (less data movement is what still buys time on this power-limited kernel)
   auto issue_tile_dma = [&](int64_t t, Tile& tl) {
     const char* vsrc = reinterpret_cast<const char*>(pkv + ((int64_t)blockIdx.y * ntile_all + t) * kVPK);
@@ -715,13 +723,13 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h3(const float* __res
     char* adst = reinterpret_cast<char*>(&tl.ajh[0][0]);
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
-    for (int c = 0; c < (kVPK / 64 + 3) / 4; ++c) {
-      const int piece = w + 4 * c;
+    for (int c = 0; c < (kVPK / 64 + WV - 1) / WV; ++c) {
+      const int piece = w + WV * c;
       if (piece < kVPK / 64) glds16(vsrc + piece * 1024 + lane * 16, vdst + piece * 1024);
     }
 #pragma unroll
-    for (int c = 0; c < (kAPK / 64 + 3) / 4; ++c) {
-      const int piece = w + 4 * c;
+    for (int c = 0; c < (kAPK / 64 + WV - 1) / WV; ++c) {
+      const int piece = w + WV * c;
       if (piece < kAPK / 64) glds16(asrc + piece * 1024 + lane * 16, adst + piece * 1024);
     }
   };
@@ -1180,12 +1188,14 @@ __global__ __launch_bounds__(256) void k_pack_tiles(const float* __restrict__ xs
 
 // column splits of the pipelined matvec: enough workgroups for two per CU, at least 8 tiles each, at most 8 splits
 static int rbf_split_count(int64_t n, int64_t p) {
-  const int64_t wgs = ((n + 255) / 256) * ((p + (p <= 32 ? 32 : 64) - 1) / (p <= 32 ? 32 : 64));
-  if (wgs >= 384) return 1;
-  int64_t s = (512 + wgs - 1) / wgs;
+  // 512-row workgroups of 8 waves, one per CU: as many column splits as still fit ONE round of 256 workgroups (a second,
+  // nearly empty round costs more than a slightly under-filled first one), at least 8 tiles per split, at most 16 splits
+  const int64_t wgs = ((n + 511) / 512) * ((p + (p <= 32 ? 32 : 64) - 1) / (p <= 32 ? 32 : 64));
+  if (wgs >= 192) return 1;
+  int64_t s = 256 / wgs;
   const int64_t max_by_tiles = ((n + 63) / 64) / 8;
   if (s > max_by_tiles) s = max_by_tiles;
-  if (s > 8) s = 8;
+  if (s > 16) s = 16;
   return s < 1 ? 1 : (int)s;
 }
 
@@ -1228,7 +1238,7 @@ static int launch_apply_h3k(const mfx_operator* op, const float* xs, const float
   const int64_t n = op->n;
   MFX_TRY(row_scales(x, ldx, n, p, vscale, stream));
   const unsigned chunks = (unsigned)((p + NB * 32 - 1) / (NB * 32));
-  const dim3 grid((unsigned)((n + 255) / 256), chunks);
+  const dim3 grid((unsigned)((n + 255) / 256), chunks);  // 4-wave workgroups (256 rows); the pre-packed variant uses grid_pk
   const bool vec4 = (n % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) &&
                     (reinterpret_cast<uintptr_t>(y) % 16 == 0);
   const bool pack = rbf_dist_f16() && rbf_prepack() && pk != nullptr;
@@ -1240,6 +1250,7 @@ static int launch_apply_h3k(const mfx_operator* op, const float* xs, const float
   float* part = pk ? reinterpret_cast<float*>(static_cast<char*>(pk) + off_a + align_up(ntile * 64 * arow * 2, 256)) : nullptr;
   const int nsplit = (part && ldy % 4 == 0 && ldy == align_up(n, 4)) ? rbf_split_count(n, p) : 1;
   const dim3 grid3(grid.x, grid.y, (unsigned)nsplit);
+  const dim3 grid_pk((unsigned)((n + 511) / 512), grid.y, (unsigned)nsplit);
   int* rangeflag = reinterpret_cast<int*>(vscale + 3 * p);  // zeroed by row_scales
   if (pack) {
     pkv = static_cast<uintx4*>(pk);
@@ -1248,7 +1259,7 @@ static int launch_apply_h3k(const mfx_operator* op, const float* xs, const float
     MFX_CHECK_LAUNCH();
   }
 #define MFX_H3_LAUNCH(V4, DHV, PKV, FLAG)                                                                            \
-  k_rbf_mfma_apply_h3<DPAD, NB, V4, KIND, DHV, PKV><<<grid3, 256, 0, stream>>>(xs, sq, n, (const float*)op->outputscale, \
+  k_rbf_mfma_apply_h3<DPAD, NB, V4, KIND, DHV, PKV><<<(PKV) ? grid_pk : grid3, 64 * H3Waves<PKV>::value, 0, stream>>>(xs, sq, n, (const float*)op->outputscale, \
                                                                                 (const float*)op->noise, vscale, x, ldx, y, ldy, p, pkv, pka, part, FLAG)
   if (pack) {
     if (vec4) MFX_H3_LAUNCH(true, true, true, rangeflag); else MFX_H3_LAUNCH(false, true, true, rangeflag);
