@@ -1379,10 +1379,10 @@ template <int DPAD>
 struct GradSmemH {
   union {
     struct {
-      _Float16 a_hi[2][4][kGM][8];  // [stage][kb within stage][i][8]
-      _Float16 a_lo[2][4][kGM][8];
-      _Float16 b_hi[2][4][kGN][8];
-      _Float16 b_lo[2][4][kGN][8];
+      _Float16 a_hi[4][2][kGM][8];  // [ring slot][kb within the 16-row stage][i][8]
+      _Float16 a_lo[4][2][kGM][8];
+      _Float16 b_hi[4][2][kGN][8];
+      _Float16 b_lo[4][2][kGN][8];
     } st;
     float s_t[kGN][kGLd];
   } u;
@@ -1437,29 +1437,25 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_grad_h(const float* __restr
   // at byte 16 c of its piece: wave w copies chunks [64 w + 256 u, +64), u = 0, 1 -- no staging registers.
   // Addresses are 32-bit byte offsets from the (scalar) piece bases, advanced by one constant per stage: the 64-bit
   // per-stage address arithmetic was a quarter of this kernel's VALU instructions, and VALU time adds to MFMA time.
-  const int64_t nstage = nkb / 4;
-  const uint32_t stage_bytes = (uint32_t)(4 * npad * 16);  // 4 kb-groups of npad columns x 8 halves
-  uint32_t offL[2], offR0[2];
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int c = tid + 256 * u;
-    offL[u] = (uint32_t)((((int64_t)(c >> 7) * npad) + i0 + (c & 127)) * 16);
-    offR0[u] = (uint32_t)((((int64_t)(c >> 7) * npad) + (c & 127)) * 16);
-  }
+  // Ring of FOUR 16-row stages (2 kb-groups x 128 columns x 16 B per operand piece = 256 chunks: one glds per thread and
+  // piece), three of them in flight: a stage's DMA has three stages of MFMAs (>= 1100 cycles) to land, where the two-buffer
+  // scheme of 32-row stages gave it one -- and its barrier waited for the L2/MALL latency every stage (SQ_WAIT_ANY 26 %).
+  // Per stage: wait for MY pieces of stage st (counted vmcnt: the later stages stay in flight), barrier (everybody's pieces
+  // landed AND everybody is done reading stage st - 1), refill the slot of stage st - 1 with stage st + 3, compute.
+  const int64_t nstage = nkb / 2;
+  const uint32_t stage_bytes = (uint32_t)(2 * npad * 16);  // 2 kb-groups of npad columns x 8 halves
+  const uint32_t offL = (uint32_t)((((int64_t)(tid >> 7) * npad) + i0 + (tid & 127)) * 16);
+  const uint32_t offR0 = (uint32_t)((((int64_t)(tid >> 7) * npad) + (tid & 127)) * 16);
   const char* Lhb = reinterpret_cast<const char*>(Lh);
   const char* Llb = reinterpret_cast<const char*>(Ll);
   const char* Rhb = reinterpret_cast<const char*>(Rh);
   const char* Rlb = reinterpret_cast<const char*>(Rl);
-  auto issue_stage = [&](uint32_t l_off0, uint32_t l_off1, uint32_t r_off0, uint32_t r_off1, int buf) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int cw = wid * 64 + 256 * u;  // first chunk of this wave-instruction (wave-uniform)
-      const uint32_t lo_ = u ? l_off1 : l_off0, ro_ = u ? r_off1 : r_off0;
-      glds16(Lhb + lo_, &sm.u.st.a_hi[buf][cw >> 7][cw & 127][0]);
-      glds16(Llb + lo_, &sm.u.st.a_lo[buf][cw >> 7][cw & 127][0]);
-      glds16(Rhb + ro_, &sm.u.st.b_hi[buf][cw >> 7][cw & 127][0]);
-      glds16(Rlb + ro_, &sm.u.st.b_lo[buf][cw >> 7][cw & 127][0]);
-    }
+  const int cw = wid * 64;  // first chunk of this wave's instruction (wave-uniform): kb-group cw >> 7, column cw & 127
+  auto issue_stage = [&](uint32_t l_off, uint32_t r_off, int slot) {
+    glds16(Lhb + l_off, &sm.u.st.a_hi[slot][cw >> 7][cw & 127][0]);
+    glds16(Llb + l_off, &sm.u.st.a_lo[slot][cw >> 7][cw & 127][0]);
+    glds16(Rhb + r_off, &sm.u.st.b_hi[slot][cw >> 7][cw & 127][0]);
+    glds16(Rlb + r_off, &sm.u.st.b_lo[slot][cw >> 7][cw & 127][0]);
   };
 
   for (int64_t tj = tj_begin; tj < tj_end; ++tj) {
@@ -1475,27 +1471,40 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_grad_h(const float* __restr
           master[a][b][r] = 0.f;
         }
 
-    uint32_t ol0 = offL[0], ol1 = offL[1];
-    uint32_t or0 = offR0[0] + (uint32_t)(j0 * 16), or1 = offR0[1] + (uint32_t)(j0 * 16);
+    uint32_t ol = offL, orr = offR0 + (uint32_t)(j0 * 16);
     __syncthreads();  // previous tile's epilogue reads of the overlaid S^T tile are done
-    issue_stage(ol0, ol1, or0, or1, 0);
-    __syncthreads();  // (drains the LDS-DMA: __syncthreads waits vmcnt(0))
-    for (int64_t st = 0; st < nstage; ++st) {
-      const int cur = (int)(st & 1);
-      ol0 += stage_bytes; ol1 += stage_bytes; or0 += stage_bytes; or1 += stage_bytes;
-      if (st + 1 < nstage) issue_stage(ol0, ol1, or0, or1, cur ^ 1);
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {  // two 16-deep k-steps per stage: kb-groups 2 ks + lhi
+    for (int q = 0; q < 3; ++q) {
+      if (q < nstage) issue_stage(ol, orr, q);
+      ol += stage_bytes;
+      orr += stage_bytes;
+    }
+    for (int64_t st = 0; st < nstage; ++st) {
+      const int slot = (int)(st & 3);
+      // 4 glds per stage and thread; stages st + 1, st + 2 may stay in flight
+      const int64_t later = nstage - 1 - st;
+      if (later >= 2) {
+        __builtin_amdgcn_s_waitcnt(0x0F78);  // vmcnt(8)
+      } else if (later == 1) {
+        __builtin_amdgcn_s_waitcnt(0x0F74);  // vmcnt(4)
+      } else {
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+      }
+      __builtin_amdgcn_s_barrier();
+      if (st + 3 < nstage) issue_stage(ol, orr, (int)((st + 3) & 3));
+      ol += stage_bytes;
+      orr += stage_bytes;
+      {
         half8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-          ah[a] = *reinterpret_cast<const half8*>(&sm.u.st.a_hi[cur][2 * ks + lhi][wm * 64 + a * 32 + l31][0]);
-          al[a] = *reinterpret_cast<const half8*>(&sm.u.st.a_lo[cur][2 * ks + lhi][wm * 64 + a * 32 + l31][0]);
+          ah[a] = *reinterpret_cast<const half8*>(&sm.u.st.a_hi[slot][lhi][wm * 64 + a * 32 + l31][0]);
+          al[a] = *reinterpret_cast<const half8*>(&sm.u.st.a_lo[slot][lhi][wm * 64 + a * 32 + l31][0]);
         }
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-          bh[b] = *reinterpret_cast<const half8*>(&sm.u.st.b_hi[cur][2 * ks + lhi][wn * 64 + b * 32 + l31][0]);
-          bl[b] = *reinterpret_cast<const half8*>(&sm.u.st.b_lo[cur][2 * ks + lhi][wn * 64 + b * 32 + l31][0]);
+          bh[b] = *reinterpret_cast<const half8*>(&sm.u.st.b_hi[slot][lhi][wn * 64 + b * 32 + l31][0]);
+          bl[b] = *reinterpret_cast<const half8*>(&sm.u.st.b_lo[slot][lhi][wn * 64 + b * 32 + l31][0]);
         }
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -1506,8 +1515,9 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_grad_h(const float* __restr
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
           }
       }
-      if ((st % kGChunk) == kGChunk - 1 || st + 1 == nstage) {
-        const float sgn = ((st / kGChunk) & 1) ? -1.f : 1.f;  // odd chunks hold -L
+      constexpr int kFold = 2 * kGChunk;  // 16-row stages per sign chunk
+      if ((st % kFold) == kFold - 1 || st + 1 == nstage) {
+        const float sgn = ((st / kFold) & 1) ? -1.f : 1.f;  // odd chunks hold -L
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -1518,8 +1528,8 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_grad_h(const float* __restr
               acc[a][b][r] = 0.f;
             }
       }
-      __syncthreads();
     }
+    __syncthreads();  // all waves are done with the ring before the S^T overlay is written
     // ---- epilogue (as in k_rbf_mfma_grad) -------------------------------------------------------
 #pragma unroll
     for (int b = 0; b < 2; ++b)
