@@ -646,7 +646,8 @@ __global__ __launch_bounds__(64 * H3Waves<PK>::value, PK ? 1 : 2) void k_rbf_mfm
                                                               const float* __restrict__ x, int64_t ldx,
                                                               float* __restrict__ y, int64_t ldy, int64_t p,
                                                               const uintx4* __restrict__ pkv, const uintx4* __restrict__ pka,
-                                                              float* __restrict__ part, const int* __restrict__ rangeflag) {
+                                                              float* __restrict__ part, const int* __restrict__ rangeflag,
+                                                              int64_t ldpart) {
   static_assert(!PK || DH, "pre-packed operands exist for the f16-distance variant only");
   // f16 range guard: when a scaled input is too large for the f16 image of the distance operands (|x/l|^2 beyond ~6e4 / |c|),
   // k_pack_tiles raises the flag; the f16-distance launch then returns at once and the fp32-distance launch behind it does
@@ -1080,7 +1081,8 @@ __global__ __launch_bounds__(64 * H3Waves<PK>::value, PK ? 1 : 2) void k_rbf_mfm
     __syncthreads();  // (also drains the LDS-DMA: vmcnt(0))
   }
   const float s = outputscale[0], nz = gridDim.z > 1 ? 0.f : noise[0];
-  float* yout = gridDim.z > 1 ? part + (int64_t)blockIdx.z * p * ldy : y;
+  float* yout = gridDim.z > 1 ? part + (int64_t)blockIdx.z * p * ldpart : y;
+  const int64_t ldo = gridDim.z > 1 ? ldpart : ldy;
 #pragma unroll
   for (int mi = 0; mi < kMI; ++mi)
 #pragma unroll
@@ -1098,24 +1100,24 @@ __global__ __launch_bounds__(64 * H3Waves<PK>::value, PK ? 1 : 2) void k_rbf_mfm
           o.y = fmaf(sb, acc[mi][nb][4 * g + 1], nz * xv.y);
           o.z = fmaf(sb, acc[mi][nb][4 * g + 2], nz * xv.z);
           o.w = fmaf(sb, acc[mi][nb][4 * g + 3], nz * xv.w);
-          *reinterpret_cast<float4*>(yout + b * ldy + i) = o;
+          *reinterpret_cast<float4*>(yout + b * ldo + i) = o;
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            if (i + e < n) yout[b * ldy + i + e] = fmaf(sb, acc[mi][nb][4 * g + e], nz * x[b * ldx + i + e]);
+            if (i + e < n) yout[b * ldo + i + e] = fmaf(sb, acc[mi][nb][4 * g + e], nz * x[b * ldx + i + e]);
         }
       }
     }
 }
 
 // y = sum_z part[z] + noise x   (fixed summation order: deterministic)
-__global__ __launch_bounds__(256) void k_split_reduce(const float* __restrict__ part, int nsplit, int64_t p, int64_t n,
-                                                      int64_t ldy, const float* __restrict__ noise,
+__global__ __launch_bounds__(256) void k_split_reduce(const float* __restrict__ part, int64_t ldpart, int nsplit, int64_t p,
+                                                      int64_t n, int64_t ldy, const float* __restrict__ noise,
                                                       const float* __restrict__ x, int64_t ldx, float* __restrict__ y) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
   if (i >= n) return;
   float acc = 0.f;
-  for (int z = 0; z < nsplit; ++z) acc += part[((int64_t)z * p + b) * ldy + i];
+  for (int z = 0; z < nsplit; ++z) acc += part[((int64_t)z * p + b) * ldpart + i];
   y[b * ldy + i] = fmaf(noise[0], x[b * ldx + i], acc);
 }
 
@@ -1188,15 +1190,30 @@ __global__ __launch_bounds__(256) void k_pack_tiles(const float* __restrict__ xs
 
 // column splits of the pipelined matvec: enough workgroups for two per CU, at least 8 tiles each, at most 8 splits
 static int rbf_split_count(int64_t n, int64_t p) {
-  // 512-row workgroups of 8 waves, one per CU: as many column splits as still fit ONE round of 256 workgroups (a second,
-  // nearly empty round costs more than a slightly under-filled first one), at least 8 tiles per split, at most 16 splits
+  // 512-row workgroups of 8 waves, one per CU and round.  With s column splits the launch takes ceil(wgs s / 256) rounds of 1/s of the
+  // columns each: pick the s (at most 16, at least 8 tiles per split) that minimises rounds / s, plus a small charge per split for the
+  // prologue and the partial sums.  (n = 45 730: 90 row blocks -> s = 8, 720 workgroups in 3 rounds = 0.375 of an unsplit launch,
+  // where "fill one round" (s = 2) gives 0.5.)
+  static const int forced = [] {
+    const char* e = getenv("MFX_RBF_SPLIT");  // A/B: force the split count
+    return e ? atoi(e) : 0;
+  }();
   const int64_t wgs = ((n + 511) / 512) * ((p + (p <= 32 ? 32 : 64) - 1) / (p <= 32 ? 32 : 64));
-  if (wgs >= 192) return 1;
-  int64_t s = 256 / wgs;
-  const int64_t max_by_tiles = ((n + 63) / 64) / 8;
-  if (s > max_by_tiles) s = max_by_tiles;
-  if (s > 16) s = 16;
-  return s < 1 ? 1 : (int)s;
+  int64_t smax = ((n + 63) / 64) / 8;
+  if (forced > 0) return forced <= 16 && forced <= (n + 63) / 64 ? forced : 1;
+  if (smax > 16) smax = 16;
+  if (smax < 1 || wgs >= 2048) return 1;
+  int best = 1;
+  double best_cost = 1e30;
+  for (int s = 1; s <= (int)smax; ++s) {
+    const double rounds = (double)((wgs * s + 255) / 256);
+    const double cost = rounds / s + 0.004 * s;
+    if (cost < best_cost - 1e-12) {
+      best_cost = cost;
+      best = s;
+    }
+  }
+  return best;
 }
 
 static int64_t rbf_pack_bytes_v(int64_t n, int64_t p) {
@@ -1248,7 +1265,8 @@ static int launch_apply_h3k(const mfx_operator* op, const float* xs, const float
   const int64_t off_a = align_up((int64_t)chunks * ntile * 2 * 8 * NB * 32 * 16, 256);
   const int64_t arow = ((3 * (DPAD + 2) + 15) / 16) * 16 + 8;
   float* part = pk ? reinterpret_cast<float*>(static_cast<char*>(pk) + off_a + align_up(ntile * 64 * arow * 2, 256)) : nullptr;
-  const int nsplit = (part && ldy % 4 == 0 && ldy == align_up(n, 4)) ? rbf_split_count(n, p) : 1;
+  const int64_t ldpart = align_up(n, 4);  // the partials have their own stride (any n, any ldy)
+  const int nsplit = part ? rbf_split_count(n, p) : 1;
   const dim3 grid3(grid.x, grid.y, (unsigned)nsplit);
   const dim3 grid_pk((unsigned)((n + 511) / 512), grid.y, (unsigned)nsplit);
   int* rangeflag = reinterpret_cast<int*>(vscale + 3 * p);  // zeroed by row_scales
@@ -1260,7 +1278,7 @@ static int launch_apply_h3k(const mfx_operator* op, const float* xs, const float
   }
 #define MFX_H3_LAUNCH(V4, DHV, PKV, FLAG)                                                                            \
   k_rbf_mfma_apply_h3<DPAD, NB, V4, KIND, DHV, PKV><<<(PKV) ? grid_pk : grid3, 64 * H3Waves<PKV>::value, 0, stream>>>(xs, sq, n, (const float*)op->outputscale, \
-                                                                                (const float*)op->noise, vscale, x, ldx, y, ldy, p, pkv, pka, part, FLAG)
+                                                                                (const float*)op->noise, vscale, x, ldx, y, ldy, p, pkv, pka, part, FLAG, ldpart)
   if (pack) {
     if (vec4) MFX_H3_LAUNCH(true, true, true, rangeflag); else MFX_H3_LAUNCH(false, true, true, rangeflag);
     if (vec4) MFX_H3_LAUNCH(true, false, false, rangeflag); else MFX_H3_LAUNCH(false, false, false, rangeflag);  // runs only if flagged
@@ -1272,8 +1290,8 @@ static int launch_apply_h3k(const mfx_operator* op, const float* xs, const float
 #undef MFX_H3_LAUNCH
   MFX_CHECK_LAUNCH();
   if (nsplit > 1) {
-    k_split_reduce<<<dim3((unsigned)((n + 255) / 256), (unsigned)p), 256, 0, stream>>>(part, nsplit, p, n, ldy, (const float*)op->noise,
-                                                                                     x, ldx, y);
+    k_split_reduce<<<dim3((unsigned)((n + 255) / 256), (unsigned)p), 256, 0, stream>>>(part, ldpart, nsplit, p, n, ldy,
+                                                                                     (const float*)op->noise, x, ldx, y);
     MFX_CHECK_LAUNCH();
   }
   return MFX_OK;
