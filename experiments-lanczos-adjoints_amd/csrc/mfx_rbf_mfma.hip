@@ -1393,22 +1393,27 @@ __global__ __launch_bounds__(256) void k_pack_f16(const float* __restrict__ x, i
   *reinterpret_cast<half8*>(lo + (kb * npad + i) * 8) = l;
 }
 
+// rows per workgroup tile of the split gradient GEMM: 8 waves (4 x 2 of 64 x 64) on ONE staged tile pair -- the same two waves per
+// SIMD as two 128 x 128 workgroups, but (256 + 128) instead of 2 x (128 + 128) operand columns through L2 -> LDS per stage
+constexpr int kHM = 256;
+constexpr int kHLd = kHM + 4;
+
 template <int DPAD>
 struct GradSmemH {
   union {
     struct {
-      _Float16 a_hi[4][2][kGM][8];  // [ring slot][kb within the 16-row stage][i][8]
-      _Float16 a_lo[4][2][kGM][8];
+      _Float16 a_hi[4][2][kHM][8];  // [ring slot][kb within the 16-row stage][i][8]
+      _Float16 a_lo[4][2][kHM][8];
       _Float16 b_hi[4][2][kGN][8];
       _Float16 b_lo[4][2][kGN][8];
     } st;
-    float s_t[kGN][kGLd];
+    float s_t[kGN][kHLd];
   } u;
-  float xi[kGM][DPAD];
-  float sqi[kGM];
+  float xi[kHM][DPAD];
+  float sqi[kHM];
   float xj[kGN][DPAD];
   float sqj[kGN];
-  double red[4][DPAD + 2];
+  double red[8][DPAD + 2];
 };
 
 
@@ -1421,7 +1426,7 @@ struct GradSmemH {
 constexpr int kGChunk = 8;
 
 template <int DPAD>
-__global__ __launch_bounds__(256, 2) void k_rbf_mfma_grad_h(const float* __restrict__ xs, const float* __restrict__ sq,
+__global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restrict__ xs, const float* __restrict__ sq,
                                                             int64_t n, int64_t npad, int ard, int kind,
                                                             const _Float16* __restrict__ Lh, const _Float16* __restrict__ Ll,
                                                             const _Float16* __restrict__ Rh, const _Float16* __restrict__ Rl,
@@ -1435,17 +1440,17 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_grad_h(const float* __restr
   const int wm = wid >> 1, wn = wid & 1;
   // blockIdx.x = XCD label (workgroups are dealt to XCDs round-robin in linear order); within an XCD, blockIdx.y
   // enumerates (row block, column sub-range) with the sub-range fastest, see kGSub
-  const int64_t i0 = (int64_t)(blockIdx.y / kGSub) * kGM;
+  const int64_t i0 = (int64_t)(blockIdx.y / kGSub) * kHM;
   const int64_t ntj = (n + kGN - 1) / kGN;
   const int64_t tj_begin = ((int64_t)blockIdx.x * kGSub + blockIdx.y % kGSub) * tiles_per_block;
   int64_t tj_end = tj_begin + tiles_per_block;
   if (tj_end > ntj) tj_end = ntj;
 
-  for (int t = tid; t < kGM * DPAD; t += 256) {
+  for (int t = tid; t < kHM * DPAD; t += 512) {
     const int64_t g = i0 * DPAD + t;
     (&sm.xi[0][0])[t] = g < n * DPAD ? xs[g] : 0.f;
   }
-  if (tid < kGM) sm.sqi[tid] = (i0 + tid < n) ? sq[i0 + tid] : 0.f;
+  if (tid < kHM) sm.sqi[tid] = (i0 + tid < n) ? sq[i0 + tid] : 0.f;
 
   double gsum[DPAD + 2];
 #pragma unroll
@@ -1455,25 +1460,26 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_grad_h(const float* __restr
   // at byte 16 c of its piece: wave w copies chunks [64 w + 256 u, +64), u = 0, 1 -- no staging registers.
   // Addresses are 32-bit byte offsets from the (scalar) piece bases, advanced by one constant per stage: the 64-bit
   // per-stage address arithmetic was a quarter of this kernel's VALU instructions, and VALU time adds to MFMA time.
-  // Ring of FOUR 16-row stages (2 kb-groups x 128 columns x 16 B per operand piece = 256 chunks: one glds per thread and
-  // piece), three of them in flight: a stage's DMA has three stages of MFMAs (>= 1100 cycles) to land, where the two-buffer
-  // scheme of 32-row stages gave it one -- and its barrier waited for the L2/MALL latency every stage (SQ_WAIT_ANY 26 %).
-  // Per stage: wait for MY pieces of stage st (counted vmcnt: the later stages stay in flight), barrier (everybody's pieces
-  // landed AND everybody is done reading stage st - 1), refill the slot of stage st - 1 with stage st + 3, compute.
+  // Ring of FOUR 16-row stages, three of them in flight: a stage's DMA has three stages of MFMAs (>= 1100 cycles) to land, where
+  // the two-buffer scheme of 32-row stages gave it one -- and its barrier waited for the L2/MALL latency every stage (SQ_WAIT_ANY
+  // 26 %).  Per stage: wait for MY pieces of stage st (counted vmcnt: the later stages stay in flight), barrier (everybody's
+  // pieces landed AND everybody is done reading stage st - 1), refill the slot of stage st - 1 with stage st + 3, compute.
+  // Pieces per stage (1 KiB = one wave-instruction): L hi / lo 2 kb-groups x 256 columns = 8 each, R hi / lo 2 x 128 = 4 each;
+  // wave w copies L-hi piece w, L-lo piece w and one R piece (waves 0-3: hi, 4-7: lo): 3 glds per thread and stage.
   const int64_t nstage = nkb / 2;
   const uint32_t stage_bytes = (uint32_t)(2 * npad * 16);  // 2 kb-groups of npad columns x 8 halves
-  const uint32_t offL = (uint32_t)((((int64_t)(tid >> 7) * npad) + i0 + (tid & 127)) * 16);
-  const uint32_t offR0 = (uint32_t)((((int64_t)(tid >> 7) * npad) + (tid & 127)) * 16);
+  const int cwa = wid * 64 + lane;                          // my chunk of an L piece: kb-group cwa >> 8, column cwa & 255
+  const int cwb = (wid & 3) * 64 + lane;                    // my chunk of an R piece: kb-group cwb >> 7, column cwb & 127
+  const uint32_t offL = (uint32_t)((((int64_t)(cwa >> 8) * npad) + i0 + (cwa & 255)) * 16);
+  const uint32_t offR0 = (uint32_t)((((int64_t)(cwb >> 7) * npad) + (cwb & 127)) * 16);
   const char* Lhb = reinterpret_cast<const char*>(Lh);
   const char* Llb = reinterpret_cast<const char*>(Ll);
-  const char* Rhb = reinterpret_cast<const char*>(Rh);
-  const char* Rlb = reinterpret_cast<const char*>(Rl);
-  const int cw = wid * 64;  // first chunk of this wave's instruction (wave-uniform): kb-group cw >> 7, column cw & 127
+  const char* Rxb = reinterpret_cast<const char*>(wid < 4 ? Rh : Rl);
+  const int ca = wid * 64, cb = (wid & 3) * 64;  // first chunks of this wave's instructions (wave-uniform)
   auto issue_stage = [&](uint32_t l_off, uint32_t r_off, int slot) {
-    glds16(Lhb + l_off, &sm.u.st.a_hi[slot][cw >> 7][cw & 127][0]);
-    glds16(Llb + l_off, &sm.u.st.a_lo[slot][cw >> 7][cw & 127][0]);
-    glds16(Rhb + r_off, &sm.u.st.b_hi[slot][cw >> 7][cw & 127][0]);
-    glds16(Rlb + r_off, &sm.u.st.b_lo[slot][cw >> 7][cw & 127][0]);
+    glds16(Lhb + l_off, &sm.u.st.a_hi[slot][ca >> 8][ca & 255][0]);
+    glds16(Llb + l_off, &sm.u.st.a_lo[slot][ca >> 8][ca & 255][0]);
+    glds16(Rxb + r_off, wid < 4 ? &sm.u.st.b_hi[slot][cb >> 7][cb & 127][0] : &sm.u.st.b_lo[slot][cb >> 7][cb & 127][0]);
   };
 
   for (int64_t tj = tj_begin; tj < tj_end; ++tj) {
@@ -1499,12 +1505,12 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_grad_h(const float* __restr
     }
     for (int64_t st = 0; st < nstage; ++st) {
       const int slot = (int)(st & 3);
-      // 4 glds per stage and thread; stages st + 1, st + 2 may stay in flight
+      // 3 glds per stage and thread; stages st + 1, st + 2 may stay in flight
       const int64_t later = nstage - 1 - st;
       if (later >= 2) {
-        __builtin_amdgcn_s_waitcnt(0x0F78);  // vmcnt(8)
+        __builtin_amdgcn_s_waitcnt(0x0F76);  // vmcnt(6)
       } else if (later == 1) {
-        __builtin_amdgcn_s_waitcnt(0x0F74);  // vmcnt(4)
+        __builtin_amdgcn_s_waitcnt(0x0F73);  // vmcnt(3)
       } else {
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
       }
@@ -1559,14 +1565,14 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_grad_h(const float* __restr
           q.x = master[a][b][4 * g + 0]; q.y = master[a][b][4 * g + 1]; q.z = master[a][b][4 * g + 2]; q.w = master[a][b][4 * g + 3];
           *reinterpret_cast<float4*>(&sm.u.s_t[wn * 64 + b * 32 + l31][wm * 64 + a * 32 + 8 * g + 4 * lhi]) = q;
         }
-    for (int t = tid; t < kGN * DPAD; t += 256) {
+    for (int t = tid; t < kGN * DPAD; t += 512) {
       const int64_t g = j0 * DPAD + t;
       (&sm.xj[0][0])[t] = g < n * DPAD ? xs[g] : 0.f;
     }
     if (tid < kGN) sm.sqj[tid] = (j0 + tid < n) ? sq[j0 + tid] : 0.f;
     __syncthreads();
     {
-      const int il = tid & (kGM - 1), jh = (tid >> 7) * 64;
+      const int il = tid & (kHM - 1), jh = (tid >> 8) * 64;
       const int64_t i = i0 + il;
       float xiv[DPAD];
 #pragma unroll
@@ -1626,12 +1632,13 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_grad_h(const float* __restr
   __syncthreads();
   if (tid < DPAD + 2) {
     const int64_t blk = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
-    partial[blk * (DPAD + 2) + tid] = sm.red[0][tid] + sm.red[1][tid] + sm.red[2][tid] + sm.red[3][tid];
+    partial[blk * (DPAD + 2) + tid] = ((sm.red[0][tid] + sm.red[1][tid]) + (sm.red[2][tid] + sm.red[3][tid])) +
+                                      ((sm.red[4][tid] + sm.red[5][tid]) + (sm.red[6][tid] + sm.red[7][tid]));
   }
 }
 
 int64_t rbf_grad_h_ws_bytes(int64_t n, int64_t batch) {
-  const int64_t npad = (n + 127) / 128 * 128, bpad = (batch + 31) / 32 * 32;
+  const int64_t npad = (n + kHM - 1) / kHM * kHM, bpad = (batch + 31) / 32 * 32;
   return 4 * bpad * npad * (int64_t)sizeof(_Float16) + 2 * bpad * (int64_t)sizeof(float) + 1024;
 }
 
@@ -1640,7 +1647,7 @@ static int launch_grad_h(const mfx_operator* op, const float* xs, const float* s
                          const float* R, int64_t ldr, int64_t batch, double* partial, int64_t* nblocks_out,
                          void* hws, hipStream_t stream) {
   const int64_t n = op->n;
-  const int64_t npad = (n + 127) / 128 * 128, bpad = (batch + 31) / 32 * 32;
+  const int64_t npad = (n + kHM - 1) / kHM * kHM, bpad = (batch + 31) / 32 * 32;
   char* base = static_cast<char*>(hws);
   float* amaxL = reinterpret_cast<float*>(base);
   float* amaxR = amaxL + bpad;
@@ -1657,13 +1664,13 @@ static int launch_grad_h(const mfx_operator* op, const float* xs, const float* s
   k_pack_f16<<<pgrid, 256, 0, stream>>>(L, ldl, batch, n, npad, scl, kGK * kGChunk, Lh, Ll);
   k_pack_f16<<<pgrid, 256, 0, stream>>>(R, ldr, batch, n, npad, scl + 2, 0, Rh, Rl);
   MFX_CHECK_LAUNCH();
-  const int64_t nti = (n + kGM - 1) / kGM, ntj = (n + kGN - 1) / kGN;
+  const int64_t nti = (n + kHM - 1) / kHM, ntj = (n + kGN - 1) / kGN;
   const int tiles_per_block = (int)((ntj + kGSplit * kGSub - 1) / (kGSplit * kGSub));
   const dim3 grid(kGSplit, (unsigned)(nti * kGSub));
   const size_t sh = sizeof(GradSmemH<DPAD>);
   MFX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rbf_mfma_grad_h<DPAD>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-  k_rbf_mfma_grad_h<DPAD><<<grid, 256, sh, stream>>>(xs, sq, n, npad, op->ard, op->kernel_fn, Lh, Ll, Rh, Rl, bpad / 8, tiles_per_block, partial);
+  k_rbf_mfma_grad_h<DPAD><<<grid, 512, sh, stream>>>(xs, sq, n, npad, op->ard, op->kernel_fn, Lh, Ll, Rh, Rl, bpad / 8, tiles_per_block, partial);
   MFX_CHECK_LAUNCH();
   *nblocks_out = nti * kGSub * kGSplit;
   return MFX_OK;
