@@ -1282,9 +1282,7 @@ static int launch_apply_h3k(const mfx_operator* op, const float* xs, const float
   if (pack) {
     if (vec4) MFX_H3_LAUNCH(true, true, true, rangeflag); else MFX_H3_LAUNCH(false, true, true, rangeflag);
     if (vec4) MFX_H3_LAUNCH(true, false, false, rangeflag); else MFX_H3_LAUNCH(false, false, false, rangeflag);  // runs only if flagged
-  } else if (rbf_dist_f16()) {
-    if (vec4) MFX_H3_LAUNCH(true, true, false, nullptr); else MFX_H3_LAUNCH(false, true, false, nullptr);
-  } else {
+  } else {  // MFX_RBF_DIST=0 / MFX_RBF_PACK=0 (or no pack workspace): fp32-MFMA distances, in-kernel split of the probe tiles
     if (vec4) MFX_H3_LAUNCH(true, false, false, nullptr); else MFX_H3_LAUNCH(false, false, false, nullptr);
   }
 #undef MFX_H3_LAUNCH
