@@ -356,8 +356,6 @@ static int64_t rbf_carve(const mfx_operator* op, void* ws, int64_t ws_bytes, Rbf
 bool rbf_mfma_supported(const mfx_operator* op, int64_t p);
 int rbf_mfma_apply(const mfx_operator* op, const float* xs, const float* sq, int dpad, const float* x, int64_t ldx,
                    float* y, int64_t ldy, int64_t p, hipStream_t stream);
-int rbf_mfma_apply_h(const mfx_operator* op, const float* xs, const float* sq, int dpad, const float* x, int64_t ldx,
-                     float* y, int64_t ldy, int64_t p, float* vscale, hipStream_t stream);
 int rbf_mfma_apply_h3(const mfx_operator* op, const float* xs, const float* sq, int dpad, const float* x, int64_t ldx,
                       float* y, int64_t ldy, int64_t p, float* vscale, void* pk, hipStream_t stream);
 int rbf_mfma_grad_h(const mfx_operator* op, const float* xs, const float* sq, int dpad, const float* L, int64_t ldl,
@@ -419,8 +417,6 @@ static int rbf_apply(const mfx_operator* op, const T* x, int64_t ldx, T* y, int6
     if (rbf_mfma_supported(op, p)) {
       if (rbf_mode(op) >= MFX_RBF_F16X3_MATVEC)
         return rbf_mfma_apply_h3(op, (const float*)w.xs, (const float*)w.sq, dpad, x, ldx, y, ldy, p, w.vscale, w.pk, stream);
-      if (rbf_mode(op) == -1 && op->kernel_fn == MFX_KERNEL_RBF)
-        return rbf_mfma_apply_h(op, (const float*)w.xs, (const float*)w.sq, dpad, x, ldx, y, ldy, p, w.vscale, stream);
       return rbf_mfma_apply(op, (const float*)w.xs, (const float*)w.sq, dpad, x, ldx, y, ldy, p, stream);
     }
   }

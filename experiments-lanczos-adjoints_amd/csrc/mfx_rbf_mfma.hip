@@ -359,227 +359,6 @@ struct RbfTileH {
   _Float16 vlo[(kTJ / 32) * 4][ROW];
 };
 
-template <int DPAD, int NB, bool VEC4>
-__global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply_h(const float* __restrict__ xs, const float* __restrict__ sq,
-                                                             int64_t n, const float* __restrict__ outputscale,
-                                                             const float* __restrict__ noise,
-                                                             const float* __restrict__ vscale,
-                                                             const float* __restrict__ x, int64_t ldx,
-                                                             float* __restrict__ y, int64_t ldy, int64_t p) {
-  constexpr float cfac = kNegHalfLog2e;  // RBF only (A/B variant of the pipelined kernel)
-  constexpr int kMI = 2, kTJ = 64;
-  using Tile = RbfTileH<DPAD, NB, kTJ>;
-  constexpr int KD = Tile::KD, KS = KD / 2;
-  __shared__ __attribute__((aligned(16))) Tile tile[2];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int l31 = lane & 31, lhi = lane >> 5;
-  const int64_t i_wave = (int64_t)blockIdx.x * (4 * kMI * 32) + (int64_t)wid * (kMI * 32);
-  const int64_t b0 = (int64_t)blockIdx.y * (NB * 32);
-
-  float bi[kMI][KS];
-#pragma unroll
-  for (int mi = 0; mi < kMI; ++mi) {
-    int64_t i = i_wave + mi * 32 + l31;
-    if (i >= n) i = n - 1;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const int k = 2 * s + lhi;
-      bi[mi][s] = (k < DPAD) ? xs[i * DPAD + k] : (k == DPAD ? 1.f : sq[i]);
-    }
-  }
-  floatx16 acc[kMI][NB];
-#pragma unroll
-  for (int mi = 0; mi < kMI; ++mi)
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][nb][r] = 0.f;
-
-  constexpr int kF4 = NB * 32 * (kTJ / 4);
-  constexpr int kVPT = (kF4 + 255) / 256;
-  constexpr int kXPT = (kTJ * DPAD + 255) / 256;
-  float4 rv[kVPT];
-  float rx[kXPT], rsq = 0.f;
-  float vs[kVPT];  // scale of the probe each of this thread's chunks belongs to (fixed across tiles)
-#pragma unroll
-  for (int u = 0; u < kVPT; ++u) {
-    const int f = tid + 256 * u;
-    const int64_t b = b0 + f / (kTJ / 4);
-    vs[u] = (f < kF4 && b < p) ? vscale[2 * b] : 0.f;
-  }
-
-  auto load_tile = [&](int64_t j0) {
-#pragma unroll
-    for (int u = 0; u < kVPT; ++u) {
-      const int f = tid + 256 * u;
-      const int bq = f / (kTJ / 4), j4 = (f % (kTJ / 4)) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (f < kF4 && b0 + bq < p) {
-        const float* src = x + (b0 + bq) * ldx + j0 + j4;
-        if (VEC4 && j0 + j4 + 3 < n) {
-          v = *reinterpret_cast<const float4*>(src);
-        } else {
-          if (j0 + j4 + 0 < n) v.x = src[0];
-          if (j0 + j4 + 1 < n) v.y = src[1];
-          if (j0 + j4 + 2 < n) v.z = src[2];
-          if (j0 + j4 + 3 < n) v.w = src[3];
-        }
-      }
-      rv[u] = v;
-    }
-#pragma unroll
-    for (int u = 0; u < kXPT; ++u) {
-      const int t = tid + 256 * u;
-      const int64_t g = j0 * DPAD + t;
-      rx[u] = (t < kTJ * DPAD && g < n * DPAD) ? xs[g] : 0.f;
-    }
-    if (tid < kTJ) rsq = (j0 + tid < n) ? sq[j0 + tid] : 0.f;
-  };
-  auto store_tile = [&](Tile& tl) {
-#pragma unroll
-    for (int u = 0; u < kVPT; ++u) {
-      const int f = tid + 256 * u;
-      if (f < kF4) {
-        const int bq = f / (kTJ / 4), j4 = (f % (kTJ / 4)) * 4;
-        // column j = j4 + e lives in pack row (jb, s, h) = (j>>5, (j>>4)&1, (j>>2)&1) at element 4*((j>>3)&1) + e
-        const int row = ((j4 >> 5) * 2 + ((j4 >> 4) & 1)) * 2 + ((j4 >> 2) & 1);
-        const int col = bq * 8 + 4 * ((j4 >> 3) & 1);
-        float h0, h1, h2, h3, l0, l1, l2, l3;
-        split_hi_lo(rv[u].x * vs[u], h0, l0);
-        split_hi_lo(rv[u].y * vs[u], h1, l1);
-        split_hi_lo(rv[u].z * vs[u], h2, l2);
-        split_hi_lo(rv[u].w * vs[u], h3, l3);
-        half4 hh = {(_Float16)h0, (_Float16)h1, (_Float16)h2, (_Float16)h3};
-        half4 ll = {(_Float16)l0, (_Float16)l1, (_Float16)l2, (_Float16)l3};
-        *reinterpret_cast<half4*>(&tl.vhi[row][col]) = hh;
-        *reinterpret_cast<half4*>(&tl.vlo[row][col]) = ll;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < kXPT; ++u) {
-      const int t = tid + 256 * u;
-      if (t < kTJ * DPAD) tl.aj[t % DPAD][t / DPAD] = -2.f * cfac * rx[u];
-    }
-    if (tid < kTJ) {
-      tl.aj[DPAD][tid] = kNegHalfLog2e * rsq + kKShift;  // K' = 2^15 K: keeps lo(K') a NORMAL f16 for K >= 4e-6
-      tl.aj[DPAD + 1][tid] = kNegHalfLog2e;
-    }
-  };
-
-  load_tile(0);
-  store_tile(tile[0]);
-  __syncthreads();
-  const int64_t ntile = (n + kTJ - 1) / kTJ;
-  for (int64_t t = 0; t < ntile; ++t) {
-    const Tile& tl = tile[t & 1];
-    if (t + 1 < ntile) load_tile((t + 1) * kTJ);
-#pragma unroll
-    for (int jb = 0; jb < kTJ / 32; ++jb) {
-      float aj[KS];
-#pragma unroll
-      for (int s = 0; s < KS; ++s) aj[s] = tl.aj[2 * s + lhi][jb * 32 + l31];
-      half8 bh[2][NB], bl[2][NB];
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-          const int row = (jb * 2 + s) * 2 + lhi;
-          bh[s][nb] = *reinterpret_cast<const half8*>(&tl.vhi[row][(nb * 32 + l31) * 8]);
-          bl[s][nb] = *reinterpret_cast<const half8*>(&tl.vlo[row][(nb * 32 + l31) * 8]);
-        }
-#pragma unroll
-      for (int mi = 0; mi < kMI; ++mi) {
-        floatx16 kd;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) kd[r] = 0.f;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) kd = __builtin_amdgcn_mfma_f32_32x32x2f32(aj[s], bi[mi][s], kd, 0, 0, 0);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          half8 ah, al;
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            const float kv = __builtin_amdgcn_exp2f(fminf(kd[8 * s + q], kKShift));
-            float hi, lo;
-            split_hi_lo(kv, hi, lo);
-            ah[q] = (_Float16)hi;
-            al[q] = (_Float16)lo;
-          }
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb) {
-            acc[mi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[s][nb], acc[mi][nb], 0, 0, 0);
-            acc[mi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[s][nb], acc[mi][nb], 0, 0, 0);
-            acc[mi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[s][nb], acc[mi][nb], 0, 0, 0);
-          }
-        }
-      }
-    }
-    if (t + 1 < ntile) store_tile(tile[(t + 1) & 1]);
-    __syncthreads();
-  }
-  const float s = outputscale[0], nz = noise[0];
-#pragma unroll
-  for (int mi = 0; mi < kMI; ++mi)
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      const int64_t b = b0 + nb * 32 + l31;
-      if (b >= p) continue;
-      const float sb = s * vscale[2 * b + 1] * (1.f / 32768.f);  // undo the probe's and K's power-of-two scales
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int64_t i = i_wave + mi * 32 + 8 * g + 4 * lhi;
-        if (VEC4 && i + 3 < n) {
-          const float4 xv = *reinterpret_cast<const float4*>(x + b * ldx + i);
-          float4 o;
-          o.x = fmaf(sb, acc[mi][nb][4 * g + 0], nz * xv.x);
-          o.y = fmaf(sb, acc[mi][nb][4 * g + 1], nz * xv.y);
-          o.z = fmaf(sb, acc[mi][nb][4 * g + 2], nz * xv.z);
-          o.w = fmaf(sb, acc[mi][nb][4 * g + 3], nz * xv.w);
-          *reinterpret_cast<float4*>(y + b * ldy + i) = o;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (i + e < n) y[b * ldy + i + e] = fmaf(sb, acc[mi][nb][4 * g + e], nz * x[b * ldx + i + e]);
-        }
-      }
-    }
-}
-
-template <int DPAD, int NB>
-static int launch_apply_h(const mfx_operator* op, const float* xs, const float* sq, const float* x, int64_t ldx,
-                          float* y, int64_t ldy, int64_t p, float* vscale, hipStream_t stream) {
-  const int64_t n = op->n;
-  MFX_TRY(row_scales(x, ldx, n, p, vscale, stream));
-  const dim3 grid((unsigned)((n + 255) / 256), (unsigned)((p + NB * 32 - 1) / (NB * 32)));
-  const bool vec4 = (n % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) &&
-                    (reinterpret_cast<uintptr_t>(y) % 16 == 0);
-  if (vec4) {
-    k_rbf_mfma_apply_h<DPAD, NB, true><<<grid, 256, 0, stream>>>(xs, sq, n, (const float*)op->outputscale,
-                                                                 (const float*)op->noise, vscale, x, ldx, y, ldy, p);
-  } else {
-    k_rbf_mfma_apply_h<DPAD, NB, false><<<grid, 256, 0, stream>>>(xs, sq, n, (const float*)op->outputscale,
-                                                                  (const float*)op->noise, vscale, x, ldx, y, ldy, p);
-  }
-  MFX_CHECK_LAUNCH();
-  return MFX_OK;
-}
-
-int rbf_mfma_apply_h(const mfx_operator* op, const float* xs, const float* sq, int dpad, const float* x, int64_t ldx,
-                     float* y, int64_t ldy, int64_t p, float* vscale, hipStream_t stream) {
-#define MFX_H_CASE(D)                                                                                   \
-  case D:                                                                                               \
-    return p <= 32 ? launch_apply_h<D, 1>(op, xs, sq, x, ldx, y, ldy, p, vscale, stream)                 \
-                   : launch_apply_h<D, 2>(op, xs, sq, x, ldx, y, ldy, p, vscale, stream)
-  switch (dpad) {
-    MFX_H_CASE(4);
-    MFX_H_CASE(8);
-    MFX_H_CASE(12);
-    MFX_H_CASE(16);
-    default: set_error("RBF MFMA path supports d <= 16"); return MFX_ERR_UNSUPPORTED;
-  }
-#undef MFX_H_CASE
-}
-
 // The reference clamps the squared distance at 0 before the exponential (util/gp_util.py:173).  In fp32 a computed squared
 // distance is negative only by round-off (|t| <~ 1e-6 of the operands' squares), so the clamp changes K_ij by at most that
 // round-off -- the same size as the error of every other entry -- while costing one VALU instruction per entry (7 % of the
