@@ -21,7 +21,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         if row["Counter_Name"] != c:
             continue
         for tag in ("k_rbf_mfma_apply_h3", "k_rbf_mfma_grad_h"):
-            if tag in row["Kernel_Name"]:
+            if tag in row["Kernel_Name"] and "false, false>" not in row["Kernel_Name"]:  # not the empty range-guard fallback launch
                 acc[tag][0] += float(row["Counter_Value"]); acc[tag][1] += 1
     for tag, (v, n) in acc.items():
         res[f"{tag}_{c}_KB"] = v / n
