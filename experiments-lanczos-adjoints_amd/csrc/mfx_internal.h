@@ -54,6 +54,10 @@ inline int64_t num_slices(int64_t n) { return (n + kSlice - 1) / kSlice; }
 inline size_t dtype_size(int dtype) { return dtype == MFX_F64 ? 8 : 4; }
 inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
+// row block of an operator (mfx_operator.row0 / nrows; nrows == 0 = all rows)
+inline int64_t op_row0(const mfx_operator* op) { return op->nrows > 0 ? op->row0 : 0; }
+inline int64_t op_nrows(const mfx_operator* op) { return op->nrows > 0 ? op->nrows : op->n; }
+
 // carve helper for caller-provided workspace
 struct Carver {
   char* base;
@@ -73,9 +77,11 @@ int op_apply(const mfx_operator* op, const void* x, int64_t ldx, void* y, int64_
              int transpose, void* ws, int64_t ws_bytes, hipStream_t stream);
 int op_apply_cb(const mfx_operator* op, int mode, const void* x, int64_t ldx, const void* aux,
                 int64_t ldaux, void* y, int64_t ldy, int64_t p, hipStream_t stream);
+// inner > 1: the batch rows come as (batch / inner) groups of `inner` rows whose magnitudes differ widely WITHIN a group
+// ((probe, Krylov step) order): lets the split gradient GEMM regroup them, see k_pack_f16
 int op_vjp_params(const mfx_operator* op, const void* L, int64_t ldl, const void* R, int64_t ldr,
                   int64_t batch, const mfx_op_grads* grads, void* ws, int64_t ws_bytes,
-                  hipStream_t stream);
+                  hipStream_t stream, int64_t inner = 1);
 
 int64_t rbf_cross_ws_bytes(const mfx_operator* op, int64_t m);
 int op_cross_apply(const mfx_operator* op, const void* xnew, int64_t m, const void* v, int64_t ldv, void* y, int64_t ldy,

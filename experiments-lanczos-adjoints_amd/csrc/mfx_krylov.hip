@@ -332,15 +332,18 @@ __global__ __launch_bounds__(kBlock) void k_lz_adj_dvec(const T* __restrict__ x0
 struct KrylovWs {
   void *w, *p1, *p2, *pn, *small, *opws;
   int64_t opws_bytes;
+  // row-sharded drivers only
+  void *stage, *send, *gathered, *xfull;
 };
 
+// n = length of the vectors this process holds (the operator size, or the rows of its shard: comm != NULL)
 static int64_t carve_ws(const mfx_operator* op, int64_t n, int64_t k, int64_t p, void* ws, int64_t ws_bytes,
-                        KrylovWs* out) {
+                        KrylovWs* out, const mfx_comm* comm = nullptr) {
   const size_t es = dtype_size(op->dtype);
   const int64_t nblk = (n + 64 * kEpt - 1) / (64 * kEpt);  // the finest slicing the drivers may choose
   const int64_t kmax = k + 1;
   Carver cv(ws, ws_bytes);
-  KrylovWs r;
+  KrylovWs r{};
   r.w = cv.take(2 * p * n * es);                // two (p, n) scratch vectors
   r.p1 = cv.take(p * kmax * nblk * es);         // dots partials
   r.p2 = cv.take(p * kmax * nblk * es);         // second-pass partials
@@ -348,18 +351,73 @@ static int64_t carve_ws(const mfx_operator* op, int64_t n, int64_t k, int64_t p,
   r.small = cv.take((2 * p * k * k + 4 * p * k + 8 * p) * es);  // Gamma, Pi_gamma, eta, coefficients
   r.opws_bytes = op_workspace_bytes(op, p * (k + 1), p);  // the deferred gradient sweep batches all (probe, step) pairs
   r.opws = cv.take(r.opws_bytes);
+  if (comm) {
+    r.stage = cv.take(p * kmax * nblk * es);                 // producers' per-slice partials before the all-reduce
+    r.send = cv.take(p * comm->nloc * es);                   // this rank's (p, nloc) iterate, zero padded
+    r.gathered = cv.take(comm->world * p * comm->nloc * es); // (world, p, nloc)
+    r.xfull = cv.take(p * op->n * es);                       // the full iterate (p, n) (adjoint; the forward writes Qfull)
+  }
   if (out) *out = r;
   return cv.off;
 }
 
 // ------------------------------------------------------------------------------------------------
+// row-sharded operator application: all-gather the iterate, apply the rows this rank owns
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_pack_shard(const T* __restrict__ x, int64_t ldx, int64_t nrows, int64_t nloc,
+                                                    T* __restrict__ send) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (i < nloc) send[b * nloc + i] = i < nrows ? x[b * ldx + i] : T(0);
+}
+
+// gathered (world, p, nloc) -> full[b][g nloc + i], the first n columns
+template <typename T>
+__global__ __launch_bounds__(256) void k_unshard(const T* __restrict__ gathered, int64_t nloc, int64_t p, int64_t n,
+                                                 T* __restrict__ full, int64_t ldfull) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (j >= n) return;
+  const int64_t g = j / nloc, i = j - g * nloc;
+  full[b * ldfull + j] = gathered[(g * p + b) * nloc + i];
+}
+
+static inline int64_t shard_row0(const mfx_comm* cm) { return (int64_t)cm->rank * cm->nloc; }
+static inline int64_t shard_nrows(const mfx_comm* cm, int64_t n) {
+  const int64_t left = n - shard_row0(cm);
+  return left < cm->nloc ? left : cm->nloc;
+}
+
+// y (p rows of nrows, this rank's rows of A x or A^T x) from the sharded x; `full` (p, n) receives the gathered iterate
+template <typename T>
+static int apply_sharded(const mfx_operator* op, const mfx_comm* cm, int transpose, const T* x, int64_t ldx, T* y,
+                         int64_t ldy, int64_t p, T* full, int64_t ldfull, const KrylovWs& ws, hipStream_t stream) {
+  const int64_t n = op->n, nloc = cm->nloc, nrows = shard_nrows(cm, n);
+  {
+    ScopedTimer t(3, stream);
+    k_pack_shard<T><<<dim3((unsigned)((nloc + 255) / 256), (unsigned)p), 256, 0, stream>>>(x, ldx, nrows, nloc, (T*)ws.send);
+    MFX_CHECK_LAUNCH();
+    const int rc = cm->allgather(cm->ctx, ws.send, ws.gathered, p * nloc, op->dtype, stream);
+    MFX_REQUIRE(rc == 0, MFX_ERR_CALLBACK, "all-gather callback failed with code %d", rc);
+    k_unshard<T><<<dim3((unsigned)((n + 255) / 256), (unsigned)p), 256, 0, stream>>>((const T*)ws.gathered, nloc, p, n, full, ldfull);
+    MFX_CHECK_LAUNCH();
+  }
+  mfx_operator rows = *op;
+  rows.row0 = shard_row0(cm);
+  rows.nrows = nrows;
+  ScopedTimer t(0, stream);
+  return op_apply(&rows, full, ldfull, y, ldy, p, transpose, ws.opws, ws.opws_bytes, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
 // drivers
 // ------------------------------------------------------------------------------------------------
+// comm != NULL: row-sharded (n = rows of this rank, op->n = operator size, Qfull (p, k, op->n) receives the gathered basis)
 template <typename T>
 static int arnoldi_forward_t(const mfx_operator* op, const T* v0, int64_t n, int64_t k, int64_t p,
                              int second_pass, T* Q, T* H, T* r, T* cinv, const KrylovWs& ws,
-                             hipStream_t stream) {
+                             hipStream_t stream, const mfx_comm* comm = nullptr, T* Qfull = nullptr) {
   Ctx<T> c(n, k, p, pick_vec<T>(n, {v0, Q, r, ws.w}), stream);
+  if (comm) c.shard(comm, static_cast<T*>(ws.stage));
   T* P1 = static_cast<T*>(ws.p1);
   T* P2 = static_cast<T*>(ws.p2);
   T* PN = static_cast<T*>(ws.pn);
@@ -373,7 +431,11 @@ static int arnoldi_forward_t(const mfx_operator* op, const T* v0, int64_t n, int
   T* w = r;  // the running vector lives in the remainder output (arnoldi.py:75 returns it as r)
   for (int64_t i = 0; i < k; ++i) {
     const int m = (int)(i + 1);
-    MFX_TRY(apply_any(op, 0, Q + i * n, ldq, nullptr, 0, w, n, p, ws.opws, ws.opws_bytes, stream));
+    if (comm) {
+      MFX_TRY(apply_sharded<T>(op, comm, 0, Q + i * n, ldq, w, n, p, Qfull + i * op->n, k * op->n, ws, stream));
+    } else {
+      MFX_TRY(apply_any(op, 0, Q + i * n, ldq, nullptr, 0, w, n, p, ws.opws, ws.opws_bytes, stream));
+    }
     ScopedTimer t(2, stream);
     MFX_TRY(launch_dots<T>(c, Q, ldq, n, m, w, n, P1));
     UpdateArgs<T> a{};
@@ -403,8 +465,9 @@ template <typename T>
 static int arnoldi_adjoint_t(const mfx_operator* op, int64_t n, int64_t k, int64_t p, const T* Q, const T* H,
                              const T* r, const T* cinv, const T* dQ, const T* dH, const T* dr, const T* dc,
                              int reortho, T* dv, T* Lam, const mfx_op_grads* grads, const KrylovWs& ws,
-                             hipStream_t stream) {
+                             hipStream_t stream, const mfx_comm* comm = nullptr, const T* Qfull = nullptr) {
   Ctx<T> c(n, k, p, pick_vec<T>(n, {Q, r, dQ, dr, dv, Lam, ws.w}), stream);
+  if (comm) c.shard(comm, static_cast<T*>(ws.stage));
   T* P1 = static_cast<T*>(ws.p1);
   T* lam = static_cast<T*>(ws.w);  // current lambda (p, n)
   T* z = lam + p * n;              // A^T lambda     (p, n)
@@ -416,12 +479,12 @@ static int arnoldi_adjoint_t(const mfx_operator* op, int64_t n, int64_t k, int64
   {
     ScopedTimer t(2, stream);
     if (dr) MFX_TRY(launch_dots<T>(c, Q, ldq, n, (int)k, dr, n, P1));
-    k_adj_setup<T><<<(unsigned)p, 256, 0, stream>>>(H, dH, cinv, dc, dr ? P1 : nullptr, c.kmax, c.nblk, (int)k, eta, pig);
+    k_adj_setup<T><<<(unsigned)p, 256, 0, stream>>>(H, dH, cinv, dc, dr ? P1 : nullptr, c.kmax, c.nblk_in, (int)k, eta, pig);
     MFX_CHECK_LAUNCH();
     if (dQ) {
       for (int64_t col = 0; col < k; ++col) {
         MFX_TRY(launch_dots<T>(c, Q, ldq, n, (int)k, dQ + col * n, ldq, P1));
-        k_pig_sub<T><<<(unsigned)p, 64, 0, stream>>>(pig, (int)k, (int)col, P1, c.kmax, c.nblk);
+        k_pig_sub<T><<<(unsigned)p, 64, 0, stream>>>(pig, (int)k, (int)col, P1, c.kmax, c.nblk_in);
         MFX_CHECK_LAUNCH();
       }
     }
@@ -451,10 +514,14 @@ static int arnoldi_adjoint_t(const mfx_operator* op, int64_t n, int64_t k, int64
       }
     }
     // z = A^T lambda (+ parameter gradient for callback operators), arnoldi.py:207-209
-    MFX_TRY(apply_any(op, 1, lam_idx, ldq, Q + idx * n, ldq, z, n, p, ws.opws, ws.opws_bytes, stream));
+    if (comm) {
+      MFX_TRY(apply_sharded<T>(op, comm, 1, lam_idx, ldq, z, n, p, static_cast<T*>(ws.xfull), op->n, ws, stream));
+    } else {
+      MFX_TRY(apply_any(op, 1, lam_idx, ldq, Q + idx * n, ldq, z, n, p, ws.opws, ws.opws_bytes, stream));
+    }
     ScopedTimer t(2, stream);
     MFX_TRY(launch_dots<T>(c, Q, ldq, n, (int)(idx + 1), z, n, P1));
-    CombineArgs<T> ca{Q, Lam, H, pig, eta, r, dQ, z, P1, Gam, lam, n, (int)k, (int)idx, c.kmax, c.nblk};
+    CombineArgs<T> ca{Q, Lam, H, pig, eta, r, dQ, z, P1, Gam, lam, n, (int)k, (int)idx, c.kmax, c.nblk_in};
     const size_t sh = (size_t)2 * k * sizeof(T);
     MFX_VEC_SWITCH(c.vec, (k_adj_combine<T, VEC><<<c.grid(), c.wg, sh, stream>>>(ca)));
     MFX_CHECK_LAUNCH();
@@ -465,7 +532,14 @@ static int arnoldi_adjoint_t(const mfx_operator* op, int64_t n, int64_t k, int64
   }
   if (op->kind != MFX_OP_CALLBACK && grads) {
     ScopedTimer t(1, stream);
-    MFX_TRY(op_vjp_params(op, Lam, n, Q, n, p * k, grads, ws.opws, ws.opws_bytes, stream));
+    if (comm) {  // this rank's rows of S = Lambda^T Q against all columns: L = local adjoint states, R = the gathered basis
+      mfx_operator rows = *op;
+      rows.row0 = shard_row0(comm);
+      rows.nrows = n;
+      MFX_TRY(op_vjp_params(&rows, Lam, n, Qfull, op->n, p * k, grads, ws.opws, ws.opws_bytes, stream, k));
+    } else {
+      MFX_TRY(op_vjp_params(op, Lam, n, Q, n, p * k, grads, ws.opws, ws.opws_bytes, stream, k));
+    }
   }
   return MFX_OK;
 }
@@ -559,6 +633,7 @@ static int check_common(const mfx_operator* op, int64_t n, int64_t k, int64_t p)
   MFX_REQUIRE(op->dtype == MFX_F32 || op->dtype == MFX_F64, MFX_ERR_UNSUPPORTED, "unsupported dtype %d", op->dtype);
   MFX_REQUIRE(n >= 1 && p >= 1, MFX_ERR_INVALID, "n=%lld, p=%lld must be positive", (long long)n, (long long)p);
   MFX_REQUIRE(op->n == n, MFX_ERR_INVALID, "operator size %lld != n=%lld", (long long)op->n, (long long)n);
+  MFX_REQUIRE(op->nrows == 0, MFX_ERR_INVALID, "the Krylov drivers take the whole operator (nrows = 0); row shards go through mfx_*_sharded");
   MFX_REQUIRE(k >= 1 && k <= n, MFX_ERR_INVALID, "Parameter depth %lld is outside the expected range", (long long)k);
   MFX_REQUIRE(p <= 65535, MFX_ERR_UNSUPPORTED, "p=%lld exceeds the grid limit 65535", (long long)p);
   MFX_REQUIRE((int64_t)(4 * (k + 1) + (k + 1) + 4) * 8 <= 64 * 1024, MFX_ERR_UNSUPPORTED, "k=%lld too large", (long long)k);
@@ -626,6 +701,59 @@ int mfx_arnoldi_adjoint(const mfx_operator* op, int64_t n, int64_t k, int64_t p,
   return arnoldi_adjoint_t<double>(op, n, k, p, (const double*)Q, (const double*)H, (const double*)r, (const double*)c,
                                    (const double*)dQ, (const double*)dH, (const double*)dr, (const double*)dc, reortho,
                                    (double*)dv, (double*)Lambda, grads, kws, s);
+}
+
+static int check_sharded(const mfx_operator* op, const mfx_comm* cm, int64_t n, int64_t k, int64_t p) {
+  MFX_TRY(check_common(op, n, k, p));
+  MFX_REQUIRE(cm && cm->allreduce_sum && cm->allgather, MFX_ERR_INVALID, "communicator without callbacks");
+  MFX_REQUIRE(op->kind != MFX_OP_CALLBACK, MFX_ERR_UNSUPPORTED, "row sharding needs a native operator");
+  MFX_REQUIRE(cm->world >= 1 && cm->rank >= 0 && cm->rank < cm->world, MFX_ERR_INVALID, "bad rank %d of %d", cm->rank, cm->world);
+  MFX_REQUIRE(cm->nloc >= 64 && cm->nloc % 64 == 0, MFX_ERR_INVALID, "rows per rank (%lld) must be a positive multiple of 64", (long long)cm->nloc);
+  MFX_REQUIRE((int64_t)cm->world * cm->nloc >= n && (int64_t)(cm->world - 1) * cm->nloc < n, MFX_ERR_INVALID,
+              "%d ranks x %lld rows do not tile n = %lld with a non-empty last shard", cm->world, (long long)cm->nloc, (long long)n);
+  return MFX_OK;
+}
+
+#define MFX_SHARDED_PROLOGUE()                                                                  \
+  MFX_TRY(check_sharded(op, comm, n, k, p));                                                    \
+  const int64_t nrows = shard_nrows(comm, n);                                                   \
+  KrylovWs kws;                                                                                 \
+  const int64_t need = carve_ws(op, nrows, k, p, ws, ws_bytes, &kws, comm);                      \
+  MFX_REQUIRE(ws && need <= ws_bytes, MFX_ERR_WORKSPACE, "workspace too small: need %lld bytes", \
+              (long long)need);                                                                 \
+  hipStream_t s = static_cast<hipStream_t>(stream)
+
+int64_t mfx_sharded_workspace_bytes(const mfx_operator* op, const mfx_comm* comm, int64_t n, int64_t k, int64_t p) {
+  if (!op || !comm || comm->nloc < 1) return -1;
+  return carve_ws(op, comm->nloc, k, p, nullptr, 0, nullptr, comm);
+}
+
+int mfx_arnoldi_forward_sharded(const mfx_operator* op, const mfx_comm* comm, const void* v0, int64_t n, int64_t k,
+                                int64_t p, int second_pass, void* Q, void* Qfull, void* H, void* r, void* c, void* ws,
+                                int64_t ws_bytes, void* stream) {
+  MFX_REQUIRE(v0 && Q && Qfull && H && r && c, MFX_ERR_INVALID, "null argument");
+  MFX_SHARDED_PROLOGUE();
+  if (op->dtype == MFX_F32)
+    return arnoldi_forward_t<float>(op, (const float*)v0, nrows, k, p, second_pass, (float*)Q, (float*)H, (float*)r, (float*)c,
+                                    kws, s, comm, (float*)Qfull);
+  return arnoldi_forward_t<double>(op, (const double*)v0, nrows, k, p, second_pass, (double*)Q, (double*)H, (double*)r,
+                                   (double*)c, kws, s, comm, (double*)Qfull);
+}
+
+int mfx_arnoldi_adjoint_sharded(const mfx_operator* op, const mfx_comm* comm, int64_t n, int64_t k, int64_t p,
+                                const void* Q, const void* Qfull, const void* H, const void* r, const void* c,
+                                const void* dQ, const void* dH, const void* dr, const void* dc, int reortho, void* dv,
+                                void* Lambda, const mfx_op_grads* grads, void* ws, int64_t ws_bytes, void* stream) {
+  MFX_REQUIRE(Q && Qfull && H && r && c && dH && dv && Lambda, MFX_ERR_INVALID, "null argument");
+  MFX_REQUIRE(reortho == MFX_REORTHO_NONE || reortho == MFX_REORTHO_FULL, MFX_ERR_INVALID, "bad reortho flag %d", reortho);
+  MFX_SHARDED_PROLOGUE();
+  if (op->dtype == MFX_F32)
+    return arnoldi_adjoint_t<float>(op, nrows, k, p, (const float*)Q, (const float*)H, (const float*)r, (const float*)c,
+                                    (const float*)dQ, (const float*)dH, (const float*)dr, (const float*)dc, reortho,
+                                    (float*)dv, (float*)Lambda, grads, kws, s, comm, (const float*)Qfull);
+  return arnoldi_adjoint_t<double>(op, nrows, k, p, (const double*)Q, (const double*)H, (const double*)r, (const double*)c,
+                                   (const double*)dQ, (const double*)dH, (const double*)dr, (const double*)dc, reortho,
+                                   (double*)dv, (double*)Lambda, grads, kws, s, comm, (const double*)Qfull);
 }
 
 int mfx_lanczos_forward(const mfx_operator* op, const void* v0, int64_t n, int64_t k, int64_t p, void* xs,

@@ -16,15 +16,15 @@ namespace mfx {
 template <typename T, int PB>
 __global__ __launch_bounds__(256) void k_dense_apply(const T* __restrict__ A, int64_t lda, int64_t n,
                                                      const T* __restrict__ x, int64_t ldx, T* __restrict__ y,
-                                                     int64_t ldy, int64_t p) {
+                                                     int64_t ldy, int64_t p, int64_t row0, int64_t nrow) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int64_t i = (int64_t)blockIdx.x * 4 + wid;
+  const int64_t i = (int64_t)blockIdx.x * 4 + wid;  // local row: y[i] = (A x)[row0 + i]
   const int64_t b0 = (int64_t)blockIdx.y * PB;
-  if (i >= n) return;
+  if (i >= nrow) return;
   T acc[PB];
 #pragma unroll
   for (int q = 0; q < PB; ++q) acc[q] = T(0);
-  const T* row = A + i * lda;
+  const T* row = A + (row0 + i) * lda;
   for (int64_t j = lane; j < n; j += 64) {
     const T a = row[j];
 #pragma unroll
@@ -42,17 +42,17 @@ __global__ __launch_bounds__(256) void k_dense_apply(const T* __restrict__ A, in
 template <typename T, int PB>
 __global__ __launch_bounds__(256) void k_dense_apply_t(const T* __restrict__ A, int64_t lda, int64_t n,
                                                        const T* __restrict__ x, int64_t ldx, T* __restrict__ y,
-                                                       int64_t ldy, int64_t p) {
+                                                       int64_t ldy, int64_t p, int64_t row0, int64_t nrow) {
   __shared__ T sm[4][PB][64];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int64_t j = (int64_t)blockIdx.x * 64 + lane;
+  const int64_t j = (int64_t)blockIdx.x * 64 + lane;  // local row of A^T: y[j] = (A^T x)[row0 + j]
   const int64_t b0 = (int64_t)blockIdx.y * PB;
   T acc[PB];
 #pragma unroll
   for (int q = 0; q < PB; ++q) acc[q] = T(0);
-  if (j < n) {
+  if (j < nrow) {
     for (int64_t i = wid; i < n; i += 4) {
-      const T a = A[i * lda + j];
+      const T a = A[i * lda + row0 + j];
 #pragma unroll
       for (int q = 0; q < PB; ++q)
         if (b0 + q < p) acc[q] += a * x[(b0 + q) * ldx + i];
@@ -61,23 +61,24 @@ __global__ __launch_bounds__(256) void k_dense_apply_t(const T* __restrict__ A, 
 #pragma unroll
   for (int q = 0; q < PB; ++q) sm[wid][q][lane] = acc[q];
   __syncthreads();
-  if (wid == 0 && j < n) {
+  if (wid == 0 && j < nrow) {
 #pragma unroll
     for (int q = 0; q < PB; ++q)
       if (b0 + q < p) y[(b0 + q) * ldy + j] = sm[0][q][lane] + sm[1][q][lane] + sm[2][q][lane] + sm[3][q][lane];
   }
 }
 
-// dA[i][j] += sum_bt L[bt][i] R[bt][j]
+// dA[row0 + i][j] += sum_bt L[bt][i] R[bt][j]   (i < nrow: the rows this call owns)
 template <typename T>
 __global__ __launch_bounds__(256) void k_dense_grad(const T* __restrict__ L, int64_t ldl, const T* __restrict__ R,
-                                                    int64_t ldr, int64_t batch, int64_t n, T* __restrict__ dA) {
+                                                    int64_t ldr, int64_t batch, int64_t n, T* __restrict__ dA,
+                                                    int64_t row0, int64_t nrow) {
   const int tj = threadIdx.x & 15, ti = threadIdx.x >> 4;
   const int64_t i = (int64_t)blockIdx.y * 16 + ti, j = (int64_t)blockIdx.x * 16 + tj;
-  if (i >= n || j >= n) return;
+  if (i >= nrow || j >= n) return;
   double acc = 0.0;
   for (int64_t bt = 0; bt < batch; ++bt) acc += (double)L[bt * ldl + i] * (double)R[bt * ldr + j];
-  dA[i * n + j] += (T)acc;
+  dA[(row0 + i) * n + j] += (T)acc;
 }
 
 // ================================================================================================
@@ -87,15 +88,15 @@ __global__ __launch_bounds__(256) void k_dense_grad(const T* __restrict__ L, int
 template <typename T>
 __global__ __launch_bounds__(256) void k_csr_apply(const int32_t* __restrict__ crow, const int32_t* __restrict__ col,
                                                    const int32_t* __restrict__ perm, const T* __restrict__ val,
-                                                   int64_t n, const T* __restrict__ x, int64_t ldx,
-                                                   T* __restrict__ y, int64_t ldy) {
+                                                   int64_t nrow, const T* __restrict__ x, int64_t ldx,
+                                                   T* __restrict__ y, int64_t ldy, int64_t row0) {
   const int sub = threadIdx.x & 7;
-  const int64_t row = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+  const int64_t row = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);  // local: y[row] = (A x)[row0 + row]
   const int64_t b = blockIdx.y;
   T acc = T(0);
-  if (row < n) {
+  if (row < nrow) {
     const T* xb = x + b * ldx;
-    for (int32_t e = crow[row] + sub; e < crow[row + 1]; e += 8) {
+    for (int32_t e = crow[row0 + row] + sub; e < crow[row0 + row + 1]; e += 8) {
       const T v = perm ? val[perm[e]] : val[e];
       acc += v * xb[col[e]];
     }
@@ -103,18 +104,20 @@ __global__ __launch_bounds__(256) void k_csr_apply(const int32_t* __restrict__ c
   acc += __shfl_down(acc, 4, 8);
   acc += __shfl_down(acc, 2, 8);
   acc += __shfl_down(acc, 1, 8);
-  if (row < n && sub == 0) y[b * ldy + row] = acc;
+  if (row < nrow && sub == 0) y[b * ldy + row] = acc;
 }
 
-// dval[e] += sum_bt L[bt][row_e] R[bt][col_e]   (SDDMM on the sparsity pattern)
+// dval[e] += sum_bt L[bt][row_e - row0] R[bt][col_e]   (SDDMM on the sparsity pattern; only entries of the rows
+// [row0, row0 + nrow) this call owns -- the others belong to other row shards)
 template <typename T>
 __global__ __launch_bounds__(256) void k_csr_grad(const int32_t* __restrict__ row, const int32_t* __restrict__ col,
                                                   int64_t nnz, const T* __restrict__ L, int64_t ldl,
                                                   const T* __restrict__ R, int64_t ldr, int64_t batch,
-                                                  T* __restrict__ dval) {
+                                                  T* __restrict__ dval, int64_t row0, int64_t nrow) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= nnz) return;
-  const int64_t r = row[e], c = col[e];
+  const int64_t r = (int64_t)row[e] - row0, c = col[e];
+  if (r < 0 || r >= nrow) return;
   double acc = 0.0;
   for (int64_t bt = 0; bt < batch; ++bt) acc += (double)L[bt * ldl + r] * (double)R[bt * ldr + c];
   dval[e] += (T)acc;
@@ -148,10 +151,12 @@ __global__ __launch_bounds__(256) void k_rbf_apply(const T* __restrict__ xs, con
                                                    const T* __restrict__ outputscale, const T* __restrict__ noise,
                                                    const T* __restrict__ x, int64_t ldx, T* __restrict__ y,
                                                    int64_t ldy, int64_t p, int kind,
-                                                   const T* __restrict__ xrow, const T* __restrict__ sqrow, int64_t m) {
-  // rows i < m come from (xrow, sqrow); xrow == xs is the square Gram operator (self distances exactly 0, noise on
-  // the diagonal), anything else the cross-covariance K(X_new, X) of the posterior mean (util/gp_util.py:299-301)
-  const bool self = xrow == xs;
+                                                   const T* __restrict__ xrow, const T* __restrict__ sqrow, int64_t m,
+                                                   int64_t row0) {
+  // rows i < m come from (xrow, sqrow).  row0 >= 0: they are the points row0 .. row0 + m of X itself -- the square Gram
+  // operator (or a row block of it): self distances exactly 0, noise on the diagonal; row0 < 0: another point set, the
+  // cross-covariance K(X_new, X) of the posterior mean (util/gp_util.py:299-301)
+  const bool self = row0 >= 0;
   __shared__ __attribute__((aligned(16))) T xj[kRbfTJ][DPAD];
   __shared__ T sqj[kRbfTJ];
   __shared__ T vj[PB][kRbfTJ];
@@ -188,7 +193,7 @@ __global__ __launch_bounds__(256) void k_rbf_apply(const T* __restrict__ xs, con
       if (kind == MFX_KERNEL_RBF) {
         kv = exp_neg_half(dist);
       } else {
-        if (self && j0 + jj == i) dist = T(0);  // a point's distance to itself is exactly 0 (sqrt amplifies round-off)
+        if (self && j0 + jj == row0 + i) dist = T(0);  // a point's distance to itself is exactly 0 (sqrt amplifies round-off)
         kernel_eval<T>(kind, dist, kv, wl);
       }
 #pragma unroll
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(256) void k_rbf_apply(const T* __restrict__ xs, con
     const T s = outputscale[0], nz = noise[0];
 #pragma unroll
     for (int q = 0; q < PB; ++q)
-      if (b0 + q < p) y[(b0 + q) * ldy + i] = self ? s * acc[q] + nz * x[(b0 + q) * ldx + i] : s * acc[q];
+      if (b0 + q < p) y[(b0 + q) * ldy + i] = self ? s * acc[q] + nz * x[(b0 + q) * ldx + row0 + i] : s * acc[q];
   }
 }
 
@@ -214,15 +219,17 @@ template <typename T, int DPAD>
 __global__ __launch_bounds__(256) void k_rbf_grad(const T* __restrict__ xs, const T* __restrict__ sq, int64_t n,
                                                   int ard, int kind, const T* __restrict__ L, int64_t ldl,
                                                   const T* __restrict__ R, int64_t ldr, int64_t batch,
-                                                  double* __restrict__ partial /* (nblocks, DPAD + 2) */) {
+                                                  double* __restrict__ partial /* (nblocks, DPAD + 2) */,
+                                                  int64_t row0, int64_t nrow) {
   __shared__ __attribute__((aligned(16))) T xj[kGradTJ][DPAD];
   __shared__ T sqj[kGradTJ];
   __shared__ T rj[kGradBC][kGradTJ];
   __shared__ double red[4][DPAD + 2];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int64_t i = (int64_t)blockIdx.x * 256 + tid;
-  const bool live = i < n;
-  const int64_t ic = live ? i : n - 1;
+  const int64_t il = (int64_t)blockIdx.x * 256 + tid;  // local row: L is indexed by il, the point is row0 + il
+  const bool live = il < nrow;
+  const int64_t i = row0 + il;
+  const int64_t ic = live ? i : row0 + nrow - 1;
   T xi[DPAD];
 #pragma unroll
   for (int c = 0; c < DPAD; ++c) xi[c] = xs[ic * DPAD + c];
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(256) void k_rbf_grad(const T* __restrict__ xs, cons
       __syncthreads();
       const int qmax = (int)((batch - bt0) < kGradBC ? (batch - bt0) : kGradBC);
       for (int q = 0; q < qmax; ++q) {
-        const T l = live ? L[(bt0 + q) * ldl + i] : T(0);
+        const T l = live ? L[(bt0 + q) * ldl + il] : T(0);
 #pragma unroll
         for (int jj = 0; jj < kGradTJ; ++jj) S[jj] += l * rj[q][jj];
       }
@@ -359,7 +366,7 @@ int rbf_mfma_apply(const mfx_operator* op, const float* xs, const float* sq, int
 int rbf_mfma_apply_h3(const mfx_operator* op, const float* xs, const float* sq, int dpad, const float* x, int64_t ldx,
                       float* y, int64_t ldy, int64_t p, float* vscale, void* pk, hipStream_t stream);
 int rbf_mfma_grad_h(const mfx_operator* op, const float* xs, const float* sq, int dpad, const float* L, int64_t ldl,
-                    const float* R, int64_t ldr, int64_t batch, double* partial, int64_t* nblocks_out, void* hws,
+                    const float* R, int64_t ldr, int64_t batch, int64_t inner, double* partial, int64_t* nblocks_out, void* hws,
                     const float** scales_out, hipStream_t stream);
 bool rbf_mfma_grad_supported(const mfx_operator* op, int64_t batch);
 int rbf_mfma_grad(const mfx_operator* op, const float* xs, const float* sq, int dpad, const float* L, int64_t ldl,
@@ -377,16 +384,18 @@ static int rbf_prep(const mfx_operator* op, const RbfWs& w, int dpad, hipStream_
 template <typename T, int DPAD>
 static int rbf_apply_d(const mfx_operator* op, const RbfWs& w, const T* x, int64_t ldx, T* y, int64_t ldy, int64_t p,
                        hipStream_t stream, const T* xrow = nullptr, const T* sqrow = nullptr, int64_t m = 0) {
-  if (!xrow) {
-    xrow = (const T*)w.xs;
-    sqrow = (const T*)w.sq;
-    m = op->n;
+  int64_t row0 = -1;  // cross-covariance rows (another point set)
+  if (!xrow) {        // rows row0 .. row0 + m of the square Gram operator
+    row0 = op_row0(op);
+    m = op_nrows(op);
+    xrow = (const T*)w.xs + row0 * DPAD;
+    sqrow = (const T*)w.sq + row0;
   }
   const unsigned gx = (unsigned)((m + 255) / 256);
 #define MFX_RBF_LAUNCH(PB)                                                                           \
   k_rbf_apply<T, DPAD, PB><<<dim3(gx, (unsigned)((p + PB - 1) / PB)), 256, 0, stream>>>(               \
       (const T*)w.xs, (const T*)w.sq, op->n, (const T*)op->outputscale, (const T*)op->noise, x, ldx, y, ldy, p, \
-      op->kernel_fn, xrow, sqrow, m)
+      op->kernel_fn, xrow, sqrow, m, row0)
   if (p == 1) {
     MFX_RBF_LAUNCH(1);
   } else if (p == 2) {
@@ -470,21 +479,22 @@ int op_cross_apply(const mfx_operator* op, const void* xnew, int64_t m, const vo
 }
 
 template <typename T>
-static int rbf_grad(const mfx_operator* op, const T* L, int64_t ldl, const T* R, int64_t ldr, int64_t batch,
+static int rbf_grad(const mfx_operator* op, const T* L, int64_t ldl, const T* R, int64_t ldr, int64_t batch, int64_t inner,
                     const mfx_op_grads* grads, void* ws, int64_t ws_bytes, hipStream_t stream) {
   const int dpad = rbf_dpad(op->d);
   MFX_REQUIRE(dpad > 0, MFX_ERR_UNSUPPORTED, "RBF operator supports d <= 32 (got %d)", op->d);
   RbfWs w;
   MFX_REQUIRE(rbf_carve(op, ws, ws_bytes, &w, batch) <= ws_bytes && ws, MFX_ERR_WORKSPACE, "RBF workspace too small");
   MFX_TRY(rbf_prep<T>(op, w, dpad, stream));
-  int64_t nblocks = (op->n + 255) / 256;
+  const int64_t row0 = op_row0(op), nrow = op_nrows(op);
+  int64_t nblocks = (nrow + 255) / 256;
   bool done = false;
   const float* scales = nullptr;
   if constexpr (sizeof(T) == 4) {
     // the split GEMM stages its packed operands through 32-bit byte offsets: 2 B x padded batch x padded n < 4 GiB
-    const bool fits32 = ((batch + 31) / 32 * 32) * ((op->n + 127) / 128 * 128) * 2 < ((int64_t)1 << 32);
+    const bool fits32 = ((batch + 31) / 32 * 32) * ((op->n + 255) / 256 * 256) * 2 < ((int64_t)1 << 32);
     if (rbf_mfma_grad_supported(op, batch) && rbf_mode(op) == MFX_RBF_F16X3 && w.hws && fits32) {
-      MFX_TRY(rbf_mfma_grad_h(op, (const float*)w.xs, (const float*)w.sq, dpad, L, ldl, R, ldr, batch, w.partial, &nblocks,
+      MFX_TRY(rbf_mfma_grad_h(op, (const float*)w.xs, (const float*)w.sq, dpad, L, ldl, R, ldr, batch, inner, w.partial, &nblocks,
                               w.hws, &scales, stream));
       done = true;
     } else if (rbf_mfma_grad_supported(op, batch)) {
@@ -496,7 +506,7 @@ static int rbf_grad(const mfx_operator* op, const T* L, int64_t ldl, const T* R,
   if (!done) {
 #define MFX_RBF_GRAD(D)                                                                                    \
   k_rbf_grad<T, D><<<(unsigned)nblocks, 256, 0, stream>>>((const T*)w.xs, (const T*)w.sq, op->n, op->ard, op->kernel_fn, L, ldl, R, \
-                                                           ldr, batch, w.partial)
+                                                           ldr, batch, w.partial, row0, nrow)
     switch (dpad) {
       case 4: MFX_RBF_GRAD(4); break;
       case 8: MFX_RBF_GRAD(8); break;
@@ -526,29 +536,32 @@ template <typename T>
 static int op_apply_t(const mfx_operator* op, const T* x, int64_t ldx, T* y, int64_t ldy, int64_t p, int transpose,
                       void* ws, int64_t ws_bytes, hipStream_t stream) {
   const int64_t n = op->n;
+  const int64_t row0 = op_row0(op), nrow = op_nrows(op);
+  MFX_REQUIRE(row0 >= 0 && nrow >= 1 && row0 + nrow <= n, MFX_ERR_INVALID, "row block [%lld, +%lld) outside the operator (n = %lld)",
+              (long long)row0, (long long)nrow, (long long)n);
   switch (op->kind) {
     case MFX_OP_DENSE: {
       MFX_REQUIRE(op->dense_a, MFX_ERR_INVALID, "dense operator without matrix");
       constexpr int PB = 4;
       if (!transpose) {
-        k_dense_apply<T, PB><<<dim3((unsigned)((n + 3) / 4), (unsigned)((p + PB - 1) / PB)), 256, 0, stream>>>(
-            (const T*)op->dense_a, op->lda, n, x, ldx, y, ldy, p);
+        k_dense_apply<T, PB><<<dim3((unsigned)((nrow + 3) / 4), (unsigned)((p + PB - 1) / PB)), 256, 0, stream>>>(
+            (const T*)op->dense_a, op->lda, n, x, ldx, y, ldy, p, row0, nrow);
       } else {
-        k_dense_apply_t<T, PB><<<dim3((unsigned)((n + 63) / 64), (unsigned)((p + PB - 1) / PB)), 256, 0, stream>>>(
-            (const T*)op->dense_a, op->lda, n, x, ldx, y, ldy, p);
+        k_dense_apply_t<T, PB><<<dim3((unsigned)((nrow + 63) / 64), (unsigned)((p + PB - 1) / PB)), 256, 0, stream>>>(
+            (const T*)op->dense_a, op->lda, n, x, ldx, y, ldy, p, row0, nrow);
       }
       MFX_CHECK_LAUNCH();
       return MFX_OK;
     }
     case MFX_OP_CSR: {
       MFX_REQUIRE(op->crow && op->col && op->val, MFX_ERR_INVALID, "CSR operator without structure");
-      const dim3 grid((unsigned)((n + 31) / 32), (unsigned)p);
+      const dim3 grid((unsigned)((nrow + 31) / 32), (unsigned)p);
       if (!transpose) {
-        k_csr_apply<T><<<grid, 256, 0, stream>>>(op->crow, op->col, nullptr, (const T*)op->val, n, x, ldx, y, ldy);
+        k_csr_apply<T><<<grid, 256, 0, stream>>>(op->crow, op->col, nullptr, (const T*)op->val, nrow, x, ldx, y, ldy, row0);
       } else {
         MFX_REQUIRE(op->t_crow && op->t_col && op->t_perm, MFX_ERR_INVALID,
                     "CSR transpose structure required for the Arnoldi adjoint");
-        k_csr_apply<T><<<grid, 256, 0, stream>>>(op->t_crow, op->t_col, op->t_perm, (const T*)op->val, n, x, ldx, y, ldy);
+        k_csr_apply<T><<<grid, 256, 0, stream>>>(op->t_crow, op->t_col, op->t_perm, (const T*)op->val, nrow, x, ldx, y, ldy, row0);
       }
       MFX_CHECK_LAUNCH();
       return MFX_OK;
@@ -582,25 +595,28 @@ int op_apply_cb(const mfx_operator* op, int mode, const void* x, int64_t ldx, co
 
 template <typename T>
 static int op_vjp_params_t(const mfx_operator* op, const T* L, int64_t ldl, const T* R, int64_t ldr, int64_t batch,
-                           const mfx_op_grads* grads, void* ws, int64_t ws_bytes, hipStream_t stream) {
+                           int64_t inner, const mfx_op_grads* grads, void* ws, int64_t ws_bytes, hipStream_t stream) {
   const int64_t n = op->n;
+  const int64_t row0 = op_row0(op), nrow = op_nrows(op);
+  MFX_REQUIRE(row0 >= 0 && nrow >= 1 && row0 + nrow <= n, MFX_ERR_INVALID, "row block [%lld, +%lld) outside the operator (n = %lld)",
+              (long long)row0, (long long)nrow, (long long)n);
   switch (op->kind) {
     case MFX_OP_DENSE:
       if (!grads->dense_a) return MFX_OK;
-      k_dense_grad<T><<<dim3((unsigned)((n + 15) / 16), (unsigned)((n + 15) / 16)), 256, 0, stream>>>(
-          L, ldl, R, ldr, batch, n, (T*)grads->dense_a);
+      k_dense_grad<T><<<dim3((unsigned)((n + 15) / 16), (unsigned)((nrow + 15) / 16)), 256, 0, stream>>>(
+          L, ldl, R, ldr, batch, n, (T*)grads->dense_a, row0, nrow);
       MFX_CHECK_LAUNCH();
       return MFX_OK;
     case MFX_OP_CSR:
       if (!grads->val) return MFX_OK;
       MFX_REQUIRE(op->row && op->col, MFX_ERR_INVALID, "CSR gradient needs the COO row index");
       k_csr_grad<T><<<(unsigned)((op->nnz + 255) / 256), 256, 0, stream>>>(op->row, op->col, op->nnz, L, ldl, R, ldr,
-                                                                         batch, (T*)grads->val);
+                                                                         batch, (T*)grads->val, row0, nrow);
       MFX_CHECK_LAUNCH();
       return MFX_OK;
     case MFX_OP_RBF:
       if (!grads->lengthscale && !grads->outputscale && !grads->noise) return MFX_OK;
-      return rbf_grad<T>(op, L, ldl, R, ldr, batch, grads, ws, ws_bytes, stream);
+      return rbf_grad<T>(op, L, ldl, R, ldr, batch, inner, grads, ws, ws_bytes, stream);
     default:
       set_error("unknown operator kind %d", op->kind);
       return MFX_ERR_UNSUPPORTED;
@@ -608,11 +624,11 @@ static int op_vjp_params_t(const mfx_operator* op, const T* L, int64_t ldl, cons
 }
 
 int op_vjp_params(const mfx_operator* op, const void* L, int64_t ldl, const void* R, int64_t ldr, int64_t batch,
-                  const mfx_op_grads* grads, void* ws, int64_t ws_bytes, hipStream_t stream) {
+                  const mfx_op_grads* grads, void* ws, int64_t ws_bytes, hipStream_t stream, int64_t inner) {
   if (op->dtype == MFX_F32)
-    return op_vjp_params_t<float>(op, (const float*)L, ldl, (const float*)R, ldr, batch, grads, ws, ws_bytes, stream);
+    return op_vjp_params_t<float>(op, (const float*)L, ldl, (const float*)R, ldr, batch, inner, grads, ws, ws_bytes, stream);
   if (op->dtype == MFX_F64)
-    return op_vjp_params_t<double>(op, (const double*)L, ldl, (const double*)R, ldr, batch, grads, ws, ws_bytes, stream);
+    return op_vjp_params_t<double>(op, (const double*)L, ldl, (const double*)R, ldr, batch, inner, grads, ws, ws_bytes, stream);
   set_error("unsupported dtype %d", op->dtype);
   return MFX_ERR_UNSUPPORTED;
 }

@@ -117,14 +117,16 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply(const float* __restri
                                                            int64_t n, const float* __restrict__ outputscale,
                                                            const float* __restrict__ noise,
                                                            const float* __restrict__ x, int64_t ldx,
-                                                           float* __restrict__ y, int64_t ldy, int64_t p, int kind) {
+                                                           float* __restrict__ y, int64_t ldy, int64_t p, int kind,
+                                                           int64_t row0, int64_t rend) {
+  // rows [row0, rend) of the operator (a row shard, or all of it): x has the full length n, y is indexed from row0
   using Tile = RbfTile<DPAD, NB, kTJ>;
   const float cfac = dist_factor(kind);
   constexpr int KD = Tile::KD, KS = KD / 2;
   __shared__ __attribute__((aligned(16))) Tile tile[2];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
-  const int64_t i_wave = (int64_t)blockIdx.x * (4 * kMI * 32) + (int64_t)wid * (kMI * 32);
+  const int64_t i_wave = row0 + (int64_t)blockIdx.x * (4 * kMI * 32) + (int64_t)wid * (kMI * 32);
   const int64_t b0 = (int64_t)blockIdx.y * (NB * 32);
 
   // B operand of the distance product: B_i[k], k = 2 s + lhi
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply(const float* __restri
 #pragma unroll
   for (int mi = 0; mi < kMI; ++mi) {
     int64_t i = i_wave + mi * 32 + l31;
-    if (i >= n) i = n - 1;
+    if (i >= rend) i = rend - 1;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int k = 2 * s + lhi;
@@ -261,18 +263,18 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply(const float* __restri
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int64_t i = i_wave + mi * 32 + 8 * g + 4 * lhi;
-        if (VEC4 && i + 3 < n) {
+        if (VEC4 && i + 3 < rend) {
           const float4 xv = *reinterpret_cast<const float4*>(x + b * ldx + i);
           float4 o;
           o.x = fmaf(s, acc[mi][nb][4 * g + 0], nz * xv.x);
           o.y = fmaf(s, acc[mi][nb][4 * g + 1], nz * xv.y);
           o.z = fmaf(s, acc[mi][nb][4 * g + 2], nz * xv.z);
           o.w = fmaf(s, acc[mi][nb][4 * g + 3], nz * xv.w);
-          *reinterpret_cast<float4*>(y + b * ldy + i) = o;
+          *reinterpret_cast<float4*>(y + b * ldy + (i - row0)) = o;
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            if (i + e < n) y[b * ldy + i + e] = fmaf(s, acc[mi][nb][4 * g + e], nz * x[b * ldx + i + e]);
+            if (i + e < rend) y[b * ldy + (i - row0) + e] = fmaf(s, acc[mi][nb][4 * g + e], nz * x[b * ldx + i + e]);
         }
       }
     }
@@ -331,7 +333,7 @@ __global__ void k_row_scale_from_bits(const unsigned* __restrict__ amax_bits, in
   float s = 1.f;
   if (m > 0.f && m < 3.0e38f) {
     frexpf(m, &e);  // m = f * 2^e, f in [0.5, 1)
-    s = ldexpf(1.f, 14 - e);
+    s = ldexpf(1.f, 14 - e < 126 ? 14 - e : 126);  // tiny / denormal rows (|max| < 2^-112): keep s and 1/s finite and normal
   }
   scale[2 * b] = s;
   scale[2 * b + 1] = 1.f / s;
@@ -426,7 +428,9 @@ __global__ __launch_bounds__(64 * H3Waves<PK>::value, PK ? 1 : 2) void k_rbf_mfm
                                                               float* __restrict__ y, int64_t ldy, int64_t p,
                                                               const uintx4* __restrict__ pkv, const uintx4* __restrict__ pka,
                                                               float* __restrict__ part, const int* __restrict__ rangeflag,
-                                                              int64_t ldpart) {
+                                                              int64_t ldpart, int64_t row0, int64_t rend) {
+  // rows [row0, rend) of the operator (a row shard, or all of it; row0 % 64 == 0): x and the packed tile images cover all n
+  // columns, y / part are indexed from row0
   static_assert(!PK || DH, "pre-packed operands exist for the f16-distance variant only");
   // f16 range guard: when a scaled input is too large for the f16 image of the distance operands (|x/l|^2 beyond ~6e4 / |c|),
   // k_pack_tiles raises the flag; the f16-distance launch then returns at once and the fp32-distance launch behind it does
@@ -442,7 +446,7 @@ __global__ __launch_bounds__(64 * H3Waves<PK>::value, PK ? 1 : 2) void k_rbf_mfm
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
   constexpr int WV = H3Waves<PK>::value;
-  const int64_t i_wave = (int64_t)blockIdx.x * (WV * kMI * 32) + (int64_t)wid * (kMI * 32);
+  const int64_t i_wave = row0 + (int64_t)blockIdx.x * (WV * kMI * 32) + (int64_t)wid * (kMI * 32);
   const int64_t b0 = (int64_t)blockIdx.y * (NB * 32);
 
   // B operand of the distance product, resident in registers: [x_i, 1, |x_i|^2].
@@ -455,7 +459,7 @@ __global__ __launch_bounds__(64 * H3Waves<PK>::value, PK ? 1 : 2) void k_rbf_mfm
 #pragma unroll
   for (int mi = 0; mi < kMI; ++mi) {
     int64_t i = i_wave + mi * 32 + l31;
-    if (i >= n) i = n - 1;
+    if (i >= rend) i = rend - 1;
     if constexpr (DH) {
 #pragma unroll
       for (int q = 0; q < NKD; ++q)
@@ -524,7 +528,7 @@ __global__ __launch_bounds__(64 * H3Waves<PK>::value, PK ? 1 : 2) void k_rbf_mfm
   for (int u = 0; u < kVPT; ++u) {
     const int f = tid + 256 * u;
     const int64_t b = b0 + f / (kTJ / 4);
-    vs[u] = (f < kF4 && b < p) ? vscale[2 * b] : 0.f;
+    vs[u] = (f < kF4 && b < p) ? ((blockIdx.z & 1) ? -vscale[2 * b] : vscale[2 * b]) : 0.f;  // odd column splits: negated tile
   }
 
   auto load_tile = [&](int64_t j0) {
@@ -872,18 +876,18 @@ __global__ __launch_bounds__(64 * H3Waves<PK>::value, PK ? 1 : 2) void k_rbf_mfm
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int64_t i = i_wave + mi * 32 + 8 * g + 4 * lhi;
-        if (VEC4 && i + 3 < n) {
+        if (VEC4 && i + 3 < rend) {
           const float4 xv = *reinterpret_cast<const float4*>(x + b * ldx + i);
           float4 o;
           o.x = fmaf(sb, acc[mi][nb][4 * g + 0], nz * xv.x);
           o.y = fmaf(sb, acc[mi][nb][4 * g + 1], nz * xv.y);
           o.z = fmaf(sb, acc[mi][nb][4 * g + 2], nz * xv.z);
           o.w = fmaf(sb, acc[mi][nb][4 * g + 3], nz * xv.w);
-          *reinterpret_cast<float4*>(yout + b * ldo + i) = o;
+          *reinterpret_cast<float4*>(yout + b * ldo + (i - row0)) = o;
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            if (i + e < n) yout[b * ldo + i + e] = fmaf(sb, acc[mi][nb][4 * g + e], nz * x[b * ldx + i + e]);
+            if (i + e < rend) yout[b * ldo + (i - row0) + e] = fmaf(sb, acc[mi][nb][4 * g + e], nz * x[b * ldx + i + e]);
         }
       }
     }
@@ -891,13 +895,18 @@ __global__ __launch_bounds__(64 * H3Waves<PK>::value, PK ? 1 : 2) void k_rbf_mfm
 
 // y = sum_z part[z] + noise x   (fixed summation order: deterministic)
 __global__ __launch_bounds__(256) void k_split_reduce(const float* __restrict__ part, int64_t ldpart, int nsplit, int64_t p,
-                                                      int64_t n, int64_t ldy, const float* __restrict__ noise,
-                                                      const float* __restrict__ x, int64_t ldx, float* __restrict__ y) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-  if (i >= n) return;
+                                                      int64_t nrow, int64_t ldy, const float* __restrict__ noise,
+                                                      const float* __restrict__ x, int64_t ldx, float* __restrict__ y,
+                                                      int64_t row0) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;  // local row: the point is row0 + i
+  if (i >= nrow) return;
   float acc = 0.f;
-  for (int z = 0; z < nsplit; ++z) acc += part[((int64_t)z * p + b) * ldpart + i];
-  y[b * ldy + i] = fmaf(noise[0], x[b * ldx + i], acc);
+  for (int z = 0; z < nsplit; z += 2) {  // odd splits hold the negated partial sum
+    const float pe = part[((int64_t)z * p + b) * ldpart + i];
+    const float po = z + 1 < nsplit ? part[((int64_t)(z + 1) * p + b) * ldpart + i] : 0.f;
+    acc += pe - po;
+  }
+  y[b * ldy + i] = fmaf(noise[0], x[b * ldx + row0 + i], acc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -907,11 +916,19 @@ __global__ __launch_bounds__(256) void k_split_reduce(const float* __restrict__ 
 //   column operand pka[tile][j][AROW] : [Ah | Ah | Al | 0] of c [-2 x_j, |x_j|^2 (+ shift or eps), 1], odd 32-column block negated
 // grid (ntile, chunks + 1): blockIdx.y < chunks packs that probe chunk, the last one the column operand.
 // ------------------------------------------------------------------------------------------------
+// column split z owns the tiles [ntile z / nsplit, ntile (z + 1) / nsplit): the split of tile t
+__device__ __forceinline__ int split_of_tile(int64_t t, int64_t ntile, int nsplit) {
+  int z = (int)((t * nsplit) / ntile);
+  while (z + 1 < nsplit && ntile * (z + 1) / nsplit <= t) ++z;
+  while (z > 0 && ntile * z / nsplit > t) --z;
+  return z;
+}
+
 template <int DPAD, int NB, int KIND>
 __global__ __launch_bounds__(256) void k_pack_tiles(const float* __restrict__ xs, const float* __restrict__ sq, int64_t n,
                                                     const float* __restrict__ vscale, const float* __restrict__ x,
                                                     int64_t ldx, int64_t p, uintx4* __restrict__ pkv,
-                                                    uintx4* __restrict__ pka, int* __restrict__ rangeflag) {
+                                                    uintx4* __restrict__ pka, int* __restrict__ rangeflag, int nsplit) {
   constexpr int kTJ = 64;
   using Tile = RbfTileH3<DPAD, NB, kTJ>;
   constexpr int KD = Tile::KD, P = Tile::P, AROW = Tile::AROW;
@@ -929,7 +946,8 @@ __global__ __launch_bounds__(256) void k_pack_tiles(const float* __restrict__ xs
       const int jb = row >> 2, s = (row >> 1) & 1, h = row & 1;
       const int64_t b = b0 + bq;
       half8 hh, ll;
-      const float vs = b < p ? vscale[2 * b] : 0.f;
+      // odd column splits sweep the NEGATED probe tile (see the sign note at rbf_split_count)
+      const float vs = b < p ? ((split_of_tile(t, ntile, nsplit) & 1) ? -vscale[2 * b] : vscale[2 * b]) : 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int64_t j = j0 + 32 * jb + 16 * s + 8 * (e >> 2) + 4 * h + (e & 3);
@@ -967,8 +985,16 @@ __global__ __launch_bounds__(256) void k_pack_tiles(const float* __restrict__ xs
   }
 }
 
-// column splits of the pipelined matvec: enough workgroups for two per CU, at least 8 tiles each, at most 8 splits
-static int rbf_split_count(int64_t n, int64_t p) {
+// column splits of the pipelined matvec.  Two reasons to split the sweep over the n columns (grid.z):
+//  (1) occupancy: too few 512-row workgroups to fill 256 CUs (small n, or a row shard of a large n);
+//  (2) accuracy: the f16 MFMA aligns its addends with a few guard bits and truncates towards -infinity, so an accumulator that
+//      grows monotonically -- Krylov vectors are dominated by the smooth leading eigenvectors of an all-positive kernel matrix --
+//      picks up a bias proportional to the length of its MFMA chain (tools/diag_matvec_bias.py, tools/mfma_f16_trunc.hip:
+//      -8.7e-5 relative for a constant vector over 2048 tiles at n = 131072; the SLQ gradient at that size was 4.4e-4 off).
+//      Chains are therefore cut to <= kMaxChainTiles tiles, and ODD splits sweep the NEGATED probe tile: their partial sums carry
+//      the floor bias with the opposite sign and k_split_reduce subtracts them, so the biases of neighbouring splits cancel.
+constexpr int kMaxChainTiles = 128;
+static int rbf_split_count(int64_t nrow, int64_t n, int64_t p) {
   // 512-row workgroups of 8 waves, one per CU and round.  With s column splits the launch takes ceil(wgs s / 256) rounds of 1/s of the
   // columns each: pick the s (at most 16, at least 8 tiles per split) that minimises rounds / s, plus a small charge per split for the
   // prologue and the partial sums.  (n = 45 730: 90 row blocks -> s = 8, 720 workgroups in 3 rounds = 0.375 of an unsplit launch,
@@ -977,21 +1003,27 @@ static int rbf_split_count(int64_t n, int64_t p) {
     const char* e = getenv("MFX_RBF_SPLIT");  // A/B: force the split count
     return e ? atoi(e) : 0;
   }();
-  const int64_t wgs = ((n + 511) / 512) * ((p + (p <= 32 ? 32 : 64) - 1) / (p <= 32 ? 32 : 64));
-  int64_t smax = ((n + 63) / 64) / 8;
-  if (forced > 0) return forced <= 16 && forced <= (n + 63) / 64 ? forced : 1;
+  const int64_t wgs = ((nrow + 511) / 512) * ((p + (p <= 32 ? 32 : 64) - 1) / (p <= 32 ? 32 : 64));
+  const int64_t ntile = (n + 63) / 64;
+  int64_t smax = ntile / 8;
+  if (forced > 0) return forced <= 16 && forced <= ntile ? forced : 1;
   if (smax > 16) smax = 16;
-  if (smax < 1 || wgs >= 2048) return 1;
+  if (smax < 1) return 1;
   int best = 1;
-  double best_cost = 1e30;
-  for (int s = 1; s <= (int)smax; ++s) {
-    const double rounds = (double)((wgs * s + 255) / 256);
-    const double cost = rounds / s + 0.004 * s;
-    if (cost < best_cost - 1e-12) {
-      best_cost = cost;
-      best = s;
+  if (wgs < 2048) {
+    double best_cost = 1e30;
+    for (int s = 1; s <= (int)smax; ++s) {
+      const double rounds = (double)((wgs * s + 255) / 256);
+      const double cost = rounds / s + 0.004 * s;
+      if (cost < best_cost - 1e-12) {
+        best_cost = cost;
+        best = s;
+      }
     }
   }
+  const int64_t s_acc = (ntile + kMaxChainTiles - 1) / kMaxChainTiles;  // reason (2)
+  if (best < s_acc) best = (int)(s_acc < smax ? s_acc : smax);
+  if (best > 1 && (best & 1) && best < smax) ++best;  // pairs of (+, -) splits
   return best;
 }
 
@@ -1005,7 +1037,7 @@ int64_t rbf_pack_ws_bytes(const mfx_operator* op, int64_t p) {
   const int dpad = op->d <= 4 ? 4 : op->d <= 8 ? 8 : op->d <= 12 ? 12 : 16;
   const int64_t arow = ((3 * (dpad + 2) + 15) / 16) * 16 + 8;
   return align_up(rbf_pack_bytes_v(op->n, p), 256) + align_up(ntile * 64 * arow * 2, 256) +
-         align_up((int64_t)rbf_split_count(op->n, p) * p * align_up(op->n, 4) * 4, 256);
+         align_up((int64_t)rbf_split_count(op_nrows(op), op->n, p) * p * align_up(op_nrows(op), 4) * 4, 256);
 }
 
 // distances of the pipelined kernel on the f16 matrix pipe (3-product split, alternating block sign: default) or on the
@@ -1032,10 +1064,12 @@ template <int DPAD, int NB, int KIND>
 static int launch_apply_h3k(const mfx_operator* op, const float* xs, const float* sq, const float* x, int64_t ldx,
                             float* y, int64_t ldy, int64_t p, float* vscale, void* pk, hipStream_t stream) {
   const int64_t n = op->n;
+  const int64_t row0 = op_row0(op), nrow = op_nrows(op), rend = row0 + nrow;
+  MFX_REQUIRE(row0 % 64 == 0, MFX_ERR_INVALID, "matrix-core Gram matvec: row0 = %lld must be a multiple of 64", (long long)row0);
   MFX_TRY(row_scales(x, ldx, n, p, vscale, stream));
   const unsigned chunks = (unsigned)((p + NB * 32 - 1) / (NB * 32));
-  const dim3 grid((unsigned)((n + 255) / 256), chunks);  // 4-wave workgroups (256 rows); the pre-packed variant uses grid_pk
-  const bool vec4 = (n % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) &&
+  const dim3 grid((unsigned)((nrow + 255) / 256), chunks);  // 4-wave workgroups (256 rows); the pre-packed variant uses grid_pk
+  const bool vec4 = (n % 4 == 0) && (nrow % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) &&
                     (reinterpret_cast<uintptr_t>(y) % 16 == 0);
   const bool pack = rbf_dist_f16() && rbf_prepack() && pk != nullptr;
   uintx4* pkv = nullptr;
@@ -1044,20 +1078,20 @@ static int launch_apply_h3k(const mfx_operator* op, const float* xs, const float
   const int64_t off_a = align_up((int64_t)chunks * ntile * 2 * 8 * NB * 32 * 16, 256);
   const int64_t arow = ((3 * (DPAD + 2) + 15) / 16) * 16 + 8;
   float* part = pk ? reinterpret_cast<float*>(static_cast<char*>(pk) + off_a + align_up(ntile * 64 * arow * 2, 256)) : nullptr;
-  const int64_t ldpart = align_up(n, 4);  // the partials have their own stride (any n, any ldy)
-  const int nsplit = part ? rbf_split_count(n, p) : 1;
+  const int64_t ldpart = align_up(nrow, 4);  // the partials have their own stride (any n, any ldy)
+  const int nsplit = part ? rbf_split_count(nrow, n, p) : 1;
   const dim3 grid3(grid.x, grid.y, (unsigned)nsplit);
-  const dim3 grid_pk((unsigned)((n + 511) / 512), grid.y, (unsigned)nsplit);
+  const dim3 grid_pk((unsigned)((nrow + 511) / 512), grid.y, (unsigned)nsplit);
   int* rangeflag = reinterpret_cast<int*>(vscale + 3 * p);  // zeroed by row_scales
   if (pack) {
     pkv = static_cast<uintx4*>(pk);
     pka = reinterpret_cast<uintx4*>(static_cast<char*>(pk) + off_a);
-    k_pack_tiles<DPAD, NB, KIND><<<dim3((unsigned)ntile, chunks + 1), 256, 0, stream>>>(xs, sq, n, vscale, x, ldx, p, pkv, pka, rangeflag);
+    k_pack_tiles<DPAD, NB, KIND><<<dim3((unsigned)ntile, chunks + 1), 256, 0, stream>>>(xs, sq, n, vscale, x, ldx, p, pkv, pka, rangeflag, nsplit);
     MFX_CHECK_LAUNCH();
   }
 #define MFX_H3_LAUNCH(V4, DHV, PKV, FLAG)                                                                            \
   k_rbf_mfma_apply_h3<DPAD, NB, V4, KIND, DHV, PKV><<<(PKV) ? grid_pk : grid3, 64 * H3Waves<PKV>::value, 0, stream>>>(xs, sq, n, (const float*)op->outputscale, \
-                                                                                (const float*)op->noise, vscale, x, ldx, y, ldy, p, pkv, pka, part, FLAG, ldpart)
+                                                                                (const float*)op->noise, vscale, x, ldx, y, ldy, p, pkv, pka, part, FLAG, ldpart, row0, rend)
   if (pack) {
     if (vec4) MFX_H3_LAUNCH(true, true, true, rangeflag); else MFX_H3_LAUNCH(false, true, true, rangeflag);
     if (vec4) MFX_H3_LAUNCH(true, false, false, rangeflag); else MFX_H3_LAUNCH(false, false, false, rangeflag);  // runs only if flagged
@@ -1067,8 +1101,8 @@ static int launch_apply_h3k(const mfx_operator* op, const float* xs, const float
 #undef MFX_H3_LAUNCH
   MFX_CHECK_LAUNCH();
   if (nsplit > 1) {
-    k_split_reduce<<<dim3((unsigned)((n + 255) / 256), (unsigned)p), 256, 0, stream>>>(part, ldpart, nsplit, p, n, ldy,
-                                                                                     (const float*)op->noise, x, ldx, y);
+    k_split_reduce<<<dim3((unsigned)((nrow + 255) / 256), (unsigned)p), 256, 0, stream>>>(part, ldpart, nsplit, p, nrow, ldy,
+                                                                                        (const float*)op->noise, x, ldx, y, row0);
     MFX_CHECK_LAUNCH();
   }
   return MFX_OK;
@@ -1139,28 +1173,54 @@ __global__ void k_global_scale(const float* __restrict__ amax, int64_t rows, flo
     float s = 1.f;
     if (sm[0] > 0.f && sm[0] < 3.0e38f) {
       frexpf(sm[0], &e);
-      s = ldexpf(1.f, 14 - e);
+      s = ldexpf(1.f, 14 - e < 126 ? 14 - e : 126);
     }
     scale[0] = s;
     scale[1] = 1.f / s;
   }
 }
 
-// hi/lo packs: out[(kb * npad + i) * 8 + q] = piece of scale * x[8 kb + q][i]
-// sign_period > 0: rows of every other block of `sign_period` batch rows are stored NEGATED (see kGChunk)
+// Pseudo-random sign of column i of a packed gradient-GEMM operand (salt: which operand).  Column i of L carries sigma_i,
+// column j of R carries tau_j, so the accumulator of S_ij holds sigma_i tau_j S_ij and the epilogue undoes the sign.
+// Why: the f16 MFMA's floor bias (see kGChunk below) is the SAME sign in every accumulator; with the operands' columns signed
+// at random it enters S_ij as -sigma_i tau_j beta ulp -- sign-random over (i, j), uncorrelated with dK_ij/dtheta -- and
+// sums like noise (~ |dK|_F) instead of coherently (~ sum_ij dK_ij, n times larger).  Measured: profiles/r02a_*.
+__host__ __device__ __forceinline__ bool grad_col_sign(int64_t i, uint32_t salt) {
+  if (salt == 0u) return false;  // MFX_RBF_GRAD_SIGNS=0 (A/B runs): no column signs
+  uint32_t h = (uint32_t)i * 0x9E3779B1u + salt;
+  h ^= h >> 15;
+  h *= 0x85EBCA77u;
+  h ^= h >> 13;
+  h *= 0xC2B2AE3Du;
+  return (h >> 31) != 0;
+}
+constexpr uint32_t kSaltL = 0x51ED270Bu, kSaltR = 0xB5297A4Du;
+
+// hi/lo packs: out[(kb * npad + i) * 8 + q] = piece of (+-) scale * x[8 kb + q][i], sign per column i = grad_col_sign(i, salt)
+// sign_period > 0: rows of every other block of `sign_period` batch rows are additionally stored NEGATED (see kGChunk)
+// inner > 1: the source rows come as (batch / inner) groups of `inner` rows -- (probe, Krylov step) -- and are packed
+// TRANSPOSED, (step, probe): the 16 rows that meet in one MFMA then belong to the same step of different probes and have
+// similar magnitudes.  Why it matters: the f16 MFMA aligns the 16 products of an output element to the largest of them and
+// truncates the others TOWARDS ZERO (tools/mfma_f16_trunc.hip), and the adjoint states of different steps differ by orders of
+// magnitude -- with (probe, step) order every small product lost bits, always in the direction that shrinks its contribution,
+// a sign-symmetric bias that no sign alternation can cancel (1.6e-4 / 4.3e-4 gradient error at n = 65536).
 __global__ __launch_bounds__(256) void k_pack_f16(const float* __restrict__ x, int64_t ldx, int64_t batch, int64_t n,
                                                   int64_t npad, const float* __restrict__ scale, int sign_period,
-                                                  _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
+                                                  uint32_t salt, int64_t inner, _Float16* __restrict__ hi,
+                                                  _Float16* __restrict__ lo) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t kb = blockIdx.y;
   if (i >= npad) return;
   float s = scale[0];
   if (sign_period > 0 && ((kb * 8 / sign_period) & 1)) s = -s;
+  if (grad_col_sign(i, salt)) s = -s;
   half8 h, l;
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const int64_t bt = kb * 8 + q;
-    const float v = (bt < batch && i < n) ? x[bt * ldx + i] * s : 0.f;
+    const int64_t outer = batch / inner;
+    const int64_t src = inner > 1 ? (bt % outer) * inner + bt / outer : bt;
+    const float v = (bt < batch && i < n) ? x[src * ldx + i] * s : 0.f;
     float fh, fl;
     split_hi_lo(v, fh, fl);
     h[q] = (_Float16)fh;
@@ -1190,6 +1250,7 @@ struct GradSmemH {
   float sqi[kHM];
   float xj[kGN][DPAD];
   float sqj[kGN];
+  float sgj[kGN];  // tau_j of the staged column tile (+-1)
   double red[8][DPAD + 2];
 };
 
@@ -1204,11 +1265,13 @@ constexpr int kGChunk = 8;
 
 template <int DPAD>
 __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restrict__ xs, const float* __restrict__ sq,
-                                                            int64_t n, int64_t npad, int ard, int kind,
+                                                            int64_t n, int64_t npad_l, int64_t npad_r, int ard, int kind,
                                                             const _Float16* __restrict__ Lh, const _Float16* __restrict__ Ll,
                                                             const _Float16* __restrict__ Rh, const _Float16* __restrict__ Rl,
                                                             int64_t nkb /* batch_pad / 8 */, int tiles_per_block,
-                                                            double* __restrict__ partial) {
+                                                            uint32_t salt_l, uint32_t salt_r, double* __restrict__ partial,
+                                                            int64_t row0, int64_t nrow) {
+  // rows: the nrow points row0 .. of X that the L operand covers (a row shard, or all n); columns: all n points
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   GradSmemH<DPAD>& sm = *reinterpret_cast<GradSmemH<DPAD>*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1225,9 +1288,9 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
 
   for (int t = tid; t < kHM * DPAD; t += 512) {
     const int64_t g = i0 * DPAD + t;
-    (&sm.xi[0][0])[t] = g < n * DPAD ? xs[g] : 0.f;
+    (&sm.xi[0][0])[t] = g < nrow * DPAD ? xs[row0 * DPAD + g] : 0.f;
   }
-  if (tid < kHM) sm.sqi[tid] = (i0 + tid < n) ? sq[i0 + tid] : 0.f;
+  if (tid < kHM) sm.sqi[tid] = (i0 + tid < nrow) ? sq[row0 + i0 + tid] : 0.f;
 
   double gsum[DPAD + 2];
 #pragma unroll
@@ -1244,11 +1307,12 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
   // Pieces per stage (1 KiB = one wave-instruction): L hi / lo 2 kb-groups x 256 columns = 8 each, R hi / lo 2 x 128 = 4 each;
   // wave w copies L-hi piece w, L-lo piece w and one R piece (waves 0-3: hi, 4-7: lo): 3 glds per thread and stage.
   const int64_t nstage = nkb / 2;
-  const uint32_t stage_bytes = (uint32_t)(2 * npad * 16);  // 2 kb-groups of npad columns x 8 halves
+  const uint32_t stage_bytes_l = (uint32_t)(2 * npad_l * 16);  // 2 kb-groups of npad columns x 8 halves
+  const uint32_t stage_bytes_r = (uint32_t)(2 * npad_r * 16);
   const int cwa = wid * 64 + lane;                          // my chunk of an L piece: kb-group cwa >> 8, column cwa & 255
   const int cwb = (wid & 3) * 64 + lane;                    // my chunk of an R piece: kb-group cwb >> 7, column cwb & 127
-  const uint32_t offL = (uint32_t)((((int64_t)(cwa >> 8) * npad) + i0 + (cwa & 255)) * 16);
-  const uint32_t offR0 = (uint32_t)((((int64_t)(cwb >> 7) * npad) + (cwb & 127)) * 16);
+  const uint32_t offL = (uint32_t)((((int64_t)(cwa >> 8) * npad_l) + i0 + (cwa & 255)) * 16);
+  const uint32_t offR0 = (uint32_t)((((int64_t)(cwb >> 7) * npad_r) + (cwb & 127)) * 16);
   const char* Lhb = reinterpret_cast<const char*>(Lh);
   const char* Llb = reinterpret_cast<const char*>(Ll);
   const char* Rxb = reinterpret_cast<const char*>(wid < 4 ? Rh : Rl);
@@ -1277,8 +1341,8 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       if (q < nstage) issue_stage(ol, orr, q);
-      ol += stage_bytes;
-      orr += stage_bytes;
+      ol += stage_bytes_l;
+      orr += stage_bytes_r;
     }
     for (int64_t st = 0; st < nstage; ++st) {
       const int slot = (int)(st & 3);
@@ -1293,8 +1357,8 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
       }
       __builtin_amdgcn_s_barrier();
       if (st + 3 < nstage) issue_stage(ol, orr, (int)((st + 3) & 3));
-      ol += stage_bytes;
-      orr += stage_bytes;
+      ol += stage_bytes_l;
+      orr += stage_bytes_r;
       {
         half8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
@@ -1346,11 +1410,15 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
       const int64_t g = j0 * DPAD + t;
       (&sm.xj[0][0])[t] = g < n * DPAD ? xs[g] : 0.f;
     }
-    if (tid < kGN) sm.sqj[tid] = (j0 + tid < n) ? sq[j0 + tid] : 0.f;
+    if (tid < kGN) {
+      sm.sqj[tid] = (j0 + tid < n) ? sq[j0 + tid] : 0.f;
+      sm.sgj[tid] = grad_col_sign(j0 + tid, salt_r) ? -1.f : 1.f;
+    }
     __syncthreads();
     {
       const int il = tid & (kHM - 1), jh = (tid >> 8) * 64;
-      const int64_t i = i0 + il;
+      const int64_t i = row0 + i0 + il;  // the point; L / the packs are indexed by the local row i0 + il
+      const float sgi = grad_col_sign(i0 + il, salt_l) ? -1.f : 1.f;  // sigma_i: the accumulators hold sigma_i tau_j S_ij
       float xiv[DPAD];
 #pragma unroll
       for (int c = 0; c < DPAD; c += 4) {
@@ -1376,8 +1444,8 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
         for (int c = 0; c < DPAD; ++c) dot = fmaf(xiv[c], xjv[c], dot);
         float dist = fmaf(-2.f, dot, si + sm.sqj[jl]);
         dist = fmaxf(dist, 0.f);
-        const bool live = (i < n) && (j < n);
-        const float s_ij = live ? sm.u.s_t[jl][il] : 0.f;
+        const bool live = (i0 + il < nrow) && (j < n);
+        const float s_ij = live ? sm.u.s_t[jl][il] * (sgi * sm.sgj[jl]) : 0.f;
         float kv, wl;
         grad_weights(kind, i == j ? 0.f : dist, kv, wl);
         gt[DPAD] = fmaf(s_ij, kv, gt[DPAD]);
@@ -1421,33 +1489,38 @@ int64_t rbf_grad_h_ws_bytes(int64_t n, int64_t batch) {
 
 template <int DPAD>
 static int launch_grad_h(const mfx_operator* op, const float* xs, const float* sq, const float* L, int64_t ldl,
-                         const float* R, int64_t ldr, int64_t batch, double* partial, int64_t* nblocks_out,
+                         const float* R, int64_t ldr, int64_t batch, int64_t inner, double* partial, int64_t* nblocks_out,
                          void* hws, hipStream_t stream) {
-  const int64_t n = op->n;
-  const int64_t npad = (n + kHM - 1) / kHM * kHM, bpad = (batch + 31) / 32 * 32;
+  const int64_t n = op->n, row0 = op_row0(op), nrow = op_nrows(op);
+  const int64_t npad = (n + kHM - 1) / kHM * kHM, npad_l = (nrow + kHM - 1) / kHM * kHM, bpad = (batch + 31) / 32 * 32;
+  if (inner < 1 || batch % inner != 0) inner = 1;
   char* base = static_cast<char*>(hws);
   float* amaxL = reinterpret_cast<float*>(base);
   float* amaxR = amaxL + bpad;
   float* scl = amaxR + bpad;  // [sL, 1/sL, sR, 1/sR]
   _Float16* Lh = reinterpret_cast<_Float16*>(base + align_up(2 * bpad * 4 + 64, 256));
-  _Float16* Ll = Lh + bpad * npad;
-  _Float16* Rh = Ll + bpad * npad;
+  _Float16* Ll = Lh + bpad * npad_l;
+  _Float16* Rh = Ll + bpad * npad_l;
   _Float16* Rl = Rh + bpad * npad;
-  k_row_amax<<<(unsigned)batch, 256, 0, stream>>>(L, ldl, n, amaxL);
+  k_row_amax<<<(unsigned)batch, 256, 0, stream>>>(L, ldl, nrow, amaxL);
   k_row_amax<<<(unsigned)batch, 256, 0, stream>>>(R, ldr, n, amaxR);
   k_global_scale<<<1, 256, 0, stream>>>(amaxL, batch, scl);
   k_global_scale<<<1, 256, 0, stream>>>(amaxR, batch, scl + 2);
   const dim3 pgrid((unsigned)((npad + 255) / 256), (unsigned)(bpad / 8));
-  k_pack_f16<<<pgrid, 256, 0, stream>>>(L, ldl, batch, n, npad, scl, kGK * kGChunk, Lh, Ll);
-  k_pack_f16<<<pgrid, 256, 0, stream>>>(R, ldr, batch, n, npad, scl + 2, 0, Rh, Rl);
+  const dim3 pgrid_l((unsigned)((npad_l + 255) / 256), (unsigned)(bpad / 8));
+  static const bool signs = [] { const char* e = getenv("MFX_RBF_GRAD_SIGNS"); return e ? atoi(e) != 0 : true; }();
+  const uint32_t salt_l = signs ? kSaltL : 0u, salt_r = signs ? kSaltR : 0u;
+  k_pack_f16<<<pgrid_l, 256, 0, stream>>>(L, ldl, batch, nrow, npad_l, scl, kGK * kGChunk, salt_l, inner, Lh, Ll);
+  k_pack_f16<<<pgrid, 256, 0, stream>>>(R, ldr, batch, n, npad, scl + 2, 0, salt_r, inner, Rh, Rl);
   MFX_CHECK_LAUNCH();
-  const int64_t nti = (n + kHM - 1) / kHM, ntj = (n + kGN - 1) / kGN;
+  const int64_t nti = (nrow + kHM - 1) / kHM, ntj = (n + kGN - 1) / kGN;
   const int tiles_per_block = (int)((ntj + kGSplit * kGSub - 1) / (kGSplit * kGSub));
   const dim3 grid(kGSplit, (unsigned)(nti * kGSub));
   const size_t sh = sizeof(GradSmemH<DPAD>);
   MFX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rbf_mfma_grad_h<DPAD>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-  k_rbf_mfma_grad_h<DPAD><<<grid, 512, sh, stream>>>(xs, sq, n, npad, op->ard, op->kernel_fn, Lh, Ll, Rh, Rl, bpad / 8, tiles_per_block, partial);
+  k_rbf_mfma_grad_h<DPAD><<<grid, 512, sh, stream>>>(xs, sq, n, npad_l, npad, op->ard, op->kernel_fn, Lh, Ll, Rh, Rl, bpad / 8,
+                                                     tiles_per_block, salt_l, salt_r, partial, row0, nrow);
   MFX_CHECK_LAUNCH();
   *nblocks_out = nti * kGSub * kGSplit;
   return MFX_OK;
@@ -1455,15 +1528,15 @@ static int launch_grad_h(const mfx_operator* op, const float* xs, const float* s
 
 // returns the device pointer holding [sL, 1/sL, sR, 1/sR] through scales_out
 int rbf_mfma_grad_h(const mfx_operator* op, const float* xs, const float* sq, int dpad, const float* L, int64_t ldl,
-                    const float* R, int64_t ldr, int64_t batch, double* partial, int64_t* nblocks_out, void* hws,
+                    const float* R, int64_t ldr, int64_t batch, int64_t inner, double* partial, int64_t* nblocks_out, void* hws,
                     const float** scales_out, hipStream_t stream) {
   const int64_t bpad = (batch + 31) / 32 * 32;
   *scales_out = reinterpret_cast<const float*>(hws) + 2 * bpad;
   switch (dpad) {
-    case 4: return launch_grad_h<4>(op, xs, sq, L, ldl, R, ldr, batch, partial, nblocks_out, hws, stream);
-    case 8: return launch_grad_h<8>(op, xs, sq, L, ldl, R, ldr, batch, partial, nblocks_out, hws, stream);
-    case 12: return launch_grad_h<12>(op, xs, sq, L, ldl, R, ldr, batch, partial, nblocks_out, hws, stream);
-    case 16: return launch_grad_h<16>(op, xs, sq, L, ldl, R, ldr, batch, partial, nblocks_out, hws, stream);
+    case 4: return launch_grad_h<4>(op, xs, sq, L, ldl, R, ldr, batch, inner, partial, nblocks_out, hws, stream);
+    case 8: return launch_grad_h<8>(op, xs, sq, L, ldl, R, ldr, batch, inner, partial, nblocks_out, hws, stream);
+    case 12: return launch_grad_h<12>(op, xs, sq, L, ldl, R, ldr, batch, inner, partial, nblocks_out, hws, stream);
+    case 16: return launch_grad_h<16>(op, xs, sq, L, ldl, R, ldr, batch, inner, partial, nblocks_out, hws, stream);
     default: set_error("RBF MFMA path supports d <= 16"); return MFX_ERR_UNSUPPORTED;
   }
 }
@@ -1484,15 +1557,17 @@ template <int DPAD, int NB, int MI, int TJ>
 static int launch_apply_mi(const mfx_operator* op, const float* xs, const float* sq, const float* x, int64_t ldx,
                            float* y, int64_t ldy, int64_t p, hipStream_t stream) {
   const int64_t n = op->n;
-  const dim3 grid((unsigned)((n + 4 * MI * 32 - 1) / (4 * MI * 32)), (unsigned)((p + NB * 32 - 1) / (NB * 32)));
-  const bool vec4 = (n % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) &&
+  const int64_t row0 = op_row0(op), nrow = op_nrows(op), rend = row0 + nrow;
+  MFX_REQUIRE(row0 % 64 == 0, MFX_ERR_INVALID, "matrix-core Gram matvec: row0 = %lld must be a multiple of 64", (long long)row0);
+  const dim3 grid((unsigned)((nrow + 4 * MI * 32 - 1) / (4 * MI * 32)), (unsigned)((p + NB * 32 - 1) / (NB * 32)));
+  const bool vec4 = (n % 4 == 0) && (nrow % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) &&
                     (reinterpret_cast<uintptr_t>(y) % 16 == 0);
   if (vec4) {
     k_rbf_mfma_apply<DPAD, NB, true, MI, TJ><<<grid, 256, 0, stream>>>(xs, sq, n, (const float*)op->outputscale,
-                                                                   (const float*)op->noise, x, ldx, y, ldy, p, op->kernel_fn);
+                                                                   (const float*)op->noise, x, ldx, y, ldy, p, op->kernel_fn, row0, rend);
   } else {
     k_rbf_mfma_apply<DPAD, NB, false, MI, TJ><<<grid, 256, 0, stream>>>(xs, sq, n, (const float*)op->outputscale,
-                                                                    (const float*)op->noise, x, ldx, y, ldy, p, op->kernel_fn);
+                                                                    (const float*)op->noise, x, ldx, y, ldy, p, op->kernel_fn, row0, rend);
   }
   MFX_CHECK_LAUNCH();
   return MFX_OK;
@@ -1503,7 +1578,7 @@ static int launch_apply(const mfx_operator* op, const float* xs, const float* sq
                         float* y, int64_t ldy, int64_t p, hipStream_t stream) {
   static const int mi_env = [] { const char* e = getenv("MFX_RBF_MI"); return e ? atoi(e) : 0; }();
   // 64 rows per wave (2 workgroups per CU at n = 131072) unless the problem is too small to fill the chip
-  const bool small = (op->n + 255) / 256 < 512;
+  const bool small = (op_nrows(op) + 255) / 256 < 512;
   static const int tj_env = [] { const char* e = getenv("MFX_RBF_TJ"); return e ? atoi(e) : 0; }();
   if (mi_env == 1 || (mi_env == 0 && small)) return launch_apply_mi<DPAD, NB, 1, 64>(op, xs, sq, x, ldx, y, ldy, p, stream);
   if (tj_env == 128) return launch_apply_mi<DPAD, NB, 2, 128>(op, xs, sq, x, ldx, y, ldy, p, stream);
@@ -1565,7 +1640,7 @@ struct GradSmem {
 template <int DPAD, bool VEC4>
 __device__ __forceinline__ void grad_load_stage(float4 (&ra)[4], float4 (&rb)[4], const float* __restrict__ L,
                                                 int64_t ldl, const float* __restrict__ R, int64_t ldr,
-                                                int64_t batch, int64_t n, int64_t bt0, int64_t i0, int64_t j0,
+                                                int64_t batch, int64_t nrow, int64_t n, int64_t bt0, int64_t i0, int64_t j0,
                                                 int tid) {
   // 32 rows x 128 floats = 1024 float4 per operand; thread t takes float4 (row = f / 32, col4 = f % 32)
 #pragma unroll
@@ -1577,13 +1652,13 @@ __device__ __forceinline__ void grad_load_stage(float4 (&ra)[4], float4 (&rb)[4]
     if (bt < batch) {
       const float* pa = L + bt * ldl + i0 + c4;
       const float* pb = R + bt * ldr + j0 + c4;
-      if (VEC4 && i0 + c4 + 3 < n) {
+      if (VEC4 && i0 + c4 + 3 < nrow) {
         va = *reinterpret_cast<const float4*>(pa);
       } else {
-        if (i0 + c4 + 0 < n) va.x = pa[0];
-        if (i0 + c4 + 1 < n) va.y = pa[1];
-        if (i0 + c4 + 2 < n) va.z = pa[2];
-        if (i0 + c4 + 3 < n) va.w = pa[3];
+        if (i0 + c4 + 0 < nrow) va.x = pa[0];
+        if (i0 + c4 + 1 < nrow) va.y = pa[1];
+        if (i0 + c4 + 2 < nrow) va.z = pa[2];
+        if (i0 + c4 + 3 < nrow) va.w = pa[3];
       }
       if (VEC4 && j0 + c4 + 3 < n) {
         vb = *reinterpret_cast<const float4*>(pb);
@@ -1604,7 +1679,8 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_grad(const float* __restric
                                                           int64_t n, int ard, int kind, const float* __restrict__ L,
                                                           int64_t ldl, const float* __restrict__ R, int64_t ldr,
                                                           int64_t batch, int tiles_per_block,
-                                                          double* __restrict__ partial) {
+                                                          double* __restrict__ partial, int64_t row0, int64_t nrow) {
+  // rows: the nrow points row0 .. of X that L covers (a row shard, or all n), L indexed locally; columns: all n points
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   GradSmem<DPAD>& sm = *reinterpret_cast<GradSmem<DPAD>*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1619,9 +1695,9 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_grad(const float* __restric
   // x_i, |x_i|^2 of this row tile (fixed for the workgroup)
   for (int t = tid; t < kGM * DPAD; t += 256) {
     const int64_t g = i0 * DPAD + t;
-    (&sm.xi[0][0])[t] = g < n * DPAD ? xs[g] : 0.f;
+    (&sm.xi[0][0])[t] = g < nrow * DPAD ? xs[row0 * DPAD + g] : 0.f;
   }
-  if (tid < kGM) sm.sqi[tid] = (i0 + tid < n) ? sq[i0 + tid] : 0.f;
+  if (tid < kGM) sm.sqi[tid] = (i0 + tid < nrow) ? sq[row0 + i0 + tid] : 0.f;
 
   double gsum[DPAD + 2];
 #pragma unroll
@@ -1639,7 +1715,7 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_grad(const float* __restric
         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     float4 ra[4], rb[4];
-    grad_load_stage<DPAD, VEC4>(ra, rb, L, ldl, R, ldr, batch, n, 0, i0, j0, tid);
+    grad_load_stage<DPAD, VEC4>(ra, rb, L, ldl, R, ldr, batch, nrow, n, 0, i0, j0, tid);
     __syncthreads();  // previous tile's epilogue / LDS reads are done
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -1650,7 +1726,7 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_grad(const float* __restric
     __syncthreads();
     for (int64_t st = 0; st < nstage; ++st) {
       const int cur = (int)(st & 1);
-      if (st + 1 < nstage) grad_load_stage<DPAD, VEC4>(ra, rb, L, ldl, R, ldr, batch, n, (st + 1) * kGK, i0, j0, tid);
+      if (st + 1 < nstage) grad_load_stage<DPAD, VEC4>(ra, rb, L, ldl, R, ldr, batch, nrow, n, (st + 1) * kGK, i0, j0, tid);
 #pragma unroll
       for (int kk = 0; kk < kGK; kk += 2) {
         float av[2], bv[2];
@@ -1694,7 +1770,7 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_grad(const float* __restric
     __syncthreads();
     {
       const int il = tid & (kGM - 1), jh = (tid >> 7) * 64;
-      const int64_t i = i0 + il;
+      const int64_t i = row0 + i0 + il;  // the point; L is indexed by the local row i0 + il
       float xiv[DPAD];
 #pragma unroll
       for (int c = 0; c < DPAD; c += 4) {
@@ -1720,7 +1796,7 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_grad(const float* __restric
         for (int c = 0; c < DPAD; ++c) dot = fmaf(xiv[c], xjv[c], dot);
         float dist = fmaf(-2.f, dot, si + sm.sqj[jl]);
         dist = fmaxf(dist, 0.f);
-        const bool live = (i < n) && (j < n);
+        const bool live = (i0 + il < nrow) && (j < n);
         const float s_ij = live ? sm.u.s_t[jl][il] : 0.f;
         float kv, wl;
         grad_weights(kind, i == j ? 0.f : dist, kv, wl);
@@ -1770,21 +1846,21 @@ template <int DPAD>
 static int launch_grad(const mfx_operator* op, const float* xs, const float* sq, const float* L, int64_t ldl,
                        const float* R, int64_t ldr, int64_t batch, double* partial, int64_t* nblocks_out,
                        hipStream_t stream) {
-  const int64_t n = op->n;
-  const int64_t nti = (n + kGM - 1) / kGM, ntj = (n + kGN - 1) / kGN;
+  const int64_t n = op->n, row0 = op_row0(op), nrow = op_nrows(op);
+  const int64_t nti = (nrow + kGM - 1) / kGM, ntj = (n + kGN - 1) / kGN;
   const int tiles_per_block = (int)((ntj + kGSplit * kGSub - 1) / (kGSplit * kGSub));
   const dim3 grid(kGSplit, (unsigned)(nti * kGSub));
   const size_t sh = sizeof(GradSmem<DPAD>);
-  const bool vec4 = (n % 4 == 0) && (ldl % 4 == 0) && (ldr % 4 == 0) && (reinterpret_cast<uintptr_t>(L) % 16 == 0) &&
+  const bool vec4 = (n % 4 == 0) && (nrow % 4 == 0) && (ldl % 4 == 0) && (ldr % 4 == 0) && (reinterpret_cast<uintptr_t>(L) % 16 == 0) &&
                     (reinterpret_cast<uintptr_t>(R) % 16 == 0);
   if (vec4) {
     MFX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rbf_mfma_grad<DPAD, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    k_rbf_mfma_grad<DPAD, true><<<grid, 256, sh, stream>>>(xs, sq, n, op->ard, op->kernel_fn, L, ldl, R, ldr, batch, tiles_per_block, partial);
+    k_rbf_mfma_grad<DPAD, true><<<grid, 256, sh, stream>>>(xs, sq, n, op->ard, op->kernel_fn, L, ldl, R, ldr, batch, tiles_per_block, partial, row0, nrow);
   } else {
     MFX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rbf_mfma_grad<DPAD, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    k_rbf_mfma_grad<DPAD, false><<<grid, 256, sh, stream>>>(xs, sq, n, op->ard, op->kernel_fn, L, ldl, R, ldr, batch, tiles_per_block, partial);
+    k_rbf_mfma_grad<DPAD, false><<<grid, 256, sh, stream>>>(xs, sq, n, op->ard, op->kernel_fn, L, ldl, R, ldr, batch, tiles_per_block, partial, row0, nrow);
   }
   MFX_CHECK_LAUNCH();
   *nblocks_out = nti * kGSub * kGSplit;

@@ -29,6 +29,7 @@ __global__ __launch_bounds__(64) void k_tridiag_eigh(const T* __restrict__ alpha
   for (int t = lane; t < k * k; t += 64) Z[(t / k) * ldz + (t % k)] = (t / k == t % k) ? 1.0 : 0.0;
   __syncthreads();
   const double eps = 2.220446049250313e-16;
+  bool converged = true;  // wave-uniform
   for (int l = 0; l < k; ++l) {
     int iter = 0;
     while (true) {
@@ -38,7 +39,10 @@ __global__ __launch_bounds__(64) void k_tridiag_eigh(const T* __restrict__ alpha
         if (fabs(e[m]) <= eps * dd) break;
       }
       if (m == l) break;
-      if (++iter > 200) break;
+      if (++iter > 200) {  // no silent garbage: this probe's eigenvalues become NaN (documented in mfx.h)
+        converged = false;
+        break;
+      }
       double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
       double r = hypot(g, 1.0);
       g = d[m] - d[l] + e[l] / (g + copysign(r, g));
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(64) void k_tridiag_eigh(const T* __restrict__ alpha
     }
   }
   __syncthreads();
-  for (int i = lane; i < k; i += 64) evals[b * k + i] = (T)d[i];
+  for (int i = lane; i < k; i += 64) evals[b * k + i] = converged ? (T)d[i] : (T)NAN;
   for (int t = lane; t < k * k; t += 64) evecs[b * k * k + t] = (T)Z[(t / k) * ldz + (t % k)];
 }
 

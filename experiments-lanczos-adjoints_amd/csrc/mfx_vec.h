@@ -143,6 +143,7 @@ struct UpdateArgs {
   T* partial_out;   // DOTS
   T* partial_norm;  // NORM: (p, nblk)
   int kmax, nblk;
+  int nblk_in;  // slices of partial_in (1 when the partials were summed over the row shards, see Ctx::comm)
 };
 
 template <typename T, int VEC, bool DOTS, bool NORM>
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(kBlock) void k_update(UpdateArgs<T> a) {
     const int j = idx / kRedG, g = idx % kRedG;
     T c = T(0);
     if (a.partial_in)
-      c = a.s1 * reduce_partials_group<T, kRedG>(a.partial_in + ((int64_t)b * a.kmax + j) * a.nblk, a.nblk, g);
+      c = a.s1 * reduce_partials_group<T, kRedG>(a.partial_in + ((int64_t)b * a.kmax + j) * a.nblk_in, a.nblk_in, g);
     if (g == 0) {
       if (a.extra) c += a.s2 * a.extra[(int64_t)b * a.extra_ldb + (int64_t)j * a.extra_stride];
       coef[j] = c;
@@ -337,15 +338,50 @@ static int pick_vec(int64_t n, std::initializer_list<const void*> ptrs) {
 // counts is loads in flight per CU, not the number of CUs touched.)
 static int pick_wg(int64_t n, int64_t p) { return ((n + kSlice - 1) / kSlice) * p >= 16 ? kBlock : 64; }
 
+// ------------------------------------------------------------------------------------------------
+// Row-sharded mode (one process per GPU, rows of every vector split over the ranks of an mfx_comm): a producer's
+// per-slice partials are summed on the device into ONE number per coefficient, all-reduced over the ranks, and the
+// consumers read them with a single "slice" (nblk_in = 1).  Same kernels, same partial layout (b, j, slice).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_compact_partials(const T* __restrict__ in, int kmax, int nblk, int m,
+                                                          T* __restrict__ out) {
+  const int b = blockIdx.x;
+  for (int idx = threadIdx.x; idx < m * kRedG; idx += (int)blockDim.x) {
+    const int j = idx / kRedG, g = idx % kRedG;
+    const T v = reduce_partials_group<T, kRedG>(in + ((int64_t)b * kmax + j) * nblk, nblk, g);
+    if (g == 0) out[(int64_t)b * kmax + j] = v;
+  }
+}
+
 template <typename T>
 struct Ctx {
   int64_t n, k, p;
   int wg, nblk, kmax, vec;
   hipStream_t stream;
+  const mfx_comm* comm = nullptr;  // row-sharded mode
+  T* stage = nullptr;              // (p, kmax, nblk) producer scratch of the sharded mode
+  int nblk_in;                     // slices the consumers sum over
   Ctx(int64_t n_, int64_t k_, int64_t p_, int vec_, hipStream_t s)
       : n(n_), k(k_), p(p_), wg(pick_wg(n_, p_)), nblk((int)((n_ + (int64_t)wg * kEpt - 1) / ((int64_t)wg * kEpt))),
-        kmax((int)(k_ + 1)), vec(vec_), stream(s) {}
+        kmax((int)(k_ + 1)), vec(vec_), stream(s), nblk_in(nblk) {}
+  void shard(const mfx_comm* cm, T* stage_) {
+    comm = cm;
+    stage = stage_;
+    nblk_in = 1;
+  }
   dim3 grid() const { return dim3(nblk, (unsigned)p); }
+  // where a producer writes its (b, j, slice) partials that the caller wants in `dst`
+  T* producer(T* dst) const { return comm ? stage : dst; }
+  // sharded: dst[b][j] (j < m, row stride kmax_) = sum over the ranks and slices of the partials just produced in `stage`
+  int finish(T* dst, int kmax_, int m) const {
+    if (!comm) return MFX_OK;
+    k_compact_partials<T><<<(unsigned)p, 256, 0, stream>>>(stage, kmax_, nblk, m, dst);
+    MFX_CHECK_LAUNCH();
+    const int rc = comm->allreduce_sum(comm->ctx, dst, p * (int64_t)kmax_, sizeof(T) == 4 ? MFX_F32 : MFX_F64, stream);
+    MFX_REQUIRE(rc == 0, MFX_ERR_CALLBACK, "all-reduce callback failed with code %d", rc);
+    return MFX_OK;
+  }
 };
 
 template <typename T>
@@ -354,9 +390,9 @@ static int launch_dots(const Ctx<T>& c, const T* rows, int64_t rows_ldb, int64_t
   if (m <= 0) return MFX_OK;
   const size_t sh = (size_t)4 * m * sizeof(T);
   MFX_VEC_SWITCH(c.vec, (k_dots<T, VEC><<<c.grid(), c.wg, sh, c.stream>>>(
-                            rows, rows_ldb, row_stride, m, x, ldx, c.n, partial, c.kmax, c.nblk)));
+                            rows, rows_ldb, row_stride, m, x, ldx, c.n, c.producer(partial), c.kmax, c.nblk)));
   MFX_CHECK_LAUNCH();
-  return MFX_OK;
+  return c.finish(partial, c.kmax, m);
 }
 
 template <typename T>
@@ -364,6 +400,12 @@ static int launch_update(const Ctx<T>& c, UpdateArgs<T> a, bool dots, bool norm)
   a.n = c.n;
   a.kmax = c.kmax;
   a.nblk = c.nblk;
+  a.nblk_in = c.nblk_in;
+  T* const want_dots = a.partial_out;
+  T* const want_norm = a.partial_norm;
+  MFX_REQUIRE(!(c.comm && dots && norm), MFX_ERR_UNSUPPORTED, "sharded update: fused dots + norm share one staging buffer");
+  if (dots) a.partial_out = c.producer(want_dots);
+  if (norm) a.partial_norm = c.producer(want_norm);
   const size_t sh = (size_t)(a.m + (dots ? 4 * a.m : 0) + 4) * sizeof(T);
   if (dots && norm) {
     MFX_VEC_SWITCH(c.vec, (k_update<T, VEC, true, true><<<c.grid(), c.wg, sh, c.stream>>>(a)));
@@ -375,21 +417,23 @@ static int launch_update(const Ctx<T>& c, UpdateArgs<T> a, bool dots, bool norm)
     MFX_VEC_SWITCH(c.vec, (k_update<T, VEC, false, false><<<c.grid(), c.wg, sh, c.stream>>>(a)));
   }
   MFX_CHECK_LAUNCH();
+  if (dots) MFX_TRY(c.finish(want_dots, c.kmax, a.m));
+  if (norm) MFX_TRY(c.finish(want_norm, 1, 1));
   return MFX_OK;
 }
 
 template <typename T>
 static int launch_sumsq(const Ctx<T>& c, const T* x, int64_t ldx, T* partial_norm) {
-  MFX_VEC_SWITCH(c.vec, (k_sumsq<T, VEC><<<c.grid(), c.wg, 0, c.stream>>>(x, ldx, c.n, partial_norm, c.nblk)));
+  MFX_VEC_SWITCH(c.vec, (k_sumsq<T, VEC><<<c.grid(), c.wg, 0, c.stream>>>(x, ldx, c.n, c.producer(partial_norm), c.nblk)));
   MFX_CHECK_LAUNCH();
-  return MFX_OK;
+  return c.finish(partial_norm, 1, 1);
 }
 
 template <typename T>
 static int launch_scale(const Ctx<T>& c, const T* x, int64_t ldx, T* y, int64_t ldy, const T* partial_norm,
                         const T* scale, int mode, T* len_out, int64_t len_ld, T* inv_out) {
   dim3 grid = y ? c.grid() : dim3(1, (unsigned)c.p);
-  MFX_VEC_SWITCH(c.vec, (k_scale<T, VEC><<<grid, c.wg, 0, c.stream>>>(x, ldx, y, ldy, c.n, partial_norm, c.nblk,
+  MFX_VEC_SWITCH(c.vec, (k_scale<T, VEC><<<grid, c.wg, 0, c.stream>>>(x, ldx, y, ldy, c.n, partial_norm, c.nblk_in,
                                                                         scale, mode, len_out, len_ld, inv_out)));
   MFX_CHECK_LAUNCH();
   return MFX_OK;

@@ -65,6 +65,25 @@ class Operator(C.Structure):
         ("noise", C.c_void_p),
         ("callback", CALLBACK_T),
         ("ctx", C.c_void_p),
+        ("row0", C.c_int64),
+        ("nrows", C.c_int64),
+    ]
+
+
+ALLREDUCE_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)  # ctx, buf, count, dtype, stream
+ALLGATHER_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)  # ctx, in, out, count, dtype, stream
+
+
+class Comm(C.Structure):
+    """mirror of ``struct mfx_comm`` (row-sharded drivers)."""
+
+    _fields_ = [
+        ("rank", C.c_int32),
+        ("world", C.c_int32),
+        ("nloc", C.c_int64),
+        ("allreduce_sum", ALLREDUCE_T),
+        ("allgather", ALLGATHER_T),
+        ("ctx", C.c_void_p),
     ]
 
 
@@ -82,7 +101,7 @@ class OpGrads(C.Structure):
 
 # every symbol include/mfx.h declares: (name, restype, argtypes)
 _P, _I64, _I = C.c_void_p, C.c_int64, C.c_int
-_OPP, _GRP = C.POINTER(Operator), C.POINTER(OpGrads)
+_OPP, _GRP, _CMP = C.POINTER(Operator), C.POINTER(OpGrads), C.POINTER(Comm)
 SYMBOLS = {
     "mfx_last_error": (C.c_char_p, []),
     "mfx_version": (_I, []),
@@ -93,6 +112,12 @@ SYMBOLS = {
     "mfx_arnoldi_adjoint": (
         _I,
         [_OPP, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _GRP, _P, _I64, _P],
+    ),
+    "mfx_sharded_workspace_bytes": (_I64, [_OPP, _CMP, _I64, _I64, _I64]),
+    "mfx_arnoldi_forward_sharded": (_I, [_OPP, _CMP, _P, _I64, _I64, _I64, _I, _P, _P, _P, _P, _P, _P, _I64, _P]),
+    "mfx_arnoldi_adjoint_sharded": (
+        _I,
+        [_OPP, _CMP, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _GRP, _P, _I64, _P],
     ),
     "mfx_lanczos_forward": (_I, [_OPP, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _I64, _P]),
     "mfx_lanczos_adjoint": (

@@ -26,7 +26,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .operators import CallbackOp, _PtrRegistry, as_operator
+from .operators import CallbackOp, RowShardedOp, _PtrRegistry, as_operator
 
 
 def hessenberg(
@@ -49,7 +49,10 @@ def hessenberg(
             params = tuple(bound) + tuple(params)
         batched = v.dim() == 2
         V = v if batched else v[None]
-        n = V.shape[-1]
+        sharded = isinstance(op, RowShardedOp)
+        n = op.comm.n if sharded else V.shape[-1]
+        if sharded and V.shape[-1] != op.comm.nrows:
+            raise ValueError(f"row-sharded operator: expected this rank's {op.comm.nrows} rows of the start vector, got {V.shape[-1]}")
         if krylov_depth < 1 or krylov_depth > n:
             msg = f"Parameter depth {krylov_depth} is outside the expected range"
             raise ValueError(msg)
@@ -57,7 +60,10 @@ def hessenberg(
         reortho_fwd = reortho_vjp if reortho_vjp != "match" else reortho_vjp
         second_pass = reortho_fwd != "none"
         cparams = op.constrain(*params)
-        Qkn, H, r, c = _ArnoldiFn.apply(op, int(krylov_depth), second_pass, reortho, custom_vjp, V, *cparams)
+        if sharded:
+            Qkn, H, r, c = _ArnoldiShardedFn.apply(op, int(krylov_depth), second_pass, reortho, custom_vjp, V, *cparams)
+        else:
+            Qkn, H, r, c = _ArnoldiFn.apply(op, int(krylov_depth), second_pass, reortho, custom_vjp, V, *cparams)
         Q = Qkn.transpose(-1, -2)  # reference layout (n, k); storage stays (k, n)
         if not batched:
             return Q[0], H[0], r[0], c[0]
@@ -142,4 +148,82 @@ class _ArnoldiFn(torch.autograd.Function):
         if keep is not None and keep[1]:
             raise keep[1][0]
         _lib.check(rc)
+        return (None, None, None, None, None, dv, *grads)
+
+
+class _ArnoldiShardedFn(torch.autograd.Function):
+    """_ArnoldiFn on row shards (``mfx_arnoldi_forward_sharded`` / ``mfx_arnoldi_adjoint_sharded``): V, Q, r, dv hold this
+    rank's rows; H and c are replicated; the parameter gradients are summed over the row group before they are returned."""
+
+    @staticmethod
+    def forward(ctx, sop, k, second_pass, reortho_bwd, differentiable, V, *cparams):
+        op, comm = sop.op, sop.comm
+        tensors = [q for q in cparams if torch.is_tensor(q)]
+        _lib.require_device(V, *tensors)
+        lib = _lib.get()
+        V = V.contiguous()
+        p, nrows = V.shape
+        n = comm.n
+        dt, dev = V.dtype, V.device
+        Q = torch.empty((p, k, nrows), dtype=dt, device=dev)
+        Qfull = torch.empty((p, k, n), dtype=dt, device=dev)
+        H = torch.empty((p, k, k), dtype=dt, device=dev)
+        r = torch.empty((p, nrows), dtype=dt, device=dev)
+        c = torch.empty((p,), dtype=dt, device=dev)
+        desc = op.descriptor(cparams, dt, n)
+        cm0 = _lib.Comm()
+        cm0.rank, cm0.world, cm0.nloc = comm.rank, comm.world, comm.nloc
+        ws = _lib.scratch(int(lib.mfx_sharded_workspace_bytes(C.byref(desc), C.byref(cm0), n, k, p)), dev)
+        cm, keep = comm.struct(ws)
+        rc = lib.mfx_arnoldi_forward_sharded(C.byref(desc), C.byref(cm), _lib.ptr(V), n, k, p, int(second_pass),
+                                             _lib.ptr(Q), _lib.ptr(Qfull), _lib.ptr(H), _lib.ptr(r), _lib.ptr(c),
+                                             _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+        if keep[2]:
+            raise keep[2][0]
+        _lib.check(rc)
+        ctx.sop, ctx.k, ctx.reortho, ctx.differentiable = sop, k, reortho_bwd, differentiable
+        ctx.nontensor = [None if torch.is_tensor(q) else q for q in cparams]
+        ctx.save_for_backward(Q, Qfull, H, r, c, *tensors)
+        ctx.set_materialize_grads(False)
+        return Q, H, r, c
+
+    @staticmethod
+    def backward(ctx, dQ, dH, dr, dc):
+        if not ctx.differentiable:
+            raise RuntimeError("hessenberg(custom_vjp=False) is not differentiable in the MI355X build; "
+                               "use custom_vjp=True (the adjoint system).")
+        Q, Qfull, H, r, c, *tensors = ctx.saved_tensors
+        it = iter(tensors)
+        cparams = tuple(next(it) if q is None else q for q in ctx.nontensor)
+        op, comm, k, lib = ctx.sop.op, ctx.sop.comm, ctx.k, _lib.get()
+        p, _, nrows = Q.shape
+        n = comm.n
+        dt, dev = Q.dtype, Q.device
+        dQ = None if dQ is None else dQ.contiguous()
+        dr = None if dr is None else dr.contiguous()
+        dc = None if dc is None else dc.contiguous()
+        dH = torch.zeros_like(H) if dH is None else dH.contiguous()
+        dv = torch.empty((p, nrows), dtype=dt, device=dev)
+        Lam = torch.empty((p, k, nrows), dtype=dt, device=dev)
+        desc = op.descriptor(cparams, dt, n)
+        gstruct, grads = op.new_grads(*cparams)
+        cm0 = _lib.Comm()
+        cm0.rank, cm0.world, cm0.nloc = comm.rank, comm.world, comm.nloc
+        ws = _lib.scratch(int(lib.mfx_sharded_workspace_bytes(C.byref(desc), C.byref(cm0), n, k, p)), dev)
+        cm, keep = comm.struct(ws)
+        rc = lib.mfx_arnoldi_adjoint_sharded(C.byref(desc), C.byref(cm), n, k, p, _lib.ptr(Q), _lib.ptr(Qfull), _lib.ptr(H),
+                                             _lib.ptr(r), _lib.ptr(c), _lib.ptr(dQ), _lib.ptr(dH), _lib.ptr(dr), _lib.ptr(dc),
+                                             _lib.REORTHO_FULL if ctx.reortho == "full" else _lib.REORTHO_NONE,
+                                             _lib.ptr(dv), _lib.ptr(Lam), C.byref(gstruct), _lib.ptr(ws), ws.numel(),
+                                             _lib.stream_ptr(dev))
+        if keep[2]:
+            raise keep[2][0]
+        _lib.check(rc)
+        if comm.world > 1 and grads:  # partial sums over this rank's rows -> the complete gradient, ONE small all-reduce
+            flat = torch.cat([g.reshape(-1) for g in grads])
+            comm.all_reduce_(flat)
+            off = 0
+            for g in grads:
+                g.copy_(flat[off : off + g.numel()].reshape(g.shape))
+                off += g.numel()
         return (None, None, None, None, None, dv, *grads)

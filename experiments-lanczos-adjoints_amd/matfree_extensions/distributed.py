@@ -1,16 +1,29 @@
-"""Multi-GPU Hutchinson: probes shard across ranks, ONE all-reduce per estimate.
+"""Multi-GPU stochastic Lanczos quadrature: one process per GPU over torch.distributed (backend "nccl" = RCCL over xGMI).
 
-The reference is single-device (no collective anywhere).  The estimator is a mean over
-independent probes (hutchinson.py:14-15), so the natural MI355X decomposition is one process per GPU,
-the operator replicated (X is a few MB), each rank running the full forward + adjoint for its own
-probes, and a single fused RCCL all-reduce of [sum q, sum q^2, sum d/dtheta q] over xGMI -- tens of
-bytes to a few MB, i.e. latency-bound, hence exactly one collective per value-and-grad.
+The reference is single-device (no collective anywhere).  Two independent axes shard its SLQ estimate:
+
+* **probes** -- the estimator is a mean over independent probes (hutchinson.py:14-15): every rank runs the full forward +
+  adjoint for its own probes, the operator is replicated, and ONE fused all-reduce of [sum q, sum q^2, sum dq/dtheta]
+  finishes the estimate (`shard_probes`, `reduce_estimate`).  Kernel evaluations are replicated per rank, so for a FIXED
+  probe count this axis scales badly (64 probes on 8 GPUs: 2.1x).
+* **rows** -- the rows of the kernel matrix are independent (the reference's own row partition of the Gram matvec,
+  util/gp_util.py:496-509): rank r owns rows [r nloc, (r+1) nloc) of the operator AND of every Krylov vector, all probes on
+  every rank.  Per Krylov step libmfx needs one all-gather of the (p, nloc) iterate and the sum-all-reduce of the (p, k+1)
+  Gram-Schmidt coefficients / norms (`Q.T @ v`, arnoldi.py:87-92, becomes a partial sum per rank); it calls back into
+  `RowComm` for both, on its stream (`mfx_comm`, include/mfx.h).  This is the strong-scaling layout of BASELINE config 4.
+
+The axes compose: `make_grid(world, rows)` splits the world into row groups of `rows` ranks; different row groups take
+different probes.
 """
 
 from __future__ import annotations
 
+import ctypes as C
+
 import torch
 import torch.distributed as dist
+
+from . import _lib
 
 
 def shard_probes(num_total: int, rank: int, world_size: int):
@@ -21,19 +34,36 @@ def shard_probes(num_total: int, rank: int, world_size: int):
     return first, count
 
 
-def reduce_estimate(local_values, local_grads, num_total: int, group=None):
+def rows_per_rank(n: int, world_size: int) -> int:
+    """Rows per rank of the row-sharded layout: equal on every rank, a multiple of 64 (the matrix-core Gram kernels
+    start their row blocks on multiples of 64); the last rank owns what is left."""
+    nloc = -(-n // world_size)
+    nloc = -(-nloc // 64) * 64
+    if (world_size - 1) * nloc >= n:
+        raise ValueError(f"n = {n} is too small to give each of {world_size} ranks at least one 64-aligned row block")
+    return nloc
+
+
+def _active(group=None):
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
+def reduce_estimate(local_values, local_grads, num_total: int, group=None, replicas: int = 1):
     """All-reduce per-probe values and summed parameter gradients in ONE collective.
 
     local_values: (p_local,) integrand values of this rank's probes.
     local_grads : tuple of tensors = d/dtheta of SUM_b value_b over this rank's probes.
+    replicas    : ranks of ``group`` holding the SAME probes (the row group size of a row-sharded run): their
+                  contributions are identical, so the sums are divided by it.
     -> (mean, std over probes, tuple of gradients of the mean)
     """
     lv = local_values.double()  # mean^2 ~ 1e10 at n = 1e5: the second moment needs fp64
     flat = [lv.sum().reshape(1), (lv**2).sum().reshape(1)]
     flat += [g.reshape(-1).double() for g in local_grads]
     buf = torch.cat(flat).contiguous()
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _active(group):
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    buf = buf / replicas
     mean = buf[0] / num_total
     var = torch.clamp_min(buf[1] / num_total - mean**2, 0.0)
     grads, off = [], 2
@@ -43,7 +73,7 @@ def reduce_estimate(local_values, local_grads, num_total: int, group=None):
     return mean, var.sqrt(), tuple(grads)
 
 
-def value_and_grad_sharded(integrand, sample_local, params, *, num_total: int, group=None):
+def value_and_grad_sharded(integrand, sample_local, params, *, num_total: int, group=None, replicas: int = 1):
     """SLQ value-and-gradient with probes sharded over the ranks of ``group``.
 
     integrand   : batched integrand (e.g. lanczos.integrand_spd(...)), called once on this rank's probes
@@ -55,4 +85,164 @@ def value_and_grad_sharded(integrand, sample_local, params, *, num_total: int, g
     diff = [q for q in params if torch.is_tensor(q) and q.requires_grad]
     grads = torch.autograd.grad(values.sum(), diff, allow_unused=True)
     grads = tuple(torch.zeros_like(q) if g is None else g for q, g in zip(diff, grads))
-    return reduce_estimate(values.detach(), grads, num_total, group=group)
+    return reduce_estimate(values.detach(), grads, num_total, group=group, replicas=replicas)
+
+
+# ------------------------------------------------------------------------------------------------
+# row sharding
+# ------------------------------------------------------------------------------------------------
+class RowComm:
+    """The ranks of ``group`` as row shards of an n x n operator, and the collectives libmfx asks for.
+
+    rank r owns rows [r nloc, min(n, (r + 1) nloc)).  ``struct(ws)`` builds the ``mfx_comm`` the sharded drivers take:
+    its two callbacks receive raw device pointers into the workspace tensor ``ws`` of the call in progress, turn them
+    back into views and run ``all_reduce`` / ``all_gather_into_tensor`` on them (stream-ordered on the current stream
+    for "nccl"; blocking for "gloo").
+    """
+
+    def __init__(self, n: int, group=None):
+        self.group = group
+        on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if on else 1
+        self.rank = dist.get_rank(group) if on else 0
+        self.n = int(n)
+        self.nloc = rows_per_rank(self.n, self.world)
+        self.row0 = self.rank * self.nloc
+        self.nrows = min(self.nloc, self.n - self.row0)
+
+    # ---- host-side helpers ---------------------------------------------------------------------
+    def rows(self, t):
+        """this rank's slice of a tensor whose LAST axis has length n"""
+        return t[..., self.row0 : self.row0 + self.nrows].contiguous()
+
+    def all_reduce_(self, t):
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def gather_rows(self, t_local):
+        """(..., nrows) row shards -> (..., n) on every rank (tests / small host-side needs; not on the hot path)"""
+        lead = t_local.shape[:-1]
+        flat = t_local.reshape(-1, self.nrows)
+        send = torch.zeros((flat.shape[0], self.nloc), dtype=t_local.dtype, device=t_local.device)
+        send[:, : self.nrows] = flat
+        out = torch.empty((self.world * flat.shape[0], self.nloc), dtype=t_local.dtype, device=t_local.device)
+        if self.world > 1:
+            dist.all_gather_into_tensor(out, send, group=self.group)  # rank-major blocks along axis 0
+        else:
+            out.copy_(send)
+        out = out.reshape(self.world, flat.shape[0], self.nloc).movedim(0, 1).reshape(flat.shape[0], self.world * self.nloc)
+        return out[:, : self.n].reshape(*lead, self.n).contiguous()
+
+    # ---- mfx_comm ---------------------------------------------------------------------------------
+    def struct(self, ws: torch.Tensor):
+        """-> (mfx_comm, keepalive).  ``ws`` is the uint8 workspace tensor every callback pointer lies in."""
+        base, nbytes = ws.data_ptr(), ws.numel()
+        failure = []
+        world, group = self.world, self.group
+
+        def view(ptr, count, dtype_code):
+            dt = torch.float32 if dtype_code == _lib.MFX_F32 else torch.float64
+            es = 4 if dtype_code == _lib.MFX_F32 else 8
+            off = ptr - base
+            if off < 0 or off + count * es > nbytes:
+                raise RuntimeError("libmfx comm callback received a pointer outside the workspace")
+            return ws[off : off + count * es].view(dt)
+
+        def allreduce(_ctx, buf, count, dtype_code, _stream):
+            try:
+                if world > 1:
+                    dist.all_reduce(view(buf, count, dtype_code), op=dist.ReduceOp.SUM, group=group)
+                return 0
+            except Exception as exc:  # never let an exception cross the C boundary
+                failure.append(exc)
+                return 1
+
+        def allgather(_ctx, inp, out, count, dtype_code, _stream):
+            try:
+                tin, tout = view(inp, count, dtype_code), view(out, count * world, dtype_code)
+                if world > 1:
+                    dist.all_gather_into_tensor(tout, tin, group=group)
+                else:
+                    tout.copy_(tin)
+                return 0
+            except Exception as exc:
+                failure.append(exc)
+                return 1
+
+        cb_r, cb_g = _lib.ALLREDUCE_T(allreduce), _lib.ALLGATHER_T(allgather)
+        cm = _lib.Comm()
+        cm.rank, cm.world, cm.nloc = self.rank, self.world, self.nloc
+        cm.allreduce_sum, cm.allgather = cb_r, cb_g
+        return cm, (cb_r, cb_g, failure)
+
+
+class _ShardedSumSq(torch.autograd.Function):
+    """sum over ALL rows of v^2 from row shards (p, nrows) -> (p,), identical on every rank.  Backward: every rank holds
+    the same downstream cotangent, and its rows enter the sum only through its own partial sum."""
+
+    @staticmethod
+    def forward(ctx, comm, V):
+        ctx.save_for_backward(V)
+        return comm.all_reduce_((V.double() ** 2).sum(-1)).to(V.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        (V,) = ctx.saved_tensors
+        return None, 2.0 * V * g[:, None]
+
+
+def sharded_norm(comm: RowComm, V):
+    """Euclidean norm of row-sharded vectors (p, nrows) -> (p,)"""
+    return torch.sqrt(_ShardedSumSq.apply(comm, V))
+
+
+def make_grid(rows: int, group=None):
+    """Split the ranks of ``group`` into row groups of ``rows`` consecutive ranks.
+
+    -> (row_group, probe_index, num_probe_groups): ``row_group`` is the process group this rank shards rows over,
+    ``probe_index`` says which slice of the probes its row group takes.  Every rank must call this (collective).
+    """
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if world % rows != 0:
+        raise ValueError(f"row group size {rows} does not divide the world size {world}")
+    ngroups = world // rows
+    mine = None
+    members = dist.get_process_group_ranks(group) if group is not None else list(range(world))
+    for g in range(ngroups):
+        pg = dist.new_group(ranks=[members[g * rows + r] for r in range(rows)])
+        if rank // rows == g:
+            mine = pg
+    return mine, rank // rows, ngroups
+
+
+def slq_value_and_grad(op, matfun, krylov_depth, params, *, n: int, seed, num_probes: int, row_group_size: int = 1,
+                       group=None, dtype=None, device=None):
+    """SLQ value-and-gradient on a (row groups x probe groups) grid of ranks.
+
+    op             : native operator (e.g. gp_util.gram_operator(X)) -- replicated, X is a few MB
+    row_group_size : ranks per row group (1 = pure probe sharding, world size = pure row sharding)
+    -> (mean, std over probes, gradients of the mean), identical on every rank.
+    """
+    from . import hutchinson, lanczos
+    from .operators import RowShardedOp
+
+    on = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if on else 1
+    if row_group_size > 1:
+        row_group, probe_index, probe_groups = make_grid(row_group_size, group) if world > row_group_size else (group, 0, 1)
+    else:
+        row_group, probe_index, probe_groups = None, (dist.get_rank(group) if on else 0), world
+    first, count = shard_probes(num_probes, probe_index, probe_groups)
+    like = torch.empty(n, dtype=dtype, device=device)
+    probes = hutchinson.sampler_rademacher(like, num=count)((seed, first))  # this group's slice of ONE global probe matrix
+    if row_group_size > 1:
+        comm = RowComm(n, row_group)
+        probes = comm.rows(probes)
+        matvec = RowShardedOp(op, comm)
+    else:
+        matvec = op
+    integrand = lanczos.integrand_spd(matfun, krylov_depth, matvec)
+    return value_and_grad_sharded(integrand, lambda: probes, params, num_total=num_probes, group=group,
+                                  replicas=row_group_size if row_group_size > 1 else 1)

@@ -22,7 +22,18 @@ import warnings
 import torch
 
 from . import _lib, arnoldi
-from .operators import CallbackOp, _PtrRegistry, as_operator
+from .operators import CallbackOp, RowShardedOp, _PtrRegistry, as_operator
+
+
+def _vec_norm(V, matvec):
+    """Euclidean norm over the last axis; for a row-sharded operator the vectors are row shards and the sum of squares
+    is completed over the row group."""
+    op, _ = as_operator(matvec)
+    if isinstance(op, RowShardedOp):
+        from .distributed import sharded_norm
+
+        return sharded_norm(op.comm, V)
+    return torch.linalg.vector_norm(V, dim=-1)
 
 
 def tridiag(matvec, krylov_depth, /, *, reortho: str, custom_vjp: bool = True):
@@ -44,7 +55,7 @@ def _tridiag_reortho_full(matvec, krylov_depth, /, *, custom_vjp):
         T = 0.5 * (H + H.transpose(-1, -2))
         diags = torch.diagonal(T, 0, -2, -1)
         offdiags = torch.diagonal(T, 1, -2, -1)
-        vnorm = torch.linalg.vector_norm(v, dim=-1)
+        vnorm = _vec_norm(v, matvec) if v.dim() == 2 else _vec_norm(v[None], matvec)[0]
         decomposition = (Q.transpose(-1, -2), (diags, offdiags))
         remainder = (v / vnorm[..., None], vnorm)
         return decomposition, remainder
@@ -250,7 +261,7 @@ def integrand_spd(matfun, krylov_depth, matvec, /, *, reortho: str = "full",
         v0_flat, unflatten = _flatten(v0)
         batched = v0_flat.dim() == 2
         V = v0_flat if batched else v0_flat[None]
-        scale = torch.linalg.vector_norm(V, dim=-1)
+        scale = _vec_norm(V, matvec)
         V = V / scale[:, None]
         algorithm = tridiag(_flat_matvec(matvec, unflatten), krylov_depth,
                             custom_vjp=use_adjoints_for_tridiag, reortho=reortho)

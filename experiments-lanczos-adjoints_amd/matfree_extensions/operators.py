@@ -77,6 +77,39 @@ class BoundOp:
         return self.op(v, *self.params)
 
 
+class RowShardedOp:
+    """A native operator whose rows -- and the rows of every Krylov vector -- are sharded over the ranks of a
+    ``distributed.RowComm``.  Hand it to ``lanczos.tridiag(reortho="full")`` / ``arnoldi.hessenberg`` /
+    ``lanczos.integrand_spd`` in place of the operator: vectors are then this rank's row shards (p, nrows), H and the
+    SLQ values come out replicated, parameter gradients complete (summed over the row group)."""
+
+    def __init__(self, op, comm):
+        if not isinstance(op, NativeOp):
+            raise TypeError("row sharding needs a native operator (DenseOp, CsrOp, RbfGramOp)")
+        self.op, self.comm = op, comm
+
+    def bind(self, *params):
+        return BoundOp(self, params)
+
+    def constrain(self, *params):
+        return self.op.constrain(*params)
+
+    def __call__(self, v, *params):
+        """this rank's rows of A v from the row shard of v (gathers v first; not differentiable -- the Krylov drivers
+        use the fused device path instead)"""
+        with torch.no_grad():
+            cparams = self.op.constrain(*params)
+            V = v if v.dim() == 2 else v[None]
+            full = self.comm.gather_rows(V.contiguous())
+            desc = self.op.descriptor(cparams, V.dtype, self.comm.n)
+            desc.row0, desc.nrows = self.comm.row0, self.comm.nrows
+            ws = _lib.workspace(desc, self.comm.n, 1, V.shape[0], V.device)
+            y = torch.empty_like(V)
+            _lib.check(_lib.get().mfx_op_apply(C.byref(desc), _lib.ptr(full), self.comm.n, _lib.ptr(y), self.comm.nrows,
+                                               V.shape[0], 0, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(V.device)))
+        return y if v.dim() == 2 else y[0]
+
+
 class _ApplyFn(torch.autograd.Function):
     """y = A(theta) x (or A^T x); backward = A^T dy and the parameter sweep with batch = p."""
 
@@ -390,7 +423,7 @@ def as_operator(matvec):
     """matvec argument of the reference API -> (operator, bound-params or None)."""
     if isinstance(matvec, BoundOp):
         return matvec.op, matvec.params
-    if isinstance(matvec, (NativeOp, CallbackOp)):
+    if isinstance(matvec, (NativeOp, CallbackOp, RowShardedOp)):
         return matvec, None
     if callable(matvec):
         return CallbackOp(matvec), None

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MFX_VERSION 100
+#define MFX_VERSION 200
 
 enum { MFX_F32 = 0, MFX_F64 = 1 };
 enum { MFX_OP_DENSE = 0, MFX_OP_CSR = 1, MFX_OP_RBF = 2, MFX_OP_CALLBACK = 3 };
@@ -34,11 +34,13 @@ enum { MFX_REORTHO_NONE = 0, MFX_REORTHO_FULL = 1 };
 /* Arithmetic of the fp32 RBF Gram kernels (wide batches; fp64 operators ignore it):
  *   MFX_RBF_FP32          exact fp32 MFMA everywhere (v_mfma_f32_32x32x2_f32, a round-to-nearest fmaf chain)
  *   MFX_RBF_F16X3_MATVEC  Gram matvec emulated on the f16 matrix pipe: operands split hi + lo (2 x 11 bits),
- *                         hi*hi + hi*lo + lo*hi accumulated in fp32; distances/exponent stay on the fp32 MFMA;
- *                         parameter-gradient GEMM exact fp32.  Most accurate mode (measured against fp64).
- *   MFX_RBF_F16X3         additionally the parameter-gradient GEMM split the same way, with alternating-sign
- *                         K-chunks that cancel the f16 MFMA's round-towards-minus-infinity bias.  Fastest mode,
- *                         accuracy on par with MFX_RBF_FP32. */
+ *                         hi*hi + hi*lo + lo*hi accumulated in fp32; the squared distances are the same 3-product
+ *                         split on the f16 pipe, block signs alternating (falls back to fp32-MFMA distances when an
+ *                         input exceeds the f16 range); parameter-gradient GEMM exact fp32.
+ *   MFX_RBF_F16X3         additionally the parameter-gradient GEMM S = L^T R split the same way; the f16 MFMA's
+ *                         round-towards-minus-infinity bias is decorrelated by pseudo-random column signs on both
+ *                         operands plus alternating-sign K-chunks.  Fastest mode.
+ * Accuracy of the three modes against the fp64 path at the C4 size: DESIGN.md section 3.2 / profiles/r02a_*. */
 enum { MFX_RBF_FP32 = 0, MFX_RBF_F16X3_MATVEC = 1, MFX_RBF_F16X3 = 2 };
 /* Kernel family of the Gram operator, with s = |x_i/l - x_j/l|^2 clamped at 0 (util/gp_util.py:69-184):
  *   MFX_KERNEL_RBF       sigma exp(-s/2)                                   kernel_scaled_rbf        :151-184
@@ -108,6 +110,14 @@ typedef struct mfx_operator {
   /* CALLBACK */
   mfx_callback_fn callback;
   void* ctx;
+
+  /* Row block (multi-GPU row sharding; the reference's own row partition of the Gram matvec is
+   * util/gp_util.py:496-509).  nrows == 0: the whole operator.  nrows > 0: mfx_op_apply computes only rows
+   * [row0, row0 + nrows) of A x (or of A^T x): x keeps length n, y has nrows entries per vector; and
+   * mfx_op_vjp_params sums only those rows: L_b has nrows entries (rows row0.. of the full L_b), R_b length n.
+   * The matrix-core Gram kernels need row0 % 64 == 0.  The single-device drivers require nrows == 0. */
+  int64_t row0;
+  int64_t nrows;
 } mfx_operator;
 
 /* Parameter-gradient outputs (device pointers, ACCUMULATED into, caller zero-fills).  NULL = skip.
@@ -175,7 +185,9 @@ int mfx_lanczos_adjoint(const mfx_operator* op, int64_t n, int64_t k, int64_t p,
 
 /* jnp.linalg.eigh of the k x k tridiagonal (lanczos.py:48-53), batched: alpha (p, k),
  * beta (p, k-1 values, leading dimension ldbeta) -> evals (p, k) (unordered), evecs (p, k, k) with
- * evecs[b][i][a] = component i of eigenvector a.  fp64 arithmetic inside, k <= 120. */
+ * evecs[b][i][a] = component i of eigenvector a.  fp64 arithmetic inside, k <= 120.  The call is asynchronous, so
+ * a QL iteration that fails to converge (200 sweeps per eigenvalue) cannot be reported through the return code:
+ * that probe's evals are set to NaN instead (never silently wrong numbers). */
 int mfx_tridiag_eigh(const void* alpha, const void* beta, int64_t ldbeta, int64_t p, int64_t k,
                      int dtype, void* evals, void* evecs, void* stream);
 
@@ -191,6 +203,45 @@ int mfx_slq_quadform_bwd(const void* evals, const void* evecs, const void* fvals
  * (seed, first_probe + b, i), so probe shards on different GPUs form one global probe matrix. */
 int mfx_rademacher(uint64_t seed, int64_t first_probe, int64_t p, int64_t n, int dtype, void* out,
                    void* stream);
+
+/* ---- row-sharded Krylov drivers: one process per GPU, rows of every Krylov vector split over `world` ranks ---------
+ *
+ * Rank r owns rows [r nloc, min(n, (r+1) nloc)) of every vector (start vector, basis, remainder, adjoint states) and of
+ * the operator; nloc is the same on every rank, a multiple of 64.  Per Krylov step the library needs
+ *   - ONE all-gather of the (p, nloc) iterate (the operator's input is the full vector), and
+ *   - sum-all-reduces of the (p, k+1) Gram-Schmidt coefficients / norms (the reference's `Q.T @ v`, arnoldi.py:87-92,
+ *     becomes a partial sum per rank),
+ * both enqueued on the caller's stream through the two function pointers below.  The host side supplies them:
+ * matfree_extensions/distributed.py binds them to torch.distributed (backend "nccl" = RCCL over xGMI; "gloo" in tests).
+ * Buffers handed to the callbacks lie inside the workspace `ws` or inside `Qfull` of the call in progress.
+ * H, c and the coefficient buffers come out identical on every rank; parameter gradients are PARTIAL sums over this
+ * rank's rows -- the caller adds them over the ranks (one small all-reduce, folded into the estimator's). */
+typedef int (*mfx_allreduce_fn)(void* ctx, void* buf, int64_t count, int dtype, void* stream); /* in place, sum */
+typedef int (*mfx_allgather_fn)(void* ctx, const void* in, void* out, int64_t count, int dtype,
+                                void* stream); /* out[r * count + i] = in_of_rank_r[i] */
+typedef struct mfx_comm {
+  int32_t rank, world;
+  int64_t nloc; /* rows per rank (last rank: n - rank * nloc >= 1) */
+  mfx_allreduce_fn allreduce_sum;
+  mfx_allgather_fn allgather;
+  void* ctx;
+} mfx_comm;
+
+int64_t mfx_sharded_workspace_bytes(const mfx_operator* op, const mfx_comm* comm, int64_t n, int64_t k, int64_t p);
+
+/* mfx_arnoldi_forward on row shards.  v0, r: (p, nrows) packed; Q: (p, k, nrows); Qfull: (p, k, n) receives the
+ * all-gathered basis (every rank holds all of it afterwards: it is the operator's input in the forward pass anyway, and
+ * the R operand of the parameter-gradient sweep in the adjoint); H (p, k, k), c (p) replicated. */
+int mfx_arnoldi_forward_sharded(const mfx_operator* op, const mfx_comm* comm, const void* v0, int64_t n, int64_t k,
+                                int64_t p, int second_pass, void* Q, void* Qfull, void* H, void* r, void* c, void* ws,
+                                int64_t ws_bytes, void* stream);
+
+/* mfx_arnoldi_adjoint on row shards.  Q, dQ, Lambda: (p, k, nrows); r, dr, dv: (p, nrows); Qfull (p, k, n) from the
+ * forward pass; H, dH, c, dc replicated.  grads: partial sums over this rank's rows (see above). */
+int mfx_arnoldi_adjoint_sharded(const mfx_operator* op, const mfx_comm* comm, int64_t n, int64_t k, int64_t p,
+                                const void* Q, const void* Qfull, const void* H, const void* r, const void* c,
+                                const void* dQ, const void* dH, const void* dr, const void* dc, int reortho, void* dv,
+                                void* Lambda, const mfx_op_grads* grads, void* ws, int64_t ws_bytes, void* stream);
 
 /* ---- linear solves ("next" tier: the Mahalanobis half of the GP log-marginal likelihood) -------------------------
  *

@@ -77,3 +77,71 @@ def test_sharded_estimate_equals_single_process(tmp_path):
     assert np.isclose(got["mean"].item(), val, rtol=1e-12)
     assert np.isclose(got["std"].item(), np.std(vals), rtol=1e-9)
     assert np.allclose(got["gA"].numpy(), gA, rtol=1e-10, atol=1e-12)
+
+
+# ---- rows x probes grids (the strong-scaling layout): host logic + decomposition under gloo --------------------------
+N2, D2, K2, P2 = 200, 3, 6, 4  # 2 row shards of 128 and 72 rows (ragged)
+
+
+def _row_worker(rank, world, port, rows, out):
+    _setup_paths()
+    import datetime
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    import _sharded_oracle as so
+    from matfree_extensions.distributed import RowComm, make_grid, reduce_estimate, shard_probes
+    from oracle import slq_oracle as orc
+
+    X = np.random.default_rng(0).standard_normal((N2, D2))
+    raw = (np.array(0.4), np.array(0.2), np.array(-1.0))
+    row_group, probe_index, probe_groups = make_grid(rows) if world > rows else (None, 0, 1)
+    comm = RowComm(N2, row_group)
+    assert (comm.world, comm.nloc) == (rows, 128) and comm.nrows == (128 if comm.rank == 0 else 72)
+    first, count = shard_probes(P2, probe_index, probe_groups)
+    probes = orc.rademacher(3, count, N2, first_probe=first)
+    # gather_rows is the inverse of rows() on every rank
+    assert np.array_equal(comm.gather_rows(comm.rows(torch.as_tensor(probes))).numpy(), probes)
+    op = so.ShardedRbf(X, comm, noise_minval=1e-4)
+    vals, grads = [], np.zeros(3)
+    for v in probes:
+        val, g = so.integrand_value_and_grad(op, K2, v[comm.row0 : comm.row0 + comm.nrows], raw)
+        vals.append(val)
+        grads += np.array([float(x) for x in g])
+    mean, std, (g,) = reduce_estimate(torch.tensor(vals), (torch.tensor(grads),), P2, replicas=rows)
+    if rank == world - 1:
+        torch.save({"mean": mean, "std": std, "g": g}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _single_process_reference():
+    from oracle import slq_oracle as orc
+
+    X = np.random.default_rng(0).standard_normal((N2, D2))
+    raw = (np.array(0.4), np.array(0.2), np.array(-1.0))
+    probes = orc.rademacher(3, P2, N2)
+    return orc.hutchinson_value_and_grad(orc.RbfGramOp(X, noise_minval=1e-4), K2, probes, raw)
+
+
+def _run_grid(tmp_path, world, rows):
+    _setup_paths()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "last.pt")
+    mp.spawn(_row_worker, args=(world, port, rows, out), nprocs=world, join=True)
+    got = torch.load(out)
+    val, grads, vals = _single_process_reference()
+    assert np.isclose(got["mean"].item(), val, rtol=1e-11)
+    assert np.isclose(got["std"].item(), np.std(vals), rtol=1e-8)
+    assert np.allclose(got["g"].numpy(), np.array([float(x) for x in grads]), rtol=1e-9, atol=1e-12)
+
+
+def test_row_sharded_estimate_equals_single_process_world2(tmp_path):
+    _run_grid(tmp_path, 2, 2)
+
+
+def test_rows_x_probes_grid_2x2_equals_single_process(tmp_path):
+    _run_grid(tmp_path, 4, 2)

@@ -1,0 +1,190 @@
+"""Row-sharded Krylov drivers on the GPU (SURVEY.md §8(e), strong-scaling layout of BASELINE config 4).
+
+* row blocks of every native operator (`mfx_operator.row0 / nrows`): apply, transpose-apply and the parameter sweep of a
+  block equal the corresponding rows / the partial sums of the whole operator;
+* `mfx_arnoldi_*_sharded` with a one-rank communicator (all-gather = copy, all-reduce = identity) reproduce the
+  single-device drivers;
+* 2 and 4 PROCESSES sharing this one GPU (gloo moves the collectives through the host; RCCL needs one GPU per rank, which
+  the 1-GPU test box does not have): rows x probes grids 2x1, 4x1 and 2x2 reproduce the single-process estimate.
+"""
+
+import ctypes as C
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _rbf(n, d, dtype, precision="fp32", kernel="rbf", ard=True, seed=0):
+    from matfree_extensions.util import gp_util
+
+    g = torch.Generator().manual_seed(seed)
+    X = torch.randn((n, d), generator=g, dtype=torch.float64).to(dtype).to(_dev())
+    raw_l = torch.full((d,), 0.9, dtype=dtype, device=_dev()) if ard else torch.tensor(0.9, dtype=dtype, device=_dev())
+    params = [raw_l, torch.tensor(0.3, dtype=dtype, device=_dev()), torch.tensor(-1.0, dtype=dtype, device=_dev())]
+    return gp_util.gram_operator(X, noise_minval=1e-4, precision=precision, kernel=kernel), params
+
+
+def _apply_block(op, cparams, V, row0, nrows, transpose=0):
+    from matfree_extensions import _lib
+
+    p, n = V.shape
+    desc = op.descriptor(cparams, V.dtype, n)
+    desc.row0, desc.nrows = row0, nrows  # nrows = 0: the whole operator
+    nrows = nrows or n
+    ws = _lib.workspace(desc, n, 1, p, V.device)
+    y = torch.empty((p, nrows), dtype=V.dtype, device=V.device)
+    _lib.check(_lib.get().mfx_op_apply(C.byref(desc), _lib.ptr(V), n, _lib.ptr(y), nrows, p, transpose, _lib.ptr(ws), ws.numel(),
+                                       _lib.stream_ptr(V.device)))
+    return y
+
+
+def _grad_block(op, cparams, L, R, row0, nrows):
+    from matfree_extensions import _lib
+
+    batch, n = R.shape
+    desc = op.descriptor(cparams, R.dtype, n)
+    desc.row0, desc.nrows = row0, nrows
+    ws = _lib.workspace(desc, n, 1, batch, R.device)
+    gs, gt = op.new_grads(*cparams)
+    Lb = L[:, row0 : row0 + nrows].contiguous()
+    _lib.check(_lib.get().mfx_op_vjp_params(C.byref(desc), _lib.ptr(Lb), nrows, _lib.ptr(R), n, batch, C.byref(gs), _lib.ptr(ws),
+                                            ws.numel(), _lib.stream_ptr(R.device)))
+    return gt
+
+
+@pytest.mark.parametrize("dtype,precision,tol", [(torch.float64, "fp32", 1e-12), (torch.float32, "fp32", 2e-5),
+                                                 (torch.float32, "f16x3-matvec", 2e-5), (torch.float32, "f16x3", 2e-5)])
+@pytest.mark.parametrize("kernel", ["rbf", "matern32"])
+def test_gram_row_blocks_equal_the_rows_of_the_whole_operator(dtype, precision, tol, kernel):
+    n, d, p = 2600, 8, 40  # not a multiple of the 512-row workgroups; blocks start on multiples of 64
+    op, params = _rbf(n, d, dtype, precision, kernel)
+    cparams = op.constrain(*params)
+    g = torch.Generator().manual_seed(1)
+    V = torch.randn((p, n), generator=g, dtype=torch.float64).to(dtype).to(_dev())
+    full = _apply_block(op, cparams, V, 0, 0)
+    for row0, nrows in [(0, 1344), (1344, 1256), (640, 64), (2560, 40)]:
+        blk = _apply_block(op, cparams, V, row0, nrows)
+        ref = full[:, row0 : row0 + nrows]
+        assert torch.allclose(blk, ref, rtol=tol, atol=tol * ref.abs().max().item()), (row0, nrows, (blk - ref).abs().max())
+    # parameter sweep: the partial sums of the row blocks add up to the whole sweep
+    L = torch.randn((48, n), generator=g, dtype=torch.float64).to(dtype).to(_dev())
+    R = torch.randn((48, n), generator=g, dtype=torch.float64).to(dtype).to(_dev())
+    whole = _grad_block(op, cparams, L, R, 0, n)
+    parts = [_grad_block(op, cparams, L, R, r0, nr) for r0, nr in [(0, 1344), (1344, 1256)]]
+    gtol = 1e-10 if dtype == torch.float64 else 2e-4
+    for w, a, b in zip(whole, *parts):
+        assert torch.allclose(w, a + b, rtol=gtol, atol=gtol * w.abs().max().item()), (w, a + b)
+
+
+def test_dense_and_csr_row_blocks():
+    from matfree_extensions.operators import CsrOp, DenseOp
+
+    n, p = 300, 5
+    g = torch.Generator().manual_seed(2)
+    A = torch.randn((n, n), generator=g, dtype=torch.float64).to(_dev())
+    V = torch.randn((p, n), generator=g, dtype=torch.float64).to(_dev())
+    L = torch.randn((7, n), generator=g, dtype=torch.float64).to(_dev())
+    R = torch.randn((7, n), generator=g, dtype=torch.float64).to(_dev())
+    dop = DenseOp()
+    mask = torch.rand((n, n), generator=g) < 0.05
+    rows, cols = mask.nonzero(as_tuple=True)
+    cop, vals, _ = CsrOp.from_coo(rows, cols, A.cpu()[rows, cols], n, _dev())
+    Asp = torch.zeros_like(A)
+    Asp[rows.to(_dev()), cols.to(_dev())] = A[rows.to(_dev()), cols.to(_dev())]
+    for op, cparams, M in [(dop, (A,), A), (cop, (vals,), Asp)]:
+        for transpose in (0, 1):
+            ref = V @ (M if transpose else M.T)
+            for row0, nrows in [(0, 128), (128, 172), (37, 5)]:
+                blk = _apply_block(op, cparams, V, row0, nrows, transpose)
+                assert torch.allclose(blk, ref[:, row0 : row0 + nrows], rtol=1e-12, atol=1e-12)
+        whole = _grad_block(op, cparams, L, R, 0, n)[0]
+        parts = sum(_grad_block(op, cparams, L, R, r0, nr)[0] for r0, nr in [(0, 128), (128, 172)])
+        assert torch.allclose(whole, parts, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("dtype,precision,vtol,gtol", [(torch.float64, "fp32", 1e-10, 1e-8), (torch.float32, "f16x3", 2e-5, 5e-4)])
+def test_sharded_drivers_with_one_rank_equal_the_single_device_drivers(dtype, precision, vtol, gtol):
+    from matfree_extensions import hutchinson, lanczos
+    from matfree_extensions.distributed import RowComm
+    from matfree_extensions.operators import RowShardedOp
+
+    n, d, k, p = 2304, 8, 12, 8
+    op, params = _rbf(n, d, dtype, precision, ard=False)
+    probes = hutchinson.sampler_rademacher(torch.empty(n, dtype=dtype, device=_dev()), num=p)(3)
+
+    def run(matvec):
+        ps = [q.clone().requires_grad_(True) for q in params]
+        vals = lanczos.integrand_spd(torch.log, k, matvec)(probes, *ps)
+        return vals.detach(), torch.autograd.grad(vals.sum(), ps)
+
+    v0, g0 = run(op)
+    v1, g1 = run(RowShardedOp(op, RowComm(n)))
+    assert torch.allclose(v0, v1, rtol=vtol)
+    for a, b in zip(g0, g1):
+        assert torch.allclose(a, b, rtol=gtol, atol=gtol * a.abs().max().item()), (a, b)
+
+
+# ---- several processes on this one GPU -----------------------------------------------------------------------------
+_MP_SHAPE = (2290, 8, 12, 8)  # n = 2290: 4 ranks own 576, 576, 576, 562 rows (ragged last shard, no 16-byte alignment)
+
+
+def _worker(rank, world, port, rows, out, dtype_name, precision):
+    for p in (ROOT, os.path.join(ROOT, "experiments-lanczos-adjoints_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+
+    import datetime
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    from matfree_extensions.distributed import slq_value_and_grad
+
+    dtype = getattr(torch, dtype_name)
+    n, d, k, p = _MP_SHAPE
+    op, params = _rbf(n, d, dtype, precision, ard=False)
+    params = [q.clone().requires_grad_(True) for q in params]
+    mean, std, grads = slq_value_and_grad(op, torch.log, k, params, n=n, seed=3, num_probes=p, row_group_size=rows,
+                                          dtype=dtype, device=_dev())
+    torch.cuda.synchronize()
+    if rank == world - 1:  # the LAST rank reports: its shard is the ragged one
+        torch.save({"mean": mean.cpu(), "std": std.cpu(), "grads": [g.cpu() for g in grads]}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,rows", [(2, 2), (4, 4), (4, 2)])
+@pytest.mark.parametrize("dtype_name,precision,vtol,gtol", [("float64", "fp32", 1e-10, 1e-8), ("float32", "f16x3", 2e-5, 5e-4)])
+def test_row_sharded_processes_reproduce_the_single_process_estimate(tmp_path, world, rows, dtype_name, precision, vtol, gtol):
+    import torch.multiprocessing as mp
+
+    from matfree_extensions.distributed import slq_value_and_grad
+
+    dtype = getattr(torch, dtype_name)
+    n, d, k, p = _MP_SHAPE
+    op, params = _rbf(n, d, dtype, precision, ard=False)
+    params = [q.clone().requires_grad_(True) for q in params]
+    mean, std, grads = slq_value_and_grad(op, torch.log, k, params, n=n, seed=3, num_probes=p, dtype=dtype, device=_dev())
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "last.pt")
+    mp.spawn(_worker, args=(world, port, rows, out, dtype_name, precision), nprocs=world, join=True)
+    got = torch.load(out)
+    assert np.isclose(got["mean"].item(), mean.item(), rtol=vtol)
+    assert np.isclose(got["std"].item(), std.item(), rtol=1e-4, atol=1e-6 * abs(mean.item()))
+    for a, b in zip(got["grads"], grads):
+        assert torch.allclose(a, b.cpu(), rtol=gtol, atol=gtol * b.abs().max().item()), (a, b)
