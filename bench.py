@@ -1,21 +1,29 @@
 """Headline benchmark: SLQ log-det value-and-gradient for a matrix-free RBF GP kernel (BASELINE config 4).
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py --gpus N --steps K --warmup W [--scaling strong|weak] [--row-group R]
 
-One "step" = one SLQ log-determinant value AND gradient w.r.t. (raw_lengthscale, raw_outputscale,
-raw_noise) over this rank's batch of Hutchinson probes:  40 fully re-orthogonalised Lanczos steps
-(forward), the k x k eigen-quadrature, the Arnoldi adjoint scan (40 more Gram matvecs) and the deferred
-parameter-gradient sweep, followed by the single fused all-reduce of [sum q, sum q^2, sum dq/dtheta].
-Operator: X ~ N(0,1) of shape (131072, 8), lengthscale 2, outputscale 1, noise 0.1, fp32, 64 probes per
-GPU (weak scaling: probes are independent units, the operator is replicated, no data-path collective).
+N > 1 either under a launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...:
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment) or stand-alone: `python bench.py --gpus N` then starts
+the N ranks itself as child processes, BEFORE anything in the parent touches a GPU.
 
-Prints ONE JSON line on rank 0 (see the README / DESIGN.md for the field meanings).
+One "step" = one SLQ log-determinant value AND gradient w.r.t. (raw_lengthscale, raw_outputscale, raw_noise):
+40 fully re-orthogonalised Lanczos steps (forward), the k x k eigen-quadrature, the Arnoldi adjoint scan (40 more Gram
+matvecs) and the deferred parameter-gradient sweep, then the fused all-reduce of [sum q, sum q^2, sum dq/dtheta].
+Operator: X ~ N(0,1) of shape (131072, 8), lengthscale 2, outputscale 1, noise 0.1, fp32.
+
+  --scaling strong (default): BASELINE config 4 as written -- 64 probes in TOTAL on N GPUs.  The rows of the kernel matrix and
+      of every Krylov vector are sharded over the N ranks (all 64 probes on every rank): per Krylov step one all-gather of the
+      iterate and two or three small all-reduces of Gram-Schmidt coefficients.  --row-group R < N makes R-rank row groups
+      and shards the probes over the N / R groups.
+  --scaling weak: 64 probes PER GPU, probes sharded, operator replicated, one all-reduce per step.
+
+Prints ONE JSON line on rank 0 (DESIGN.md section 4 explains the fields).
 """
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -24,16 +32,14 @@ for _p in (ROOT, os.path.join(ROOT, "experiments-lanczos-adjoints_amd")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
 MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense
+MODES = ("f16x3", "f16x3-matvec", "fp32")
+DEFAULT_MODE = "f16x3"
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -41,127 +47,245 @@ def parse():
     ap.add_argument("--n", type=int, default=131072)
     ap.add_argument("--d", type=int, default=8)
     ap.add_argument("--k", type=int, default=40)
-    ap.add_argument("--probes-per-gpu", type=int, default=64)
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="strong: --probes in total over all GPUs, rows sharded (BASELINE config 4); weak: --probes per GPU, probes sharded")
+    ap.add_argument("--probes", type=int, default=64, help="probes in total (strong) or per GPU (weak)")
+    ap.add_argument("--probes-per-gpu", type=int, default=None, help="alias of --scaling weak --probes P")
+    ap.add_argument("--row-group", type=int, default=0, help="strong scaling: ranks per row group (0 = all ranks: pure row sharding)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-n", type=int, default=4608)
+    ap.add_argument("--no-modes", action="store_true", help="skip the timings of the other two arithmetic modes")
+    ap.add_argument("--cpu-sample-n", type=int, default=0, help="0 = calibrate so that one oracle run takes ~12 s")
     ap.add_argument("--kernel", default="rbf", choices=["rbf", "matern32", "matern12"],
                     help="kernel family (BASELINE config 4 is the RBF kernel; the reference's UCI runs use matern32)")
-    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f16x3-matvec", "fp32"],
-                    help="arithmetic of the fp32 Gram kernels: 3 x f16 split on the f16 matrix pipe (default; -matvec keeps the gradient GEMM in exact fp32) or exact fp32 MFMA")
-    return ap.parse_args()
+    ap.add_argument("--precision", default=DEFAULT_MODE, choices=list(MODES),
+                    help="arithmetic of the fp32 Gram kernels (DESIGN.md section 3.2): f16x3 = matvec and gradient GEMM emulated on the "
+                         "f16 matrix pipe (3 products, fp32 accumulate); f16x3-matvec = exact fp32 gradient GEMM; fp32 = exact fp32 MFMA")
+    ap.add_argument("--stub", default="", help="(tests) run the launcher / collection logic on this backend without any GPU work")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the N > 1 run (nccl = RCCL; gloo only to rehearse "
+                                                      "the multi-rank path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--share-gpus", action="store_true", help="(rehearsal) ranks beyond the visible GPUs share them (needs --backend gloo)")
+    args = ap.parse_args(argv)
+    if args.probes_per_gpu is not None:
+        args.scaling, args.probes = "weak", args.probes_per_gpu
+    return args
 
 
 def inv_softplus(x):
+    import numpy as np
+
     return float(np.log(np.expm1(x)))
 
 
+# ------------------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without a launcher starts its own ranks (the parent never touches a GPU)
+# ------------------------------------------------------------------------------------------------------------------------
+def launch_children(args, argv):
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        # rank 0 inherits stdout (its JSON line is the result); the others keep stderr only
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=None if rank == 0 else subprocess.DEVNULL))
+    rcs = [p.wait() for p in procs]
+    return next((rc for rc in rcs if rc != 0), 0)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# CPU baseline
+# ------------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(args):
-    """The oracle (NumPy port of the reference algorithm) on a bounded sample of the same workload:
-    identical d, k and hyper-parameters, ONE probe, n reduced to --cpu-sample-n; the Gram work scales
-    as n^2, so the full-size figure is the measured one times (n_sample / n)^2 (labelled estimate)."""
+    """The oracle (NumPy port of the reference algorithm, kind "port") on a bounded sample of the same workload: identical
+    d, k and hyper-parameters, ONE probe, n reduced.  Protocol: one warm-up, then the MEDIAN of 5 timed
+    runs at the sample size; the Gram work scales as n^2, so the full-size figure is the measured one times (n_sample / n)^2
+    (both are in the line)."""
+    import numpy as np
     from threadpoolctl import threadpool_limits
 
     from oracle import slq_oracle as orc
 
-    ns = args.cpu_sample_n
-    rng = np.random.default_rng(4)
-    X = rng.standard_normal((ns, args.d)).astype(np.float32)
     raw = tuple(np.float32(v) for v in (inv_softplus(2.0), inv_softplus(1.0), inv_softplus(0.1)))
-    probes = orc.rademacher(5, 1, ns, dtype=np.float32)
     threads = min(16, len(os.sched_getaffinity(0)))  # the 1-GPU box's CPU share is 16 cores
-    with threadpool_limits(limits=threads):
+
+    def once(ns):
+        rng = np.random.default_rng(4)
+        X = rng.standard_normal((ns, args.d)).astype(np.float32)
+        probes = orc.rademacher(5, 1, ns, dtype=np.float32)
         t0 = time.perf_counter()
         orc.hutchinson_value_and_grad(orc.RbfGramOp(X, cache_limit=0), args.k, probes, raw)
-        dt = time.perf_counter() - t0
-    measured = 1.0 / dt
-    est_full = measured * (ns / args.n) ** 2
+        return time.perf_counter() - t0
+
+    with threadpool_limits(limits=threads):
+        ns = args.cpu_sample_n
+        if ns <= 0:  # calibrate on a small run: aim at ~12 s per timed run (6 runs ~ 75 s)
+            t_cal = once(2048)
+            ns = int(min(16384, max(2048, 2048 * (12.0 / max(t_cal, 1e-3)) ** 0.5)) // 512 * 512)
+        once(ns)  # warm-up
+        times = sorted(once(ns) for _ in range(5))
+    med = times[2]
+    measured = 1.0 / med
     return {
-        "value": est_full,
+        "value": measured * (ns / args.n) ** 2,
         "unit": "probes/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"NumPy oracle, 1 probe, k={args.k}, d={args.d}, n={ns} (of {args.n}): {dt:.2f} s measured = "
-                  f"{measured:.4f} probes/s at n={ns}; value = that x (n_sample/n)^2 (Gram work ~ n^2), BLAS threads={threads}",
+        "measured_at_sample": {"n": ns, "probes_per_s": measured, "seconds_median_of_5": med, "seconds_all": times},
+        "sample": f"NumPy oracle (matrix-free kernel, re-evaluated per matvec), 1 probe, k={args.k}, d={args.d}, n={ns} (of {args.n}): "
+                  f"1 warm-up + median of 5 runs = {med:.2f} s = {measured:.4f} probes/s at n={ns}; value = that x (n_sample/n)^2 "
+                  f"(Gram work ~ n^2), BLAS threads={threads}",
     }
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+# ------------------------------------------------------------------------------------------------------------------------
+# one rank
+# ------------------------------------------------------------------------------------------------------------------------
+def run_stub(args, world, rank):
+    """launcher / collection logic without a GPU (tests/test_bench_launcher.py): rendezvous, barrier, max over ranks, one line"""
+    import torch
+    import torch.distributed as dist
+
+    if world > 1:
+        dist.init_process_group(args.stub)
+        dist.barrier()
+    t = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+    if rank == 0:
+        p_total = args.probes if args.scaling == "strong" else args.probes * world
+        print(json.dumps({"metric": "stub", "value": p_total / t.item(), "n_gpus": world, "scaling": args.scaling,
+                          "config": {"probes_total": p_total, "world_size_seen_by_rank0": dist.get_world_size() if world > 1 else 1}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_children(args, argv))
+    world = int(env_world or "1")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a number for another world size")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.stub:
+        return run_stub(args, world, rank)
+
+    import numpy as np  # noqa: F401
+    import torch
+    import torch.distributed as dist
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (there is no CPU product path)")
+    if args.share_gpus:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm; one rank per GPU
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm; one rank per GPU
+        else:
+            dist.init_process_group(args.backend)
 
     from matfree_extensions import _lib, hutchinson, lanczos
-    from matfree_extensions.distributed import reduce_estimate, shard_probes
+    from matfree_extensions.distributed import Layout, reduce_estimate, shard_probes
+    from matfree_extensions.operators import RowShardedOp
     from matfree_extensions.util import gp_util
 
-    n, d, k, p = args.n, args.d, args.k, args.probes_per_gpu
-    p_total = p * world
+    n, d, k = args.n, args.d, args.k
+    strong = args.scaling == "strong"
+    p_total = args.probes if strong else args.probes * world
+    row_group = (args.row_group or world) if strong else 1
+    layout = Layout(n, row_group if world > 1 else 1)
+    first, count = shard_probes(p_total, layout.probe_index, layout.probe_groups)
     gen = torch.Generator().manual_seed(4)
     X = torch.randn((n, d), generator=gen, dtype=torch.float32).to(dev)
     params = [torch.tensor(v, dtype=torch.float32, device=dev, requires_grad=True)
               for v in (inv_softplus(2.0), inv_softplus(1.0), inv_softplus(0.1))]
-    op = gp_util.gram_operator(X, precision=args.precision, kernel=args.kernel)
-    integrand = lanczos.integrand_spd(torch.log, k, op)
-    first, count = shard_probes(p_total, rank, world)
     sampler = hutchinson.sampler_rademacher(X[:, 0], num=count)
 
-    def step(seed):
-        probes = sampler((seed, first))  # this rank's slice of ONE global +-1 probe matrix
-        values = integrand(probes, *params)
-        grads = torch.autograd.grad(values.sum(), params)
-        return reduce_estimate(values.detach(), grads, p_total)
+    def make_step(precision):
+        op = gp_util.gram_operator(X, precision=precision, kernel=args.kernel)
+        matvec = RowShardedOp(op, layout.comm) if layout.comm is not None else op
+        integrand = lanczos.integrand_spd(torch.log, k, matvec)
+
+        def step(seed):
+            probes = sampler((seed, first))  # this probe group's slice of ONE global +-1 probe matrix
+            if layout.comm is not None:
+                probes = layout.comm.rows(probes)
+            values = integrand(probes, *params)
+            grads = torch.autograd.grad(values.sum(), params)
+            return reduce_estimate(values.detach(), grads, p_total, replicas=layout.replicas)
+
+        return step
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(step, steps, warmup):
+        out = None
+        for w in range(warmup):
+            out = step(100 + w)
+        fence()
+        t0 = time.perf_counter()
+        for s in range(steps):
+            out = step(s)
+        fence()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.item(), out
+
+    step = make_step(args.precision)
     for w in range(args.warmup):
-        out = step(100 + w)
+        step(100 + w)
     fence()
     _lib.timing_reset()
     _lib.timing_enable(True)
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        out = step(s)
-    fence()
-    elapsed = time.perf_counter() - t0
+    elapsed, out = timed(step, args.steps, 0)
     _lib.timing_enable(False)
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = t.item()
-
     apply_ms, apply_cnt = _lib.timing_read(0)
     grad_ms, grad_cnt = _lib.timing_read(1)
     vec_ms, vec_cnt = _lib.timing_read(2)
+    comm_ms, comm_cnt = _lib.timing_read(3)
     _lib.timing_reset()
+
+    modes = {args.precision: 1e3 * elapsed / args.steps}
+    if not args.no_modes:
+        for mode in MODES:
+            if mode != args.precision:
+                t, _ = timed(make_step(mode), 2, 1)
+                modes[mode] = 1e3 * t / 2
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = p_total * args.steps / elapsed
-        # dominant kernel: the RBF Gram matvec.  Algorithmic flops per launch: the contraction 2 n^2 p
-        # (what the matrix cores must deliver); distance + exp are extra work priced in DESIGN.md.
-        flops_launch = 2.0 * n * n * p
+        # dominant kernel: the Gram matvec.  Algorithmic flops per launch: the contraction 2 rows n p on this rank (what the matrix
+        # cores must deliver); distance + exp are extra work priced in DESIGN.md.
+        rows_local = layout.comm.nrows if layout.comm is not None else n
+        flops_launch = 2.0 * rows_local * n * count
         avg_ms = apply_ms / max(apply_cnt, 1)
         achieved = flops_launch / (avg_ms * 1e-3) / 1e12 if apply_cnt else 0.0
         split = args.precision.startswith("f16x3")
         peak = MFMA_F16_PEAK_TFLOPS if split else MFMA_F32_PEAK_TFLOPS
-        kernel = ("k_rbf_mfma_apply_h3 (Gram matvec, fp32 emulated by 3 f16 MFMA products, distances included)"
-                  if split else "k_rbf_mfma_apply (Gram matvec, exact fp32 MFMA)")
+        kernel = ("k_rbf_mfma_apply_h3 (Gram matvec, fp32 emulated by 3 f16 MFMA products, distances included; pre-pass and "
+                  "split reduction inside the timed span)" if split else "k_rbf_mfma_apply (Gram matvec, exact fp32 MFMA)")
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile):
+        if os.path.exists(tfile) and world == 1:
             traffic = json.load(open(tfile)).get("k_rbf_mfma_apply_h3_hbm_bytes_per_launch" if split
                                                  else "k_rbf_mfma_apply_hbm_bytes_per_launch")
         mean, std, grads = out
+        batch = count * k
         line = {
             "metric": "slq_logdet_value_and_grad_throughput",
             "value": value,
@@ -171,17 +295,21 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": "f32" if not split else "f32 (Gram contraction emulated with 3 f16 MFMA products, fp32 accumulate)",
+            "dtype": "f32" if not split else "f32 (Gram contraction emulated with 3 f16 MFMA products, fp32 accumulate; accuracy vs "
+                                             "fp64 at this size: profiles/r02a_accuracy)",
             "data": "synthetic",
             "config": {
-                "workload": f"matrix-free RBF GP kernel N={n} d={d}, SLQ log-det value+grad, {k} Lanczos steps "
-                            f"(full reortho) x {p} probes per GPU, fp32 (BASELINE config 4)",
-                "N": n, "d": d, "krylov_depth": k, "probes_per_gpu": p, "probes_total": p_total,
-                "parallelism": f"probe-sharded x{world}, operator replicated, one all-reduce per step",
+                "workload": f"matrix-free RBF GP kernel N={n} d={d}, SLQ log-det value+grad, {k} Lanczos steps (full reortho) x "
+                            f"{p_total} probes, fp32 (BASELINE config 4)",
+                "N": n, "d": d, "krylov_depth": k, "probes_total": p_total, "probes_on_this_rank": count,
+                "rows_on_this_rank": rows_local,
+                "parallelism": f"{layout.describe()}; world size seen by rank 0 = {dist.get_world_size() if world > 1 else 1}",
                 "gram_precision": args.precision, "kernel": args.kernel,
             },
+            "modes": {"ms_per_step": modes,
+                      "note": "same process, same inputs; the timed mode has --steps steps, the others 2 steps after 1 warm-up"},
             "roofline": {
                 "kernel": kernel + f", {apply_cnt // max(args.steps, 1)} launches per step",
                 "bound": "mfma",
@@ -201,18 +329,19 @@ def main():
                 "gram_matvec": apply_ms / args.steps,
                 "param_grad_sweep": grad_ms / args.steps,
                 "krylov_vector_kernels": vec_ms / args.steps,
+                "allgather_incl_pack_unpack": comm_ms / args.steps,  # (the small all-reduces sit inside krylov_vector_kernels)
             },
             "param_grad_gemm": {
-                # S = L^T R over all (probe, step) pairs, batch = p (k + 1): algorithmic flops 2 n^2 batch, once per step
-                "algorithmic_flops": 2.0 * n * n * p * (k + 1),
-                "achieved_TFLOPs": 2.0 * n * n * p * (k + 1) / max(grad_ms / max(grad_cnt, 1) * 1e-3, 1e-12) / 1e12,
+                # S = L^T R over all (probe, step) pairs of this rank: algorithmic flops 2 rows n batch, once per step
+                "algorithmic_flops": 2.0 * rows_local * n * batch,
+                "achieved_TFLOPs": 2.0 * rows_local * n * batch / max(grad_ms / max(grad_cnt, 1) * 1e-3, 1e-12) / 1e12,
                 "peak_TFLOPs": MFMA_F16_PEAK_TFLOPS if args.precision == "f16x3" else MFMA_F32_PEAK_TFLOPS,
                 "executed_mfma_flops_factor": 3.0 if args.precision == "f16x3" else 1.0,
             },
             "krylov_vector_hbm": {
-                # B_fwd + B_bwd = p n s [2k(k+1)+3k] + p n s [3k^2+9k] algorithmic bytes
-                "algorithmic_GB_per_step": p * n * 4 * (2 * k * (k + 1) + 3 * k + 3 * k * k + 9 * k) / 1e9,
-                "achieved_GBps": (p * n * 4 * (2 * k * (k + 1) + 3 * k + 3 * k * k + 9 * k) / 1e9)
+                # B_fwd + B_bwd = p n s [2k(k+1)+3k] + p n s [3k^2+9k] algorithmic bytes (this rank's rows)
+                "algorithmic_GB_per_step": count * rows_local * 4 * (2 * k * (k + 1) + 3 * k + 3 * k * k + 9 * k) / 1e9,
+                "achieved_GBps": (count * rows_local * 4 * (2 * k * (k + 1) + 3 * k + 3 * k * k + 9 * k) / 1e9)
                                  / max(vec_ms / args.steps * 1e-3, 1e-12),
                 "peak_GBps": HBM_PEAK_GBS,
             },

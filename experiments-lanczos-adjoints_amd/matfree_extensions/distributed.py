@@ -217,32 +217,55 @@ def make_grid(rows: int, group=None):
     return mine, rank // rows, ngroups
 
 
+class Layout:
+    """A (row groups x probe groups) grid over the ranks of ``group``, built ONCE (process groups are collective to create).
+
+    row_group_size = 1: pure probe sharding; = world size: pure row sharding (all probes on every rank).
+    """
+
+    def __init__(self, n: int, row_group_size: int = 1, group=None):
+        on = dist.is_available() and dist.is_initialized()
+        self.group = group
+        self.world = dist.get_world_size(group) if on else 1
+        rank = dist.get_rank(group) if on else 0
+        self.n = int(n)
+        self.replicas = int(row_group_size)
+        if self.replicas > 1:
+            if self.world > self.replicas:
+                row_group, self.probe_index, self.probe_groups = make_grid(self.replicas, group)
+            elif self.world == self.replicas:
+                row_group, self.probe_index, self.probe_groups = group, 0, 1
+            else:
+                raise ValueError(f"row group size {row_group_size} exceeds the world size {self.world}")
+            self.comm = RowComm(n, row_group)
+        else:
+            self.comm, self.probe_index, self.probe_groups = None, rank, self.world
+
+    def describe(self):
+        return f"{self.replicas} row shard(s) x {self.probe_groups} probe group(s)"
+
+
 def slq_value_and_grad(op, matfun, krylov_depth, params, *, n: int, seed, num_probes: int, row_group_size: int = 1,
-                       group=None, dtype=None, device=None):
+                       group=None, dtype=None, device=None, layout: Layout | None = None):
     """SLQ value-and-gradient on a (row groups x probe groups) grid of ranks.
 
     op             : native operator (e.g. gp_util.gram_operator(X)) -- replicated, X is a few MB
-    row_group_size : ranks per row group (1 = pure probe sharding, world size = pure row sharding)
+    row_group_size : ranks per row group (1 = pure probe sharding, world size = pure row sharding); or pass a ``Layout``
+                     built once when the estimate is evaluated repeatedly
     -> (mean, std over probes, gradients of the mean), identical on every rank.
     """
     from . import hutchinson, lanczos
     from .operators import RowShardedOp
 
-    on = dist.is_available() and dist.is_initialized()
-    world = dist.get_world_size(group) if on else 1
-    if row_group_size > 1:
-        row_group, probe_index, probe_groups = make_grid(row_group_size, group) if world > row_group_size else (group, 0, 1)
-    else:
-        row_group, probe_index, probe_groups = None, (dist.get_rank(group) if on else 0), world
-    first, count = shard_probes(num_probes, probe_index, probe_groups)
+    lay = layout if layout is not None else Layout(n, row_group_size, group)
+    first, count = shard_probes(num_probes, lay.probe_index, lay.probe_groups)
     like = torch.empty(n, dtype=dtype, device=device)
     probes = hutchinson.sampler_rademacher(like, num=count)((seed, first))  # this group's slice of ONE global probe matrix
-    if row_group_size > 1:
-        comm = RowComm(n, row_group)
-        probes = comm.rows(probes)
-        matvec = RowShardedOp(op, comm)
+    if lay.comm is not None:
+        probes = lay.comm.rows(probes)
+        matvec = RowShardedOp(op, lay.comm)
     else:
         matvec = op
     integrand = lanczos.integrand_spd(matfun, krylov_depth, matvec)
-    return value_and_grad_sharded(integrand, lambda: probes, params, num_total=num_probes, group=group,
-                                  replicas=row_group_size if row_group_size > 1 else 1)
+    return value_and_grad_sharded(integrand, lambda: probes, params, num_total=num_probes, group=lay.group,
+                                  replicas=lay.replicas)

@@ -116,14 +116,23 @@ def slq_rbf():
 
 
 def csr_1138_bus():
-    path = "/root/reference/data/matrices/1138_bus/1138_bus.mtx"
+    csr_suite_sparse("1138_bus", 12)
+
+
+def csr_bloweybq():
+    """SuiteSparse bloweybq (n = 10 001, 69 991 stored values after symmetric expansion): the second local matrix SURVEY.md
+    section 8(d) names for BASELINE config 3 parity."""
+    csr_suite_sparse("bloweybq", 6)
+
+
+def csr_suite_sparse(name, k):
+    path = f"/root/reference/data/matrices/{name}/{name}.mtx"
     import scipy.io
 
     M = scipy.io.mmread(path)  # symmetric expansion, as util/exp_util.py:36
     row, col, vals, n = M.row.astype(np.int64), M.col.astype(np.int64), M.data.astype(np.float64), M.shape[0]
     rng = np.random.default_rng(1)
     v = rng.standard_normal(n)
-    k = 12
     op = orc.CooOp(row, col, n)
     out = {"row": row, "col": col, "vals": vals, "v": v, "k": np.array(k)}
     for reortho in ("full", "none"):
@@ -136,7 +145,42 @@ def csr_1138_bus():
         out.update({pre + "d": d, pre + "e": e, pre + "b": b, pre + "dQ": cot[0][0], pre + "dd": cot[0][1][0],
                     pre + "de": cot[0][1][1], pre + "dq": cot[1][0], pre + "db": cot[1][1], pre + "dv": dv,
                     pre + "dvals": dvals})
-    save("csr_1138_bus.npz", **out)
+    if name != "1138_bus":  # keep the larger fixture small: int32 indices
+        out["row"], out["col"] = row.astype(np.int32), col.astype(np.int32)
+    save(f"csr_{name}.npz", **out)
+
+
+def pde_wave():
+    """The ONE numeric fixture the reference itself holds for this tier: data/pde_wave/16x16_data_{inputs,parameter,targets}.npy,
+    written by experiments/applications/partial_differential_equation/make_data.py:52-103 -- initial states (y0, dy0), the
+    coefficient field and the states at t = 1 of the anisotropic wave system (Neumann boundary, scale = parameter^2, mesh
+    linspace(0, 1, 16), Dopri8 with 128 steps, fp32).  Copied as data; the tests compare expm(A) y0 against `targets`."""
+    d = "/root/reference/data/pde_wave/16x16_data_"
+    save("pde_wave_16x16.npz", inputs=np.load(d + "inputs.npy"), parameter=np.load(d + "parameter.npy"),
+         targets=np.load(d + "targets.npy"))
+
+
+def uci_protein():
+    """BASELINE config 2's actual input, down-sized: the first 2048 rows of data/uci/protein/data.csv.gz (45 730 x 10, no header;
+    the first 9 columns are the inputs), z-scored with the statistics of ALL rows as uci_util.py:229-230 does, and
+    the oracle's SLQ log-det value-and-gradient at C2's settings (k = 30, 8 probes, raw parameters 0, noise floor 1e-4)."""
+    import pandas as pd
+
+    raw = pd.read_csv("/root/reference/data/uci/protein/data.csv.gz", header=None).values.astype(np.float64)
+    assert raw.shape == (45730, 10)
+    Xall = raw[:, :9]
+    Xall = (Xall - Xall.mean(0)) / Xall.std(0)
+    X = Xall[:2048]
+    k, p, seed = 30, 8, 2
+    probes = orc.rademacher(seed, p, X.shape[0])
+    out = {"X": X, "k": np.array(k), "seed": np.array(seed), "num_probes": np.array(p), "noise_minval": np.array(1e-4),
+           "col_mean": raw[:, :9].mean(0), "col_std": raw[:, :9].std(0)}
+    for tag, raw_l in (("ard", np.zeros(9)), ("iso", np.array(0.0))):
+        params = (raw_l, np.array(0.0), np.array(0.0))
+        val, grads, vals = orc.hutchinson_value_and_grad(orc.RbfGramOp(X, noise_minval=1e-4), k, probes, params)
+        out.update({f"{tag}_value": np.array(val), f"{tag}_values": vals, f"{tag}_g_l": grads[0], f"{tag}_g_s": np.array(grads[1]),
+                    f"{tag}_g_n": np.array(grads[2])})
+    save("uci_protein_2048.npz", **out)
 
 
 def gp_logml():
@@ -178,8 +222,9 @@ def gp_logml():
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "gp_logml":
-        gp_logml()
+    if len(sys.argv) > 1:  # regenerate single fixtures: python make_golden.py pde_wave csr_bloweybq uci_protein ...
+        for name in sys.argv[1:]:
+            globals()[name]()
         sys.exit(0)
     tridiag_forward()
     arnoldi_adjoint()
@@ -187,4 +232,7 @@ if __name__ == "__main__":
     slq_dense()
     slq_rbf()
     csr_1138_bus()
+    csr_bloweybq()
+    pde_wave()
+    uci_protein()
     gp_logml()
