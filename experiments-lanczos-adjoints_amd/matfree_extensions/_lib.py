@@ -207,32 +207,57 @@ def stream_ptr(device=None):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-_ws_cache = {}
+_ws_cache = {}  # (device index, stream) -> list of scratch buffers
+_ws_busy = set()  # id() of buffers a driver call in progress is using
+
+
+def _take(need: int, device) -> torch.Tensor:
+    """A scratch buffer of at least ``need`` bytes, cached per (device, stream) so repeated calls do not re-allocate.
+    A buffer that a driver call in progress holds (``busy``) is never handed out again: a CallbackOp whose Python matvec
+    calls a native operator re-enters here while the outer Krylov driver still keeps its iterate, partial sums and adjoint
+    state at the start of ITS buffer."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    bufs = _ws_cache.setdefault(key, [])
+    for i, buf in enumerate(bufs):
+        if id(buf) in _ws_busy:
+            continue
+        if buf.numel() < need:
+            buf = torch.empty(int(need) + 256, dtype=torch.uint8, device=device)
+            bufs[i] = buf
+        return buf
+    buf = torch.empty(int(need) + 256, dtype=torch.uint8, device=device)
+    bufs.append(buf)
+    return buf
+
+
+class busy:
+    """``with _lib.busy(ws): lib.mfx_...(ws)`` -- marks the buffer as in use for the duration of a call that may call back
+    into Python (callback operators, row-sharded collectives)."""
+
+    def __init__(self, buf):
+        self.key = id(buf)
+
+    def __enter__(self):
+        _ws_busy.add(self.key)
+
+    def __exit__(self, *exc):
+        _ws_busy.discard(self.key)
+        return False
 
 
 def workspace(desc: Operator, n: int, k: int, p: int, device) -> torch.Tensor:
-    """Caller-owned scratch, cached per (device, size bucket) so repeated calls do not re-allocate."""
+    """Caller-owned scratch for the Krylov drivers / operator calls of an (n, k, p) problem."""
     need = int(get().mfx_workspace_bytes(C.byref(desc), n, k, p))
     if need < 0:
         raise MfxError("mfx_workspace_bytes failed")
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-    buf = _ws_cache.get(key)
-    if buf is None or buf.numel() < need:
-        buf = torch.empty(int(need * 1.0) + 256, dtype=torch.uint8, device=device)
-        _ws_cache[key] = buf
-    return buf
+    return _take(need, device)
 
 
 def scratch(need: int, device) -> torch.Tensor:
     """Caller-owned scratch of at least ``need`` bytes from the same per-(device, stream) cache."""
     if need < 0:
         raise MfxError("workspace size query failed")
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-    buf = _ws_cache.get(key)
-    if buf is None or buf.numel() < need:
-        buf = torch.empty(int(need) + 256, dtype=torch.uint8, device=device)
-        _ws_cache[key] = buf
-    return buf
+    return _take(int(need), device)
 
 
 def workspace_pcg(desc: Operator, n: int, p: int, rank: int, device) -> torch.Tensor:

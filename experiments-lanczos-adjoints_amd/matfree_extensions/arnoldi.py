@@ -96,9 +96,10 @@ class _ArnoldiFn(torch.autograd.Function):
             for t in (V, Q, r):
                 reg.add(t)
             reg.add_bytes(ws, dt)
-        rc = lib.mfx_arnoldi_forward(C.byref(desc), _lib.ptr(V), n, k, p, int(second_pass), _lib.ptr(Q),
-                                     _lib.ptr(H), _lib.ptr(r), _lib.ptr(c), _lib.ptr(ws), ws.numel(),
-                                     _lib.stream_ptr(dev))
+        with _lib.busy(ws):
+            rc = lib.mfx_arnoldi_forward(C.byref(desc), _lib.ptr(V), n, k, p, int(second_pass), _lib.ptr(Q),
+                                         _lib.ptr(H), _lib.ptr(r), _lib.ptr(c), _lib.ptr(ws), ws.numel(),
+                                         _lib.stream_ptr(dev))
         if keep is not None and keep[1]:
             raise keep[1][0]
         _lib.check(rc)
@@ -140,11 +141,12 @@ class _ArnoldiFn(torch.autograd.Function):
             for t in (Q, r, Lam, dv, dQ, dr):
                 reg.add(t)
             reg.add_bytes(ws, dt)
-        rc = lib.mfx_arnoldi_adjoint(C.byref(desc), n, k, p, _lib.ptr(Q), _lib.ptr(H), _lib.ptr(r), _lib.ptr(c),
-                                     _lib.ptr(dQ), _lib.ptr(dH), _lib.ptr(dr), _lib.ptr(dc),
-                                     _lib.REORTHO_FULL if ctx.reortho == "full" else _lib.REORTHO_NONE,
-                                     _lib.ptr(dv), _lib.ptr(Lam), gptr, _lib.ptr(ws), ws.numel(),
-                                     _lib.stream_ptr(dev))
+        with _lib.busy(ws):
+            rc = lib.mfx_arnoldi_adjoint(C.byref(desc), n, k, p, _lib.ptr(Q), _lib.ptr(H), _lib.ptr(r), _lib.ptr(c),
+                                         _lib.ptr(dQ), _lib.ptr(dH), _lib.ptr(dr), _lib.ptr(dc),
+                                         _lib.REORTHO_FULL if ctx.reortho == "full" else _lib.REORTHO_NONE,
+                                         _lib.ptr(dv), _lib.ptr(Lam), gptr, _lib.ptr(ws), ws.numel(),
+                                         _lib.stream_ptr(dev))
         if keep is not None and keep[1]:
             raise keep[1][0]
         _lib.check(rc)
@@ -175,9 +177,10 @@ class _ArnoldiShardedFn(torch.autograd.Function):
         cm0.rank, cm0.world, cm0.nloc = comm.rank, comm.world, comm.nloc
         ws = _lib.scratch(int(lib.mfx_sharded_workspace_bytes(C.byref(desc), C.byref(cm0), n, k, p)), dev)
         cm, keep = comm.struct(ws)
-        rc = lib.mfx_arnoldi_forward_sharded(C.byref(desc), C.byref(cm), _lib.ptr(V), n, k, p, int(second_pass),
-                                             _lib.ptr(Q), _lib.ptr(Qfull), _lib.ptr(H), _lib.ptr(r), _lib.ptr(c),
-                                             _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+        with _lib.busy(ws):
+            rc = lib.mfx_arnoldi_forward_sharded(C.byref(desc), C.byref(cm), _lib.ptr(V), n, k, p, int(second_pass),
+                                                 _lib.ptr(Q), _lib.ptr(Qfull), _lib.ptr(H), _lib.ptr(r), _lib.ptr(c),
+                                                 _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
         if keep[2]:
             raise keep[2][0]
         _lib.check(rc)
@@ -211,11 +214,12 @@ class _ArnoldiShardedFn(torch.autograd.Function):
         cm0.rank, cm0.world, cm0.nloc = comm.rank, comm.world, comm.nloc
         ws = _lib.scratch(int(lib.mfx_sharded_workspace_bytes(C.byref(desc), C.byref(cm0), n, k, p)), dev)
         cm, keep = comm.struct(ws)
-        rc = lib.mfx_arnoldi_adjoint_sharded(C.byref(desc), C.byref(cm), n, k, p, _lib.ptr(Q), _lib.ptr(Qfull), _lib.ptr(H),
-                                             _lib.ptr(r), _lib.ptr(c), _lib.ptr(dQ), _lib.ptr(dH), _lib.ptr(dr), _lib.ptr(dc),
-                                             _lib.REORTHO_FULL if ctx.reortho == "full" else _lib.REORTHO_NONE,
-                                             _lib.ptr(dv), _lib.ptr(Lam), C.byref(gstruct), _lib.ptr(ws), ws.numel(),
-                                             _lib.stream_ptr(dev))
+        with _lib.busy(ws):
+            rc = lib.mfx_arnoldi_adjoint_sharded(C.byref(desc), C.byref(cm), n, k, p, _lib.ptr(Q), _lib.ptr(Qfull), _lib.ptr(H),
+                                                 _lib.ptr(r), _lib.ptr(c), _lib.ptr(dQ), _lib.ptr(dH), _lib.ptr(dr), _lib.ptr(dc),
+                                                 _lib.REORTHO_FULL if ctx.reortho == "full" else _lib.REORTHO_NONE,
+                                                 _lib.ptr(dv), _lib.ptr(Lam), C.byref(gstruct), _lib.ptr(ws), ws.numel(),
+                                                 _lib.stream_ptr(dev))
         if keep[2]:
             raise keep[2][0]
         _lib.check(rc)

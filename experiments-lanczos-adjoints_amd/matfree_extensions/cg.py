@@ -132,17 +132,19 @@ def _run(op, cfg, P, B, cparams):
         if m < 1:
             raise ValueError("pcg_fixed_step_reortho needs num_matvecs >= 1")
         Q = torch.zeros((p, m, n), dtype=dt, device=dev)
-        rc = lib.mfx_pcg_solve_reortho(C.byref(desc), _lib.ptr(B), n, n, p, _lib.ptr(lt), rank, _lib.ptr(minv),
-                                       _lib.ptr(shift), m, _lib.ptr(x), _lib.ptr(r), _lib.ptr(Q), _lib.ptr(ws), ws.numel(),
-                                       _lib.stream_ptr(dev))
+        with _lib.busy(ws):
+            rc = lib.mfx_pcg_solve_reortho(C.byref(desc), _lib.ptr(B), n, n, p, _lib.ptr(lt), rank, _lib.ptr(minv),
+                                           _lib.ptr(shift), m, _lib.ptr(x), _lib.ptr(r), _lib.ptr(Q), _lib.ptr(ws), ws.numel(),
+                                           _lib.stream_ptr(dev))
         if keep is not None and keep[1]:
             raise keep[1][0]
         _lib.check(rc)
         return x, r, Q
     steps = torch.empty((p,), dtype=torch.int64, device=dev)
-    rc = lib.mfx_pcg_solve(C.byref(desc), _lib.ptr(B), n, n, p, _lib.ptr(lt), rank, _lib.ptr(minv), _lib.ptr(shift),
-                           cfg["maxiter"], cfg["miniter"], cfg["atol"], cfg["rtol"], int(cfg["adaptive"]),
-                           _lib.ptr(x), _lib.ptr(r), _lib.ptr(steps), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+    with _lib.busy(ws):
+        rc = lib.mfx_pcg_solve(C.byref(desc), _lib.ptr(B), n, n, p, _lib.ptr(lt), rank, _lib.ptr(minv), _lib.ptr(shift),
+                               cfg["maxiter"], cfg["miniter"], cfg["atol"], cfg["rtol"], int(cfg["adaptive"]),
+                               _lib.ptr(x), _lib.ptr(r), _lib.ptr(steps), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
     if keep is not None and keep[1]:
         raise keep[1][0]
     _lib.check(rc)

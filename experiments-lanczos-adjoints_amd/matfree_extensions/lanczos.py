@@ -109,9 +109,10 @@ class _LanczosFn(torch.autograd.Function):
             for t in (V, xs):
                 reg.add(t)
             reg.add_bytes(ws, dt)
-        rc = lib.mfx_lanczos_forward(C.byref(desc), _lib.ptr(V), n, k, p, _lib.ptr(xs), _lib.ptr(alpha),
-                                     _lib.ptr(beta), _lib.ptr(vnorm), _lib.ptr(ws), ws.numel(),
-                                     _lib.stream_ptr(dev))
+        with _lib.busy(ws):
+            rc = lib.mfx_lanczos_forward(C.byref(desc), _lib.ptr(V), n, k, p, _lib.ptr(xs), _lib.ptr(alpha),
+                                         _lib.ptr(beta), _lib.ptr(vnorm), _lib.ptr(ws), ws.numel(),
+                                         _lib.stream_ptr(dev))
         if keep is not None and keep[1]:
             raise keep[1][0]
         _lib.check(rc)
@@ -151,10 +152,11 @@ class _LanczosFn(torch.autograd.Function):
             for t in (xs, Lam, dv, dxs):
                 reg.add(t)
             reg.add_bytes(ws, dt)
-        rc = lib.mfx_lanczos_adjoint(C.byref(desc), n, k, p, _lib.ptr(xs), _lib.ptr(alpha), _lib.ptr(beta),
-                                     _lib.ptr(vnorm), _lib.ptr(dxs), _lib.ptr(dalpha), _lib.ptr(dbeta),
-                                     _lib.ptr(dv), _lib.ptr(Lam), gptr, _lib.ptr(ws), ws.numel(),
-                                     _lib.stream_ptr(dev))
+        with _lib.busy(ws):
+            rc = lib.mfx_lanczos_adjoint(C.byref(desc), n, k, p, _lib.ptr(xs), _lib.ptr(alpha), _lib.ptr(beta),
+                                         _lib.ptr(vnorm), _lib.ptr(dxs), _lib.ptr(dalpha), _lib.ptr(dbeta),
+                                         _lib.ptr(dv), _lib.ptr(Lam), gptr, _lib.ptr(ws), ws.numel(),
+                                         _lib.stream_ptr(dev))
         if keep is not None and keep[1]:
             raise keep[1][0]
         _lib.check(rc)

@@ -112,3 +112,112 @@ def test_gp_logml_fixture_is_self_consistent(kind):
     assert abs(fd_s - float(g[kind + "_g_s"])) <= 5e-2 * abs(fd_s) + 1e-3
     fd_c = (value(raw, float(g["cval"]) + h) - value(raw, float(g["cval"]) - h)) / (2 * h)
     assert abs(fd_c - float(g[kind + "_g_c"])) <= 5e-2 * abs(fd_c) + 1e-3
+
+
+# ---- fixtures that hold REFERENCE-produced numbers or reference data files ------------------------------------------------
+def _wave_rhs(x, scale, dx):
+    """pde_wave_anisotropic(...)(scale)(x) with boundary_neumann, restated from the reference text (util/pde_util.py:126-143,
+    153-157, stencil_laplacian :18-20): x = (u, du) -> (du, scale o conv2d(stencil, pad_edge(u), "valid"))."""
+    u, du = x
+    res = u.shape[0]
+    up = np.pad(u, 1, mode="edge")
+    st = np.array([[0.0, 1.0, 0.0], [1.0, -2.0, 1.0], [0.0, 1.0, 0.0]]) / dx**2
+    fx = sum(st[a, b] * up[2 - a : 2 - a + res, 2 - b : 2 - b + res] for a in range(3) for b in range(3))  # convolution = flipped stencil
+    return np.stack([du, fx * scale])
+
+
+def _wave_matrix(parameter, dx):
+    res = parameter.shape[0]
+    n = 2 * res * res
+    A = np.zeros((n, n))
+    for j in range(n):
+        e = np.zeros(n)
+        e[j] = 1.0
+        A[:, j] = _wave_rhs(e.reshape(2, res, res), parameter**2, dx).reshape(-1)  # constrain = jnp.square (make_data.py:55-57)
+    return A
+
+
+def test_pde_wave_reference_targets_are_reproduced_by_the_restated_wave_operator():
+    """Known-answer test against numbers the REFERENCE produced (data/pde_wave/16x16_*.npy, make_data.py:28-30,52-103: Dopri8, 128
+    steps, fp32, t 0 -> 1): the system is linear, so targets = expm(A) inputs.  Achieved: 1.8e-6 of the largest entry."""
+    import scipy.linalg
+
+    g = np.load(os.path.join(GOLD, "pde_wave_16x16.npz"))
+    inputs, parameter, targets = (g[k].astype(np.float64) for k in ("inputs", "parameter", "targets"))
+    assert inputs.shape == (3, 2, 16, 16) and parameter.shape == (16, 16)
+    A = _wave_matrix(parameter, 1.0 / 15.0)
+    E = scipy.linalg.expm(A)
+    for y0, y1 in zip(inputs, targets):
+        out = (E @ y0.reshape(-1)).reshape(y1.shape)
+        assert np.abs(out - y1).max() <= 5e-6 * np.abs(y1).max()
+        # the oracle's Arnoldi path (expm_arnoldi, util/pde_util.py:257-268: (1/c) Q expm(H) e1) gives the same state
+        Q, H, _r, c = orc.arnoldi_forward(orc.DenseOp(), 12, y0.reshape(-1), A)
+        kry = (Q @ scipy.linalg.expm(H)[:, 0] / c).reshape(y1.shape)
+        assert np.abs(kry - y1).max() <= 5e-6 * np.abs(y1).max()
+
+
+def test_product_wave_operator_is_the_reference_pinned_matrix():
+    """matfree_extensions.util.pde_util.wave_operator (host-side CSR assembly; no kernel runs here) builds exactly the matrix
+    that reproduces the reference's targets above."""
+    import torch
+
+    from matfree_extensions.util import pde_util
+
+    g = np.load(os.path.join(GOLD, "pde_wave_16x16.npz"))
+    parameter = g["parameter"].astype(np.float64)
+    op, values_fn = pde_util.wave_operator(16, 1.0 / 15.0, boundary="neumann", device=torch.device("cpu"))
+    vals = values_fn(torch.as_tensor(parameter**2)).numpy()
+    crow, col = op.crow.numpy(), op.col.numpy()
+    D = np.zeros((op.n, op.n))
+    for r in range(op.n):
+        for e in range(crow[r], crow[r + 1]):
+            D[r, col[e]] += vals[e]
+    assert np.allclose(D, _wave_matrix(parameter, 1.0 / 15.0), rtol=1e-13, atol=1e-13)
+
+
+def test_csr_fixture_bloweybq_and_its_oracle_outputs():
+    g = np.load(os.path.join(GOLD, "csr_bloweybq.npz"))
+    n, k = g["v"].shape[0], int(g["k"])
+    assert n == 10001 and g["row"].shape[0] == 69991  # SURVEY.md section 8(d): symmetric expansion of the .mtx
+    row, col, vals, v = g["row"].astype(np.int64), g["col"].astype(np.int64), g["vals"], g["v"]
+    op = orc.CooOp(row, col, n)
+    assert np.allclose(op.apply(v, vals), op.apply_t(v, vals))  # symmetric
+    # Lanczos identity A Q^T = Q^T T + b q e_K^T for the stored tridiagonals (re-run: the basis is not stored)
+    for reortho in ("full", "none"):
+        (Q, (d, e)), (q, b) = orc.tridiag(op, k, v, vals, reortho=reortho)
+        assert np.allclose(d, g[reortho + "_d"], rtol=1e-12) and np.allclose(e, g[reortho + "_e"], rtol=1e-12)
+        AQ = np.stack([op.apply(qi, vals) for qi in Q])
+        T = orc.dense_tridiag(d, e)
+        R = AQ - T @ Q
+        R[-1] -= b * q
+        assert np.abs(R).max() < 1e-8 * np.abs(AQ).max()
+    # stored adjoint outputs: directional finite difference of the functional the cotangents define (full re-orthogonalisation)
+    rng = np.random.default_rng(5)
+    w = rng.standard_normal(n)
+
+    def functional(v_):
+        (Q, (d, e)), (q, b) = orc.tridiag(op, k, v_, vals, reortho="full")
+        return (Q * g["full_dQ"]).sum() + d @ g["full_dd"] + e @ g["full_de"] + q @ g["full_dq"] + b * g["full_db"]
+
+    h = 1e-6
+    fd = (functional(v + h * w) - functional(v - h * w)) / (2 * h)
+    assert np.isclose(fd, g["full_dv"] @ w, rtol=1e-5)
+
+
+def test_uci_protein_fixture():
+    """First 2048 rows of the reference's data/uci/protein/data.csv.gz, z-scored (uci_util.py:229-230), and the oracle's SLQ
+    numbers at BASELINE config 2's settings.  Independent checks: the standardisation, SPD-ness, SLQ mean vs exact log-det."""
+    g = np.load(os.path.join(GOLD, "uci_protein_2048.npz"))
+    X = g["X"]
+    assert X.shape == (2048, 9) and int(g["k"]) == 30 and int(g["num_probes"]) == 8
+    assert np.abs(X.mean(0)).max() < 0.2 and np.abs(X.std(0) - 1).max() < 0.5  # a slice of globally z-scored columns
+    op = orc.RbfGramOp(X, noise_minval=float(g["noise_minval"]))
+    raw = (np.array(0.0), np.array(0.0), np.array(0.0))
+    ls, s, noise = op.constrained(*raw)
+    K = orc.kernel_matrix("rbf", X, X, ls, s, diag_offset=0) + noise * np.eye(2048)
+    exact = np.linalg.slogdet(K)[1]
+    assert np.isclose(float(g["iso_value"]), g["iso_values"].mean())
+    assert abs(float(g["iso_value"]) - exact) < 3 * g["iso_values"].std() / np.sqrt(8) + 0.02 * abs(exact)
+    # gradient w.r.t. raw_noise of the exact log-det, tr(A^-1) dnoise/draw, is what the SLQ gradient estimates
+    exact_gn = np.trace(np.linalg.inv(K)) * orc.softplus_grad(raw[2])
+    assert abs(float(g["iso_g_n"]) - exact_gn) < 0.15 * abs(exact_gn)

@@ -1,0 +1,151 @@
+"""BASELINE configs at their stated sizes / on their stated inputs, through the C-ABI on the GPU.
+
+* C4 (n = 131072, d = 8, k = 40): the north-star ACCURACY GATE -- every fp32 arithmetic mode of the Gram kernels against the
+  fp64 HIP path (itself oracle-checked at small n, tests/test_gpu_parity.py), rtol 1e-4 on the SLQ value AND on the gradient.
+* C2 (UCI protein, d = 9, k = 30, 8 probes): the reference's own data (2048-row slice, tests/golden/uci_protein_2048.npz) against
+  the oracle, and the full size n = 45730 (synthetic inputs of the same shape: the data file does not travel) against fp64.
+* C3: SuiteSparse bloweybq next to 1138_bus (tests/test_gpu_parity.py).
+* C5 / (f)-2: the reference-produced pde_wave targets through expm_arnoldi + wave_operator.
+"""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import slq_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from matfree_extensions import hutchinson, lanczos
+    from matfree_extensions.operators import CsrOp
+    from matfree_extensions.util import gp_util, pde_util
+
+DEV = torch.device("cuda:0")
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+INV = lambda v: float(np.log(np.expm1(v)))  # noqa: E731
+
+
+def _slq(X, raw, k, probes, precision):
+    dtype = X.dtype
+    params = [torch.tensor(v, dtype=dtype, device=DEV, requires_grad=True) for v in raw]
+    op = gp_util.gram_operator(X, precision=precision)
+    vals = lanczos.integrand_spd(torch.log, k, op)(probes.to(dtype), *params)
+    grads = torch.autograd.grad(vals.sum(), params)
+    p = probes.shape[0]
+    return vals.double().mean().item(), np.array([g.double().item() / p for g in grads])
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# C4 accuracy gate
+# ------------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def c4_fp64():
+    n, d, k, p = 131072, 8, 40, 8
+    gen = torch.Generator().manual_seed(4)
+    X64 = torch.randn((n, d), generator=gen, dtype=torch.float32).double().to(DEV)
+    raw = (INV(2.0), INV(1.0), INV(0.1))
+    probes = hutchinson.sampler_rademacher(X64[:, 0], num=p)(0)
+    val, grad = _slq(X64, raw, k, probes, "fp32")  # fp64 operators ignore the mode: VALU fp64 kernels
+    torch.cuda.empty_cache()
+    return X64, raw, k, probes, val, grad
+
+
+# Measured (profiles/r02a_accuracy, 64 probes): value / worst gradient component
+#   f16x3 5.2e-6 / 2.8e-5, f16x3-matvec 5.2e-6 / 5.4e-5, fp32 (exact fp32 MFMA, the arithmetic closest to the reference's fp32) 7.6e-5 / 1.8e-3.
+@pytest.mark.parametrize("precision,vtol,gtol", [("f16x3", 1e-4, 1e-4), ("f16x3-matvec", 1e-4, 1e-4), ("fp32", 2e-4, 5e-3)])
+def test_c4_full_size_accuracy_gate(c4_fp64, precision, vtol, gtol):
+    """north_star: "matching [...] to rtol 1e-4" on the C4 log-det value and gradient.  The two modes that run the Gram
+    contraction on the f16 matrix pipe meet it against fp64; plain fp32 MFMA accumulation over 131072 columns does not (stated
+    bound 5e-3) -- which is also why agreement with ANOTHER fp32 implementation cannot be better than ~1e-3 at this size."""
+    X64, raw, k, probes, val64, grad64 = c4_fp64
+    val, grad = _slq(X64.float(), raw, k, probes, precision)
+    assert abs(val - val64) <= vtol * abs(val64), (val, val64)
+    rel = np.abs(grad - grad64) / np.abs(grad64)
+    assert np.all(rel <= gtol), (precision, rel)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# C2
+# ------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["iso", "ard"])
+@pytest.mark.parametrize("dtype,precision,vtol,gtol", [(torch.float64, "fp32", 1e-9, 1e-7), (torch.float32, "f16x3", 1e-4, 1e-3),
+                                                       (torch.float32, "f16x3-matvec", 1e-4, 1e-3), (torch.float32, "fp32", 1e-4, 1e-3)])
+def test_c2_protein_slice_matches_the_oracle(tag, dtype, precision, vtol, gtol):
+    g = np.load(os.path.join(GOLD, "uci_protein_2048.npz"))
+    X = torch.tensor(g["X"], dtype=dtype, device=DEV)
+    n, k, p, seed = X.shape[0], int(g["k"]), int(g["num_probes"]), int(g["seed"])
+    probes = hutchinson.sampler_rademacher(X[:, 0], num=p)(seed)  # bit-identical to the oracle's sampler
+    assert np.array_equal(probes.cpu().numpy(), orc.rademacher(seed, p, n))
+    raw_l = torch.zeros(9 if tag == "ard" else (), dtype=dtype, device=DEV, requires_grad=True)
+    params = [raw_l] + [torch.zeros((), dtype=dtype, device=DEV, requires_grad=True) for _ in range(2)]
+    op = gp_util.gram_operator(X, noise_minval=float(g["noise_minval"]), precision=precision)
+    vals = lanczos.integrand_spd(torch.log, k, op)(probes, *params)
+    grads = torch.autograd.grad(vals.mean(), params)
+    assert np.allclose(vals.double().cpu().numpy(), g[f"{tag}_values"], rtol=vtol)
+    for gr, name in zip(grads, ("g_l", "g_s", "g_n")):
+        ref = np.asarray(g[f"{tag}_{name}"], dtype=np.float64)
+        got = gr.double().cpu().numpy().reshape(ref.shape)
+        assert np.allclose(got, ref, rtol=gtol, atol=gtol * np.abs(ref).max()), (name, got, ref)
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f16x3-matvec"])
+def test_c2_full_size_against_fp64(precision):
+    """n = 45730, d = 9, k = 30, 8 probes: the size at which the small-n column split of the matrix-core matvec is active (90 row
+    blocks of 512 < 256 CUs) and once silently ran unsplit.  Matvec and SLQ value-and-gradient against the fp64 kernels."""
+    n, d, k, p = 45730, 9, 30, 8
+    gen = torch.Generator().manual_seed(2)
+    X64 = torch.randn((n, d), generator=gen, dtype=torch.float32).double().to(DEV)
+    raw = (0.0, 0.0, 0.0)  # lengthscale = outputscale = softplus(0), noise = 1e-4 + softplus(0): SURVEY.md section 8(d) C2
+    probes = hutchinson.sampler_rademacher(X64[:, 0], num=p)(2)
+    with torch.no_grad():
+        raw64 = [torch.tensor(v, dtype=torch.float64, device=DEV) for v in raw]
+        W64 = gp_util.gram_operator(X64, noise_minval=1e-4)(probes, *raw64)
+        W32 = gp_util.gram_operator(X64.float(), noise_minval=1e-4, precision=precision)(probes.float(), *[r.float() for r in raw64])
+        assert float((W32.double() - W64).norm() / W64.norm()) < 2e-6
+    v64, g64 = _slq(X64, raw, k, probes, "fp32")
+    v32, g32 = _slq(X64.float(), raw, k, probes, precision)
+    assert abs(v32 - v64) <= 1e-4 * abs(v64)
+    assert np.all(np.abs(g32 - g64) <= 1e-4 * np.abs(g64)), (g32, g64)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# C3: bloweybq
+# ------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("reortho", ["full", "none"])
+def test_c3_bloweybq_tridiag_and_adjoint(reortho):
+    g = np.load(os.path.join(GOLD, "csr_bloweybq.npz"))
+    n, k = g["v"].shape[0], int(g["k"])
+    op, vals, order = CsrOp.from_coo(g["row"].astype(np.int64), g["col"].astype(np.int64), g["vals"], n, DEV)
+    vals = vals.double().requires_grad_(True)
+    v = torch.tensor(g["v"], dtype=torch.float64, device=DEV, requires_grad=True)
+    (Q, (d, e)), (q, b) = lanczos.tridiag(op, k, reortho=reortho)(v, vals)
+    pre = reortho + "_"
+    assert np.allclose(d.detach().cpu().numpy(), g[pre + "d"], rtol=1e-9)
+    assert np.allclose(e.detach().cpu().numpy(), g[pre + "e"], rtol=1e-9)
+    cot = [torch.tensor(g[pre + s], dtype=torch.float64, device=DEV) for s in ("dQ", "dd", "de", "dq", "db")]
+    dv, dvals = torch.autograd.grad((Q, d, e, q, b), (v, vals), cot)
+    ref_v, ref_vals = g[pre + "dv"], g[pre + "dvals"][order.numpy()]
+    assert np.allclose(dv.cpu().numpy(), ref_v, rtol=1e-7, atol=1e-7 * np.abs(ref_v).max())
+    assert np.allclose(dvals.cpu().numpy(), ref_vals, rtol=1e-7, atol=1e-7 * np.abs(ref_vals).max())
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# (f)-2: the reference's own pde_wave numbers
+# ------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 5e-6), (torch.float32, 2e-5)])
+def test_pde_wave_reference_targets_through_expm_arnoldi(dtype, tol):
+    """targets (REFERENCE-produced: Dopri8, 128 steps, fp32; make_data.py:52-103) = expm(A) inputs for the linear wave system;
+    here through the product path: wave_operator (native CSR) + arnoldi.hessenberg kernels + expm_arnoldi (util/pde_util.py:257-268).
+    Achieved 1.8e-6 of the largest entry in fp64 (the reference's fp32 ODE solve is the limit), stated bound 5e-6 / 2e-5."""
+    g = np.load(os.path.join(GOLD, "pde_wave_16x16.npz"))
+    op, values_fn = pde_util.wave_operator(16, 1.0 / 15.0, boundary="neumann", device=DEV, dtype=dtype)
+    vals = values_fn(torch.tensor(g["parameter"].astype(np.float64) ** 2, dtype=dtype, device=DEV))
+    expm = pde_util.expm_arnoldi(12)
+    for y0, y1 in zip(g["inputs"], g["targets"]):
+        out, info = expm(op, 1.0, torch.tensor(y0.reshape(-1), dtype=dtype, device=DEV), vals)
+        assert info["num_matvecs"] == 12
+        err = np.abs(out.double().cpu().numpy().reshape(y1.shape) - y1.astype(np.float64)).max()
+        assert err <= tol * np.abs(y1).max(), err

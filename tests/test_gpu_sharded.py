@@ -188,3 +188,28 @@ def test_row_sharded_processes_reproduce_the_single_process_estimate(tmp_path, w
     assert np.isclose(got["std"].item(), std.item(), rtol=1e-4, atol=1e-6 * abs(mean.item()))
     for a, b in zip(got["grads"], grads):
         assert torch.allclose(a, b.cpu(), rtol=gtol, atol=gtol * b.abs().max().item()), (a, b)
+
+
+def test_nested_native_operator_inside_a_callback_keeps_the_outer_workspace():
+    """a CallbackOp whose Python matvec calls a native RbfGramOp re-enters the workspace cache while the outer
+    driver keeps its iterate / partial sums / adjoint state at offset 0 of its buffer.  tridiag + adjoint through the callback
+    must equal the native path."""
+    from matfree_extensions import lanczos
+    from matfree_extensions.operators import CallbackOp
+
+    n, d, k, p = 700, 3, 9, 3
+    op, params = _rbf(n, d, torch.float64, ard=False)
+    g = torch.Generator().manual_seed(5)
+    V = torch.randn((p, n), generator=g, dtype=torch.float64).to(_dev())
+
+    def run(matvec):
+        ps = [q.clone().requires_grad_(True) for q in params]
+        (Q, (dg, off)), (q, b) = lanczos.tridiag(matvec, k, reortho="full")(V, *ps)
+        loss = (Q * torch.linspace(0, 1, n, dtype=torch.float64, device=_dev())).sum() + dg.sum() + 2 * off.sum() + q.sum() + b.sum()
+        return dg.detach(), off.detach(), torch.autograd.grad(loss, ps)
+
+    d0, e0, g0 = run(op)
+    d1, e1, g1 = run(CallbackOp(lambda v, *q: op(v, *q)))
+    assert torch.allclose(d0, d1, rtol=1e-11) and torch.allclose(e0, e1, rtol=1e-9, atol=1e-12)
+    for a, b in zip(g0, g1):
+        assert torch.allclose(a, b, rtol=1e-8, atol=1e-10 * a.abs().max().item()), (a, b)
