@@ -192,6 +192,27 @@ class _ShardedSumSq(torch.autograd.Function):
         return None, 2.0 * V * g[:, None]
 
 
+class _SumGrad(torch.autograd.Function):
+    """Identity on a REPLICATED tensor (H, c of a row-sharded factorisation) whose consumers are row-sharded: each rank's
+    backward then holds only the part of the cotangent that flows through ITS rows, and the drivers need the complete one."""
+
+    @staticmethod
+    def forward(ctx, comm, t):
+        ctx.comm = comm
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, ctx.comm.all_reduce_(g.contiguous().clone())
+
+
+def sum_grad(comm: RowComm, t):
+    """Use a replicated output of a row-sharded driver inside a computation on row shards (e.g. Q_local @ f(H)): the
+    cotangent of ``t`` is summed over the row group on the way back.  NOT needed when every rank evaluates the same function
+    of ``t`` (the SLQ quadrature): there each rank already holds the complete cotangent."""
+    return _SumGrad.apply(comm, t)
+
+
 def sharded_norm(comm: RowComm, V):
     """Euclidean norm of row-sharded vectors (p, nrows) -> (p,)"""
     return torch.sqrt(_ShardedSumSq.apply(comm, V))

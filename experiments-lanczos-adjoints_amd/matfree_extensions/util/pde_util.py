@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from .. import arnoldi, lanczos
-from ..operators import CsrOp
+from ..operators import CsrOp, RowShardedOp, as_operator
 
 
 def expm_arnoldi(krylov_depth, *, max_squarings: int = 32, reortho="full", custom_vjp=True):
@@ -22,6 +22,11 @@ def expm_arnoldi(krylov_depth, *, max_squarings: int = 32, reortho="full", custo
     def expm(matvec, dt, y0_flat, *p):
         algorithm = arnoldi.hessenberg(matvec, krylov_depth, reortho=reortho, custom_vjp=custom_vjp)
         Q, H, _r, c = algorithm(y0_flat, *p)
+        op, _ = as_operator(matvec)
+        if isinstance(op, RowShardedOp):  # y0, Q and the result are row shards; H and c are replicated but consumed per shard
+            from ..distributed import sum_grad
+
+            H, c = sum_grad(op.comm, H), sum_grad(op.comm, c)
         expmat = torch.linalg.matrix_exp(dt * H)
         # Q expm(dt H) e1 as a weighted sum over the (k, n) storage of the basis: elementwise kernels in both directions (as a
         # matmul on the transposed view the backward went to a 41 ms skinny rocBLAS GEMM at n = 2e6)

@@ -84,7 +84,7 @@ def test_c2_protein_slice_matches_the_oracle(tag, dtype, precision, vtol, gtol):
     op = gp_util.gram_operator(X, noise_minval=float(g["noise_minval"]), precision=precision)
     vals = lanczos.integrand_spd(torch.log, k, op)(probes, *params)
     grads = torch.autograd.grad(vals.mean(), params)
-    assert np.allclose(vals.double().cpu().numpy(), g[f"{tag}_values"], rtol=vtol)
+    assert np.allclose(vals.detach().double().cpu().numpy(), g[f"{tag}_values"], rtol=vtol)
     for gr, name in zip(grads, ("g_l", "g_s", "g_n")):
         ref = np.asarray(g[f"{tag}_{name}"], dtype=np.float64)
         got = gr.double().cpu().numpy().reshape(ref.shape)
@@ -114,8 +114,12 @@ def test_c2_full_size_against_fp64(precision):
 # ------------------------------------------------------------------------------------------------------------------------
 # C3: bloweybq
 # ------------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("reortho", ["full", "none"])
-def test_c3_bloweybq_tridiag_and_adjoint(reortho):
+@pytest.mark.parametrize("reortho,ftol,gtol", [("full", 1e-9, 1e-7), ("none", 1e-4, 1e-3)])
+def test_c3_bloweybq_tridiag_and_adjoint(reortho, ftol, gtol):
+    """fp64 against the oracle.  The three-term recurrence (reortho="none") on this matrix (entries up to 4.9e3 next to O(1)
+    ones) amplifies rounding differences by ~1e9 within 6 steps: the oracle's own last diagonal entry moves by 2e-7 under a 1e-16
+    relative perturbation of v, and NumPy's vs the GPU's summation orders differ by 1e-5 there -- hence the looser bound for
+    that mode (the fully re-orthogonalised mode is held to 1e-9 / 1e-7)."""
     g = np.load(os.path.join(GOLD, "csr_bloweybq.npz"))
     n, k = g["v"].shape[0], int(g["k"])
     op, vals, order = CsrOp.from_coo(g["row"].astype(np.int64), g["col"].astype(np.int64), g["vals"], n, DEV)
@@ -123,13 +127,13 @@ def test_c3_bloweybq_tridiag_and_adjoint(reortho):
     v = torch.tensor(g["v"], dtype=torch.float64, device=DEV, requires_grad=True)
     (Q, (d, e)), (q, b) = lanczos.tridiag(op, k, reortho=reortho)(v, vals)
     pre = reortho + "_"
-    assert np.allclose(d.detach().cpu().numpy(), g[pre + "d"], rtol=1e-9)
-    assert np.allclose(e.detach().cpu().numpy(), g[pre + "e"], rtol=1e-9)
+    assert np.allclose(d.detach().cpu().numpy(), g[pre + "d"], rtol=ftol)
+    assert np.allclose(e.detach().cpu().numpy(), g[pre + "e"], rtol=ftol, atol=ftol * np.abs(g[pre + "e"]).max())
     cot = [torch.tensor(g[pre + s], dtype=torch.float64, device=DEV) for s in ("dQ", "dd", "de", "dq", "db")]
     dv, dvals = torch.autograd.grad((Q, d, e, q, b), (v, vals), cot)
     ref_v, ref_vals = g[pre + "dv"], g[pre + "dvals"][order.numpy()]
-    assert np.allclose(dv.cpu().numpy(), ref_v, rtol=1e-7, atol=1e-7 * np.abs(ref_v).max())
-    assert np.allclose(dvals.cpu().numpy(), ref_vals, rtol=1e-7, atol=1e-7 * np.abs(ref_vals).max())
+    assert np.allclose(dv.cpu().numpy(), ref_v, rtol=gtol, atol=gtol * np.abs(ref_v).max())
+    assert np.allclose(dvals.cpu().numpy(), ref_vals, rtol=gtol, atol=gtol * np.abs(ref_vals).max())
 
 
 # ------------------------------------------------------------------------------------------------------------------------

@@ -213,3 +213,67 @@ def test_nested_native_operator_inside_a_callback_keeps_the_outer_workspace():
     assert torch.allclose(d0, d1, rtol=1e-11) and torch.allclose(e0, e1, rtol=1e-9, atol=1e-12)
     for a, b in zip(g0, g1):
         assert torch.allclose(a, b, rtol=1e-8, atol=1e-10 * a.abs().max().item()), (a, b)
+
+
+# ---- BASELINE config 5 layout: the non-symmetric wave operator, rows sharded ------------------------------------------------
+_WAVE = (24, 14, 0.05)  # grid 24 x 24 -> state 1152 = 2 x 576 rows; Arnoldi depth; time step
+
+
+def _wave_problem(dtype=torch.float64):
+    from matfree_extensions.util import pde_util
+
+    res = _WAVE[0]
+    g = torch.Generator().manual_seed(9)
+    scale = (0.5 + torch.rand((res, res), generator=g, dtype=torch.float64)).to(_dev())
+    y0 = torch.randn((2 * res * res,), generator=g, dtype=torch.float64).to(_dev())
+    w = torch.randn((2 * res * res,), generator=g, dtype=torch.float64).to(_dev())
+    op, values_fn = pde_util.wave_operator(res, 1.0 / (res - 1), boundary="neumann", device=_dev(), dtype=dtype)
+    return op, values_fn, scale, y0, w
+
+
+def _wave_worker(rank, world, port, out):
+    for p in (ROOT, os.path.join(ROOT, "experiments-lanczos-adjoints_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import datetime
+
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    from matfree_extensions.distributed import RowComm
+    from matfree_extensions.operators import RowShardedOp
+    from matfree_extensions.util import pde_util
+
+    op, values_fn, scale, y0, w = _wave_problem()
+    comm = RowComm(op.n)
+    sc = scale.clone().requires_grad_(True)
+    y1, _ = pde_util.expm_arnoldi(_WAVE[1])(RowShardedOp(op, comm), _WAVE[2], comm.rows(y0), values_fn(sc))
+    (y1 * comm.rows(w)).sum().backward()  # this rank's part of the loss sum_i w_i y1_i; the scale gradient comes out complete
+    full = comm.gather_rows(y1.detach())
+    torch.cuda.synchronize()
+    if rank == world - 1:
+        torch.save({"y1": full.cpu(), "dscale": sc.grad.cpu()}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_sharded_wave_expm_and_its_gradient_equal_the_single_process_result(tmp_path):
+    """C5's layout on 2 processes: expm_arnoldi on the row-sharded non-symmetric CSR operator (A and A^T row blocks, SDDMM
+    gradient of the rows each rank owns) and the gradient w.r.t. the coefficient field."""
+    import torch.multiprocessing as mp
+
+    from matfree_extensions.util import pde_util
+
+    op, values_fn, scale, y0, w = _wave_problem()
+    sc = scale.clone().requires_grad_(True)
+    y1, _ = pde_util.expm_arnoldi(_WAVE[1])(op, _WAVE[2], y0, values_fn(sc))
+    (y1 * w).sum().backward()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "wave.pt")
+    mp.spawn(_wave_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    assert torch.allclose(got["y1"], y1.detach().cpu(), rtol=1e-10, atol=1e-12)
+    assert torch.allclose(got["dscale"], sc.grad.cpu(), rtol=1e-8, atol=1e-10 * sc.grad.abs().max().item())
