@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/prof_bench
 rm -rf $OUT && mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
-tail -1 $OUT/bench_under_rocprof.log > $OUT/bench_under_rocprof.json
+grep "^{\"metric" $OUT/bench_under_rocprof.log > $OUT/bench_under_rocprof.json
 f=$(find $OUT -name "*kernel_stats.csv" | head -1)
 cp "$f" $OUT/kernel_stats.csv
 head -12 $OUT/kernel_stats.csv
