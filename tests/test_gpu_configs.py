@@ -153,3 +153,30 @@ def test_pde_wave_reference_targets_through_expm_arnoldi(dtype, tol):
         assert info["num_matvecs"] == 12
         err = np.abs(out.double().cpu().numpy().reshape(y1.shape) - y1.astype(np.float64)).max()
         assert err <= tol * np.abs(y1).max(), err
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# C3 at its stated size: synthetic SPD CSR (5-point Laplacian + I on a 320 x 320 grid, n = 102400), k = 50, fp64
+# ------------------------------------------------------------------------------------------------------------------------
+def test_c3_full_size_csr_tridiag_and_adjoint_against_the_oracle():
+    """50 slices x 1 vector: the fused cooperative Arnoldi kernels (csrc/mfx_fused.hip) across many workgroups, forward and
+    adjoint with cotangents on every output and the gradient w.r.t. ALL stored values (benchmark.py:57-121)."""
+    r, c, vals, n = orc.laplacian_2d_plus_identity(320)
+    k = 50
+    rng = np.random.default_rng(3)
+    v = rng.standard_normal(n)
+    o = orc.CooOp(r, c, n)
+    (Qr, (dr_, er)), (qr, br) = orc.tridiag(o, k, v, vals, reortho="full")
+    cot = ((rng.standard_normal(Qr.shape), (rng.standard_normal(k), rng.standard_normal(k - 1))), (rng.standard_normal(n), rng.standard_normal()))
+    dv_ref, (dvals_ref,) = orc.tridiag_full_vjp(o, k, v, (vals,), cot)
+    op, vt, order = CsrOp.from_coo(r, c, vals, n, DEV)
+    vt = vt.double().requires_grad_(True)
+    x0 = torch.tensor(v, dtype=torch.float64, device=DEV, requires_grad=True)
+    (Q, (d, e)), (q, b) = lanczos.tridiag(op, k, reortho="full")(x0, vt)
+    assert np.allclose(d.detach().cpu().numpy(), dr_, rtol=1e-10) and np.allclose(e.detach().cpu().numpy(), er, rtol=1e-10)
+    assert np.allclose(b.item(), br, rtol=1e-9)
+    tc = [torch.tensor(np.asarray(t), dtype=torch.float64, device=DEV) for t in (cot[0][0], cot[0][1][0], cot[0][1][1], cot[1][0], cot[1][1])]
+    dv, dvals = torch.autograd.grad((Q, d, e, q, b), (x0, vt), tc)
+    assert np.allclose(dv.cpu().numpy(), dv_ref, rtol=1e-7, atol=1e-8 * np.abs(dv_ref).max())
+    ref = dvals_ref[order.numpy()]
+    assert np.allclose(dvals.cpu().numpy(), ref, rtol=1e-7, atol=1e-8 * np.abs(ref).max())
