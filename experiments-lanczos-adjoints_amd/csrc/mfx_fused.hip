@@ -1,11 +1,19 @@
 // libmfx: the Arnoldi forward loop and its adjoint scan as ONE cooperative kernel each (dense and CSR operators).
+// EXPERIMENTAL, OFF BY DEFAULT (MFX_FUSED=1 enables it): correct (the parity suite passes with it), but slower than the
+// separate kernels on MI355X -- kept with its measurements because the reason is instructive.
 //
-// Why: for a single start vector of moderate length (BASELINE config 3: n = 102400, k = 50, fp64; config 1: n = 512) every
-// vector kernel of mfx_krylov.hip runs for a few microseconds and the k-loop is a chain of ~6 dependent launches per step:
-// the stream spends its time in launch gaps (measured round 1: 57 us per step, 17 % of the HBM roofline).  Here the whole
-// k-loop is one launch; the steps are separated by grid-wide barriers (cooperative groups), the running vector of a workgroup's
-// slice stays in REGISTERS from one phase to the next, and the operator is applied inside the kernel (rows of the slice,
-// gathered from the published iterate).
+// Idea: for a single start vector of moderate length (BASELINE config 3: n = 102400, k = 50, fp64; config 1: n = 512) every
+// vector kernel of mfx_krylov.hip runs for a few microseconds and the k-loop is a chain of ~6 dependent launches per step
+// (57 us per step, 17 % of the HBM roofline).  Here the whole k-loop is one launch; the steps are separated by grid-wide
+// barriers (cooperative groups), the running vector of a workgroup's slice stays in REGISTERS from one phase to the next, and
+// the operator is applied inside the kernel (rows of the slice, gathered from the published iterate).
+//
+// Measured (profiles/r02e_fused_arnoldi_and_grid_barrier.log): a grid-wide barrier costs 7.3 us for 50 workgroups and 32 us
+// for 256 (cg::grid.sync(); a hand-written one-atomic-per-workgroup barrier 4.2 / 19 us: ~75 ns per arriving workgroup,
+// serialised on one L2 atomic) -- MORE than the launch gap it replaces (~5 us), and with 3 barriers per step the fused C3
+// forward takes 5.3 ms against 2.8 ms for the separate kernels (C1: 3.5 vs 0.85 ms, its single workgroup applies the whole
+// dense operator alone).  A grid barrier pays off on this part only below ~10 workgroups; the launch-bound configs need
+// fewer dependent launches per step instead.
 //
 //   forward step i (arnoldi.py:80-99), 3 barriers (2 without the second Gram-Schmidt pass):
 //     S   len = |w| from the norm partials; q_i = w / len -> Q[i]; w <- A w / len (rows of this slice); partial dots Q^T w
@@ -21,8 +29,7 @@
 //     D   Gamma row, xi, the next lam (registers): no barrier needed before A of the next step
 //
 // Same slicing (2048 elements per workgroup, 8 per thread), same partial-sum layout and the same arithmetic order as the
-// separate kernels -- the two paths agree to round-off.  Used when the grid (slices x vectors) is co-resident (the runtime checks);
-// MFX_FUSED=0 disables it.
+// separate kernels -- the two paths agree to round-off.  Only launched when the grid (slices x vectors) is co-resident.
 #include <hip/hip_cooperative_groups.h>
 #include <stdlib.h>
 
@@ -381,7 +388,7 @@ __global__ __launch_bounds__(kBlock) void k_arnoldi_adj_fused(FusedAdj<T> a) {
 bool fused_enabled() {
   static const int v = [] {
     const char* e = getenv("MFX_FUSED");
-    return e ? atoi(e) : 1;
+    return e ? atoi(e) : 0;  // off by default: slower than the separate kernels on MI355X (see the header)
   }();
   return v != 0;
 }
