@@ -14,7 +14,8 @@ Differences from the reference, all deliberate:
   * parameters must be explicit tensors (no closure conversion, arnoldi.py:22): pass a native
     operator (``operators.DenseOp`` ...) or any callable ``matvec(v, *params)``;
   * real float32/float64 only (complex Arnoldi forward, test_hessenberg_forward.py, is out of scope);
-  * ``custom_vjp=False`` returns non-differentiable outputs (there is no autodiff through HIP loops).
+  * ``custom_vjp=False`` is the reference's baseline, back-propagation THROUGH the loop: the recurrence then runs as
+    differentiable torch ops around the HIP operator (``_autodiff.py``) -- slow and memory-hungry by construction.
 Reference quirk Q1 is reproduced: the forward pass re-orthogonalises unless ``reortho_vjp="none"``
 (arnoldi.py:26,91), whatever ``reortho`` says; ``reortho`` only selects the adjoint's re-projection.
 """
@@ -59,6 +60,12 @@ def hessenberg(
         # Q1 (arnoldi.py:26): the forward always sees `reortho_vjp`
         reortho_fwd = reortho_vjp if reortho_vjp != "match" else reortho_vjp
         second_pass = reortho_fwd != "none"
+        wants_grad = torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in (V, *params))
+        if not custom_vjp and not sharded and wants_grad:  # autodiff THROUGH the loop: the reference's baseline (_autodiff.py)
+            from . import _autodiff
+
+            Qb, H, r, c = _autodiff.batched(_autodiff.arnoldi_forward, V, op, int(krylov_depth), params, second_pass=second_pass)
+            return (Qb, H, r, c) if batched else (Qb[0], H[0], r[0], c[0])
         cparams = op.constrain(*params)
         if sharded:
             Qkn, H, r, c = _ArnoldiShardedFn.apply(op, int(krylov_depth), second_pass, reortho, custom_vjp, V, *cparams)

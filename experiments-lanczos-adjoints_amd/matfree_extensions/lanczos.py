@@ -75,8 +75,14 @@ def _tridiag_reortho_none(matvec, krylov_depth, /, *, custom_vjp):
         n = V.shape[-1]
         if k < 1 or k > n:
             raise ValueError(f"Parameter depth {k} is outside the expected range")
-        cparams = op.constrain(*params)
-        xs, alpha, beta = _LanczosFn.apply(op, k, custom_vjp, V, *cparams)
+        wants_grad = torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in (V, *params))
+        if not custom_vjp and wants_grad:  # autodiff through the loop (the reference's baseline), see _autodiff.py
+            from . import _autodiff
+
+            xs, alpha, beta = _autodiff.batched(_autodiff.lanczos_forward, V, op, k, params)
+        else:
+            cparams = op.constrain(*params)
+            xs, alpha, beta = _LanczosFn.apply(op, k, custom_vjp, V, *cparams)
         out = (xs[:, :-1], (alpha, beta[:, :-1])), (xs[:, -1], beta[:, -1])
         if not batched:
             out = (out[0][0][0], (out[0][1][0][0], out[0][1][1][0])), (out[1][0][0], out[1][1][0])

@@ -2,8 +2,9 @@
 
 Same flags and output files as the reference's harness of the same path (BASELINE config 3); the gradient is taken
 w.r.t. the start vector AND every stored matrix entry.  Differences: timings are of the libmfx HIP kernels (there is
-nothing to pre-compile, ``--precompile`` only adds a warm-up call), and the "backprop through the loop" column is not
-produced (``custom_vjp=False`` outputs are not differentiable in this build): ``*_times_autodiff.npy`` is empty.
+nothing to pre-compile, ``--precompile`` only adds a warm-up call); the "backprop through the loop" column
+(``custom_vjp=False``, benchmark.py:125-139 of the reference) is torch.autograd through the recurrence written in torch ops
+around the HIP operator (``matfree_extensions/_autodiff.py``), for depths up to ``--backprop_until``.
 ``--synthetic`` builds a matrix of the named one's size when ./data/matrices/<name>/<name>.mtx is absent.
 """
 
@@ -55,9 +56,9 @@ def flatten(tree):
     return [t for x in tree for t in flatten(x)]
 
 
-def make(kdepth):
+def make(kdepth, custom_vjp=True):
     make_alg = {"arnoldi": arnoldi.hessenberg, "lanczos": lanczos.tridiag}[args.lanczos_or_arnoldi]
-    algorithm = make_alg(op, kdepth, custom_vjp=True, reortho=args.reortho)
+    algorithm = make_alg(op, kdepth, custom_vjp=custom_vjp, reortho=args.reortho)
 
     def decompose(v, p):
         return flatten(algorithm(v, p))
@@ -76,7 +77,7 @@ def timed(fun):
     return (time.perf_counter() - t0) / args.num_runs
 
 
-times_fwdpass, times_custom = [], []
+times_fwdpass, times_custom, times_autodiff = [], [], []
 step = args.backprop_until // 10
 krylov_depths = np.arange(step, args.max_krylov_depth + step, step, dtype=int)
 for krylov_depth in krylov_depths:
@@ -96,6 +97,16 @@ for krylov_depth in krylov_depths:
     time_custom = timed(lambda: torch.autograd.grad(outs, (v, p), dnu, retain_graph=True))
     times_custom.append(time_custom)
     print("Time (adjoint):\n\t", time_custom)
+    if krylov_depth <= args.backprop_until:  # backprop through the loop: forward + backward each run (the graph is the baseline's cost)
+        baseline = make(krylov_depth, custom_vjp=False)
+
+        def through_the_loop():
+            v2, p2 = vector.clone().requires_grad_(True), params.clone().requires_grad_(True)
+            return torch.autograd.grad(baseline(v2, p2), (v2, p2), dnu)
+
+        time_autodiff = timed(through_the_loop)
+        times_autodiff.append(time_autodiff)
+        print("Time (forward + backprop through the loop):\n\t", time_autodiff)
     print()
 
 print("Saving to a file")
@@ -104,4 +115,4 @@ os.makedirs(directory, exist_ok=True)
 np.save(f"{directory}/{LABEL}_krylov_depths.npy", krylov_depths)
 np.save(f"{directory}/{LABEL}_times_fwdpass.npy", np.asarray(times_fwdpass))
 np.save(f"{directory}/{LABEL}_times_custom.npy", np.asarray(times_custom))
-np.save(f"{directory}/{LABEL}_times_autodiff.npy", np.asarray([]))
+np.save(f"{directory}/{LABEL}_times_autodiff.npy", np.asarray(times_autodiff))

@@ -476,9 +476,41 @@ def test_error_paths_on_device():
         DenseOp()(v, T(np.ones((n, n + 1))))
     with pytest.raises(TypeError):
         arnoldi.hessenberg(DenseOp(), 3, reortho="full")(v.to(torch.float16), A.to(torch.float16))
-    out = arnoldi.hessenberg(DenseOp(), 3, reortho="full", custom_vjp=False)(T(np.ones(n), grad=True), A)
-    with pytest.raises(RuntimeError, match="not differentiable"):
-        out[1].sum().backward()
+
+
+@pytest.mark.parametrize("which", ["arnoldi", "lanczos-none", "lanczos-full"])
+def test_custom_vjp_equals_autodiff_through_the_loop(which):
+    """The reference's own adjoint test (tests/test_arnoldi/test_hessenberg_adjoint.py, tests/test_lanczos/test_tridiag_adjoint.py):
+    the custom VJP must agree with back-propagation through the forward loop (custom_vjp=False).  Symmetric parametrisation
+    for the three-term recurrence (its adjoint applies A, not A^T: quirk Q4)."""
+    n, k = 10, 4
+    rng = np.random.default_rng(12)
+    P = rng.standard_normal((n, n)) + n * np.eye(n)
+    v = rng.standard_normal(n)
+    sym = which != "arnoldi"
+
+    class SymOp:  # matvec(v, P) = (P + P^T) v as a python callable: exercises the callback operator too
+        def __call__(self, x, Pm):
+            return (Pm + Pm.T) @ x
+
+    def run(custom):
+        vt, Pt = T(v, grad=True), T(P, grad=True)
+        matvec = SymOp() if sym else DenseOp()
+        if which == "arnoldi":
+            outs = arnoldi.hessenberg(matvec, k, reortho="full", custom_vjp=custom)(vt, Pt)
+        else:
+            (Q, (d, e)), (q, b) = lanczos.tridiag(matvec, k, reortho=which.split("-")[1], custom_vjp=custom)(vt, Pt)
+            outs = (Q, d, e, q, b)
+        g = torch.Generator(device=DEV).manual_seed(0)
+        cot = [torch.randn(o.shape, dtype=o.dtype, device=DEV, generator=g) for o in outs]
+        return [N(o) for o in outs], [N(t) for t in torch.autograd.grad(outs, (vt, Pt), cot)]
+
+    o1, g1 = run(True)
+    o0, g0 = run(False)
+    for a, b in zip(o1, o0):
+        assert np.allclose(a, b, rtol=1e-10, atol=1e-12)
+    for a, b in zip(g1, g0):
+        assert np.allclose(a, b, rtol=1e-6, atol=1e-8 * np.abs(b).max()), np.abs(a - b).max()
 
 
 def test_pytree_start_vector_and_matfuns():
