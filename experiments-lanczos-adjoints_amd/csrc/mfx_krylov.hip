@@ -401,7 +401,13 @@ template <typename T>
 static int apply_sharded(const mfx_operator* op, const mfx_comm* cm, int transpose, const T* x, int64_t ldx, T* y,
                          int64_t ldy, int64_t p, T* full, int64_t ldfull, const KrylovWs& ws, hipStream_t stream) {
   const int64_t n = op->n, nloc = cm->nloc, nrows = shard_nrows(cm, n);
-  {
+  if (cm->exchange) {  // neighbour exchange: own rows into place, then only the entries this rank's rows read from other ranks
+    ScopedTimer t(3, stream);
+    MFX_CHECK_HIP(hipMemcpy2DAsync(full + shard_row0(cm), sizeof(T) * ldfull, x, sizeof(T) * ldx, sizeof(T) * nrows, p,
+                                   hipMemcpyDeviceToDevice, stream));
+    const int rc = cm->exchange(cm->ctx, x, ldx, full, ldfull, p, op->dtype, transpose, stream);
+    MFX_REQUIRE(rc == 0, MFX_ERR_CALLBACK, "exchange callback failed with code %d", rc);
+  } else {
     ScopedTimer t(3, stream);
     k_pack_shard<T><<<dim3((unsigned)((nloc + 255) / 256), (unsigned)p), 256, 0, stream>>>(x, ldx, nrows, nloc, (T*)ws.send);
     MFX_CHECK_LAUNCH();

@@ -72,6 +72,8 @@ class Operator(C.Structure):
 
 ALLREDUCE_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)  # ctx, buf, count, dtype, stream
 ALLGATHER_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)  # ctx, in, out, count, dtype, stream
+# ctx, local, ldlocal, full, ldfull, p, dtype, transpose, stream
+EXCHANGE_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p)
 
 
 class Comm(C.Structure):
@@ -84,6 +86,7 @@ class Comm(C.Structure):
         ("allreduce_sum", ALLREDUCE_T),
         ("allgather", ALLGATHER_T),
         ("ctx", C.c_void_p),
+        ("exchange", EXCHANGE_T),
     ]
 
 

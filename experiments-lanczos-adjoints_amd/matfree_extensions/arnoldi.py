@@ -183,7 +183,7 @@ class _ArnoldiShardedFn(torch.autograd.Function):
         cm0 = _lib.Comm()
         cm0.rank, cm0.world, cm0.nloc = comm.rank, comm.world, comm.nloc
         ws = _lib.scratch(int(lib.mfx_sharded_workspace_bytes(C.byref(desc), C.byref(cm0), n, k, p)), dev)
-        cm, keep = comm.struct(ws)
+        cm, keep = comm.struct(ws, tensors=(Q, Qfull), plans=sop.plans)
         with _lib.busy(ws):
             rc = lib.mfx_arnoldi_forward_sharded(C.byref(desc), C.byref(cm), _lib.ptr(V), n, k, p, int(second_pass),
                                                  _lib.ptr(Q), _lib.ptr(Qfull), _lib.ptr(H), _lib.ptr(r), _lib.ptr(c),
@@ -220,7 +220,7 @@ class _ArnoldiShardedFn(torch.autograd.Function):
         cm0 = _lib.Comm()
         cm0.rank, cm0.world, cm0.nloc = comm.rank, comm.world, comm.nloc
         ws = _lib.scratch(int(lib.mfx_sharded_workspace_bytes(C.byref(desc), C.byref(cm0), n, k, p)), dev)
-        cm, keep = comm.struct(ws)
+        cm, keep = comm.struct(ws, tensors=(Lam,), plans=ctx.sop.plans)
         with _lib.busy(ws):
             rc = lib.mfx_arnoldi_adjoint_sharded(C.byref(desc), C.byref(cm), n, k, p, _lib.ptr(Q), _lib.ptr(Qfull), _lib.ptr(H),
                                                  _lib.ptr(r), _lib.ptr(c), _lib.ptr(dQ), _lib.ptr(dH), _lib.ptr(dr), _lib.ptr(dc),

@@ -134,12 +134,74 @@ class RowComm:
         out = out.reshape(self.world, flat.shape[0], self.nloc).movedim(0, 1).reshape(flat.shape[0], self.world * self.nloc)
         return out[:, : self.n].reshape(*lead, self.n).contiguous()
 
+    # ---- neighbour exchange for sparse operators ------------------------------------------------------
+    def plan_exchange(self, crow, col):
+        """Which entries of the iterate do this rank's rows of a CSR matrix (crow, col: device int32) read from other ranks?
+        -> (recv, send): lists of (peer, lo, hi) column ranges -- one bounding range per owner, which is tight for banded / block
+        structures (stencils) -- to receive from / send to each peer.  Collective over the row group (one all_gather_object)."""
+        c = col[int(crow[self.row0]) : int(crow[self.row0 + self.nrows])].to(torch.int64)
+        owner = torch.div(c, self.nloc, rounding_mode="floor")
+        recv = []
+        for q in range(self.world):
+            if q == self.rank:
+                continue
+            cq = c[owner == q]
+            if cq.numel():
+                recv.append((q, int(cq.min()), int(cq.max()) + 1))
+        everyone = [None] * self.world
+        if self.world > 1:
+            dist.all_gather_object(everyone, recv, group=self.group)
+        else:
+            everyone[0] = recv
+        send = [(q, lo, hi) for q in range(self.world) if q != self.rank for (peer, lo, hi) in everyone[q] if peer == self.rank]
+        return recv, send
+
+    def _exchange(self, local, full, plan):
+        """local (p, nrows) view, full (p, n) view: receive the planned column ranges into ``full``, send ours."""
+        recv, send = plan
+        ranks = dist.get_process_group_ranks(self.group) if self.group is not None else list(range(self.world))
+        staged = dist.get_backend(self.group) != "nccl"  # gloo moves device tensors through the host
+        ops, landing = [], []
+        for q, lo, hi in send:
+            t = local[:, lo - self.row0 : hi - self.row0].contiguous()
+            ops.append(dist.P2POp(dist.isend, t.cpu() if staged else t, ranks[q], group=self.group))
+        for q, lo, hi in recv:
+            buf = torch.empty((full.shape[0], hi - lo), dtype=full.dtype, device="cpu" if staged else full.device)
+            ops.append(dist.P2POp(dist.irecv, buf, ranks[q], group=self.group))
+            landing.append((lo, hi, buf))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        for lo, hi, buf in landing:
+            full[:, lo:hi] = buf.to(full.device, non_blocking=False)
+
     # ---- mfx_comm ---------------------------------------------------------------------------------
-    def struct(self, ws: torch.Tensor):
-        """-> (mfx_comm, keepalive).  ``ws`` is the uint8 workspace tensor every callback pointer lies in."""
+    def struct(self, ws: torch.Tensor, tensors=(), plans=None):
+        """-> (mfx_comm, keepalive).  ``ws`` is the uint8 workspace tensor the collective callbacks' pointers lie in;
+        ``tensors``: further tensors the exchange callback's pointers may lie in (basis, gathered basis, adjoint states);
+        ``plans``: (forward, transpose) exchange plans of a sparse operator, or None for the all-gather."""
         base, nbytes = ws.data_ptr(), ws.numel()
         failure = []
         world, group = self.world, self.group
+        regs = [(ws.data_ptr(), ws.numel(), ws)] + [(t.data_ptr(), t.numel() * t.element_size(), t.view(-1).view(torch.uint8))
+                                                   for t in tensors if t is not None]
+
+        def strided(ptr, ld, p, ncols, dtype_code):
+            dt = torch.float32 if dtype_code == _lib.MFX_F32 else torch.float64
+            es = 4 if dtype_code == _lib.MFX_F32 else 8
+            for b0, nb, flat in regs:
+                if b0 <= ptr < b0 + nb:
+                    return flat[ptr - b0 :].view(dt).as_strided((p, ncols), (ld, 1))
+            raise RuntimeError("libmfx exchange callback received an unknown pointer")
+
+        def exchange(_ctx, local, ldlocal, full, ldfull, p, dtype_code, transpose, _stream):
+            try:
+                self._exchange(strided(local, ldlocal, p, self.nrows, dtype_code), strided(full, ldfull, p, self.n, dtype_code),
+                               plans[1 if transpose else 0])
+                return 0
+            except Exception as exc:
+                failure.append(exc)
+                return 1
 
         def view(ptr, count, dtype_code):
             dt = torch.float32 if dtype_code == _lib.MFX_F32 else torch.float64
@@ -171,10 +233,11 @@ class RowComm:
                 return 1
 
         cb_r, cb_g = _lib.ALLREDUCE_T(allreduce), _lib.ALLGATHER_T(allgather)
+        cb_x = _lib.EXCHANGE_T(exchange) if plans is not None else _lib.EXCHANGE_T()
         cm = _lib.Comm()
         cm.rank, cm.world, cm.nloc = self.rank, self.world, self.nloc
-        cm.allreduce_sum, cm.allgather = cb_r, cb_g
-        return cm, (cb_r, cb_g, failure)
+        cm.allreduce_sum, cm.allgather, cm.exchange = cb_r, cb_g, cb_x
+        return cm, (cb_r, cb_g, failure, cb_x)
 
 
 class _ShardedSumSq(torch.autograd.Function):

@@ -83,10 +83,19 @@ class RowShardedOp:
     ``lanczos.integrand_spd`` in place of the operator: vectors are then this rank's row shards (p, nrows), H and the
     SLQ values come out replicated, parameter gradients complete (summed over the row group)."""
 
-    def __init__(self, op, comm):
+    def __init__(self, op, comm, exchange="auto"):
         if not isinstance(op, NativeOp):
             raise TypeError("row sharding needs a native operator (DenseOp, CsrOp, RbfGramOp)")
         self.op, self.comm = op, comm
+        # sparse operators: neighbour exchange of the entries this rank's rows read (the halo of a stencil) instead of
+        # all-gathering the whole iterate; plans for A and A^T (collective: every rank of the row group builds them here)
+        self.plans = None
+        if exchange == "auto":
+            exchange = isinstance(op, CsrOp) and comm.world > 1
+        if exchange:
+            if not isinstance(op, CsrOp):
+                raise TypeError("the neighbour exchange needs a sparse (CSR) operator")
+            self.plans = (comm.plan_exchange(op.crow, op.col), comm.plan_exchange(op.t_crow, op.t_col))
 
     def bind(self, *params):
         return BoundOp(self, params)

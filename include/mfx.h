@@ -219,12 +219,20 @@ int mfx_rademacher(uint64_t seed, int64_t first_probe, int64_t p, int64_t n, int
 typedef int (*mfx_allreduce_fn)(void* ctx, void* buf, int64_t count, int dtype, void* stream); /* in place, sum */
 typedef int (*mfx_allgather_fn)(void* ctx, const void* in, void* out, int64_t count, int dtype,
                                 void* stream); /* out[r * count + i] = in_of_rank_r[i] */
+/* Optional neighbour exchange (sparse operators: a rank's rows read only a few entries owned by other ranks -- the halo of
+ * a stencil -- so all-gathering the whole iterate moves far more than needed).  `full` holds p vectors of length n with leading
+ * dimension ldfull; the library has already copied this rank's own rows (`local`, p rows with leading dimension ldlocal) into
+ * their place [rank nloc, ...).  The callback must fill every entry of `full` that this rank's rows of A (transpose = 0) or of
+ * A^T (transpose = 1) read and that another rank owns; it may leave the rest untouched (it is never read).  NULL: all-gather. */
+typedef int (*mfx_exchange_fn)(void* ctx, const void* local, int64_t ldlocal, void* full, int64_t ldfull, int64_t p,
+                               int dtype, int transpose, void* stream);
 typedef struct mfx_comm {
   int32_t rank, world;
   int64_t nloc; /* rows per rank (last rank: n - rank * nloc >= 1) */
   mfx_allreduce_fn allreduce_sum;
   mfx_allgather_fn allgather;
   void* ctx;
+  mfx_exchange_fn exchange; /* optional, see above */
 } mfx_comm;
 
 int64_t mfx_sharded_workspace_bytes(const mfx_operator* op, const mfx_comm* comm, int64_t n, int64_t k, int64_t p);

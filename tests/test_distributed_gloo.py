@@ -145,3 +145,49 @@ def test_row_sharded_estimate_equals_single_process_world2(tmp_path):
 
 def test_rows_x_probes_grid_2x2_equals_single_process(tmp_path):
     _run_grid(tmp_path, 4, 2)
+
+
+# ---- neighbour exchange plan of a sparse operator (the halo of a stencil) ------------------------------------------------------
+def _halo_worker(rank, world, port, out):
+    _setup_paths()
+    import datetime
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    from matfree_extensions.distributed import RowComm
+
+    n = 300  # 3 ranks x 128 rows (last: 44); tridiagonal matrix + one far coupling 0 <-> 299
+    rows = np.repeat(np.arange(n), 3)
+    cols = np.clip(rows + np.tile([-1, 0, 1], n), 0, n - 1)
+    rows, cols = np.concatenate([rows, [0, n - 1]]), np.concatenate([cols, [n - 1, 0]])
+    order = np.lexsort((cols, rows))
+    rows, cols = rows[order], cols[order]
+    crow = torch.tensor(np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=n))]), dtype=torch.int32)
+    col = torch.tensor(cols, dtype=torch.int32)
+    comm = RowComm(n)
+    plan = comm.plan_exchange(crow, col)
+    x = torch.arange(2 * n, dtype=torch.float64).reshape(2, n)  # two vectors
+    full = torch.full((2, n), -1.0, dtype=torch.float64)
+    full[:, comm.row0 : comm.row0 + comm.nrows] = comm.rows(x)
+    comm._exchange(comm.rows(x), full, plan)
+    needed = np.unique(cols[(rows >= comm.row0) & (rows < comm.row0 + comm.nrows)])
+    ok = bool(torch.equal(full[:, needed], x[:, needed]))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (plan, ok))
+    if rank == 0:
+        torch.save(gathered, out)
+    dist.destroy_process_group()
+
+
+def test_neighbour_exchange_plan_and_transfer(tmp_path):
+    _setup_paths()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "halo.pt")
+    mp.spawn(_halo_worker, args=(3, port, out), nprocs=3, join=True)
+    got = torch.load(out)
+    assert all(ok for _plan, ok in got)  # every entry a rank's rows read arrived
+    (recv0, send0), (recv1, send1), (recv2, send2) = (p for p, _ in got)
+    assert sorted(recv0) == [(1, 128, 129), (2, 299, 300)] and sorted(send0) == [(1, 127, 128), (2, 0, 1)]
+    assert sorted(recv1) == [(0, 127, 128), (2, 256, 257)] and sorted(recv2) == [(0, 0, 1), (1, 255, 256)]
