@@ -67,7 +67,7 @@ struct CombineArgs {
   int k, idx, kmax, nblk;
 };
 
-template <typename T, int VEC>
+template <typename T, int VEC, int EPT>
 __global__ __launch_bounds__(kBlock) void k_adj_combine(CombineArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* g = reinterpret_cast<T*>(smem_raw);  // [k]
@@ -100,65 +100,65 @@ __global__ __launch_bounds__(kBlock) void k_adj_combine(CombineArgs<T> a) {
   const T alpha = Hb[(int64_t)idx * k + idx];
   const T bminus = (idx == 0) ? T(1) : Hb[(int64_t)idx * k + idx - 1];
   const T eta_i = a.eta[(int64_t)b * k + idx];
-  const int64_t slice0 = (int64_t)blk * ((int64_t)blockDim.x * kEpt);
+  const int64_t slice0 = (int64_t)blk * ((int64_t)blockDim.x * EPT);
   const int64_t n = a.n;
   const T* Qb = a.Q + (int64_t)b * k * n;
   const T* Lb = a.Lam + (int64_t)b * k * n;
-  T acc[kEpt], t[kEpt];
+  T acc[EPT], t[EPT];
   load_own<T, VEC>(acc, a.z + (int64_t)b * n, slice0, n, tid);
   load_own<T, VEC>(t, Lb + (int64_t)idx * n, slice0, n, tid);
 #pragma unroll
-  for (int e = 0; e < kEpt; ++e) acc[e] -= alpha * t[e];
+  for (int e = 0; e < EPT; ++e) acc[e] -= alpha * t[e];
   load_own<T, VEC>(t, a.r + (int64_t)b * n, slice0, n, tid);
 #pragma unroll
-  for (int e = 0; e < kEpt; ++e) acc[e] += eta_i * t[e];
+  for (int e = 0; e < EPT; ++e) acc[e] += eta_i * t[e];
   if (a.dQ) {
     load_own<T, VEC>(t, a.dQ + ((int64_t)b * k + idx) * n, slice0, n, tid);
 #pragma unroll
-    for (int e = 0; e < kEpt; ++e) acc[e] += t[e];
+    for (int e = 0; e < EPT; ++e) acc[e] += t[e];
   }
-  constexpr int JT = 4;  // rows in flight per thread
+  constexpr int JT = EPT <= 4 ? 8 : 4;  // rows in flight per thread
   {
     int j = 0;
     for (; j + JT <= k; j += JT) {
-      T rr[JT][kEpt];
+      T rr[JT][EPT];
 #pragma unroll
       for (int q = 0; q < JT; ++q) load_own<T, VEC>(rr[q], Qb + (int64_t)(j + q) * n, slice0, n, tid);
 #pragma unroll
       for (int q = 0; q < JT; ++q) {
         const T gj = g[j + q];
 #pragma unroll
-        for (int e = 0; e < kEpt; ++e) acc[e] += gj * rr[q][e];
+        for (int e = 0; e < EPT; ++e) acc[e] += gj * rr[q][e];
       }
     }
     for (; j < k; ++j) {
       load_own<T, VEC>(t, Qb + (int64_t)j * n, slice0, n, tid);
       const T gj = g[j];
 #pragma unroll
-      for (int e = 0; e < kEpt; ++e) acc[e] += gj * t[e];
+      for (int e = 0; e < EPT; ++e) acc[e] += gj * t[e];
     }
     j = idx + 1;
     for (; j + JT <= k; j += JT) {
-      T rr[JT][kEpt];
+      T rr[JT][EPT];
 #pragma unroll
       for (int q = 0; q < JT; ++q) load_own<T, VEC>(rr[q], Lb + (int64_t)(j + q) * n, slice0, n, tid);
 #pragma unroll
       for (int q = 0; q < JT; ++q) {
         const T hj = hp[j + q];
 #pragma unroll
-        for (int e = 0; e < kEpt; ++e) acc[e] -= hj * rr[q][e];
+        for (int e = 0; e < EPT; ++e) acc[e] -= hj * rr[q][e];
       }
     }
     for (; j < k; ++j) {
       load_own<T, VEC>(t, Lb + (int64_t)j * n, slice0, n, tid);
       const T hj = hp[j];
 #pragma unroll
-      for (int e = 0; e < kEpt; ++e) acc[e] -= hj * t[e];
+      for (int e = 0; e < EPT; ++e) acc[e] -= hj * t[e];
     }
   }
   const T inv = T(1) / bminus;
 #pragma unroll
-  for (int e = 0; e < kEpt; ++e) acc[e] *= inv;
+  for (int e = 0; e < EPT; ++e) acc[e] *= inv;
   store_own<T, VEC>(acc, a.out + (int64_t)b * n, slice0, n, tid);
 }
 
@@ -433,6 +433,7 @@ static int arnoldi_forward_t(const mfx_operator* op, const T* v0, int64_t n, int
                              hipStream_t stream, const mfx_comm* comm = nullptr, T* Qfull = nullptr) {
   Ctx<T> c(n, k, p, pick_vec<T>(n, {v0, Q, r, ws.w}), stream);
   if (comm) c.shard(comm, static_cast<T*>(ws.stage));
+  c.fine();
   T* P1 = static_cast<T*>(ws.p1);
   T* P2 = static_cast<T*>(ws.p2);
   T* PN = static_cast<T*>(ws.pn);
@@ -489,6 +490,7 @@ static int arnoldi_adjoint_t(const mfx_operator* op, int64_t n, int64_t k, int64
                              hipStream_t stream, const mfx_comm* comm = nullptr, const T* Qfull = nullptr) {
   Ctx<T> c(n, k, p, pick_vec<T>(n, {Q, r, dQ, dr, dv, Lam, ws.w}), stream);
   if (comm) c.shard(comm, static_cast<T*>(ws.stage));
+  c.fine();
   T* P1 = static_cast<T*>(ws.p1);
   T* lam = static_cast<T*>(ws.w);  // current lambda (p, n)
   T* z = lam + p * n;              // A^T lambda     (p, n)
@@ -505,7 +507,7 @@ static int arnoldi_adjoint_t(const mfx_operator* op, int64_t n, int64_t k, int64
     if (dQ) {
       for (int64_t col = 0; col < k; ++col) {
         MFX_TRY(launch_dots<T>(c, Q, ldq, n, (int)k, dQ + col * n, ldq, P1));
-        k_pig_sub<T><<<(unsigned)p, 64, 0, stream>>>(pig, (int)k, (int)col, P1, c.kmax, c.nblk_in);
+        k_pig_sub<T><<<(unsigned)p, 512, 0, stream>>>(pig, (int)k, (int)col, P1, c.kmax, c.nblk_in);  // latency-bound: 8 lanes per coefficient
         MFX_CHECK_LAUNCH();
       }
     }
@@ -552,7 +554,7 @@ static int arnoldi_adjoint_t(const mfx_operator* op, int64_t n, int64_t k, int64
     MFX_TRY(launch_dots<T>(c, Q, ldq, n, (int)(idx + 1), z, n, P1));
     CombineArgs<T> ca{Q, Lam, H, pig, eta, r, dQ, z, P1, Gam, lam, n, (int)k, (int)idx, c.kmax, c.nblk_in};
     const size_t sh = (size_t)2 * k * sizeof(T);
-    MFX_VEC_SWITCH(c.vec, (k_adj_combine<T, VEC><<<c.grid(), c.wg, sh, stream>>>(ca)));
+    MFX_VEC_EPT_SWITCH(c, (k_adj_combine<T, VEC, EPT><<<c.grid(), c.wg, sh, stream>>>(ca)));
     MFX_CHECK_LAUNCH();
   }
   if (!fused) {

@@ -11,10 +11,10 @@ namespace mfx {
 // ------------------------------------------------------------------------------------------------
 // thread-owned elements
 // ------------------------------------------------------------------------------------------------
-template <typename T, int VEC>
-__device__ __forceinline__ void load_own(T (&dst)[kEpt], const T* __restrict__ base, int64_t slice0,
+template <typename T, int VEC, int EPT>
+__device__ __forceinline__ void load_own(T (&dst)[EPT], const T* __restrict__ base, int64_t slice0,
                                          int64_t n, int tid) {
-  constexpr int U = kEpt / VEC;
+  constexpr int U = EPT / VEC;
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int64_t off = slice0 + (int64_t)(u * (int)blockDim.x + tid) * VEC;
@@ -29,10 +29,10 @@ __device__ __forceinline__ void load_own(T (&dst)[kEpt], const T* __restrict__ b
   }
 }
 
-template <typename T, int VEC>
-__device__ __forceinline__ void store_own(const T (&src)[kEpt], T* __restrict__ base, int64_t slice0,
+template <typename T, int VEC, int EPT>
+__device__ __forceinline__ void store_own(const T (&src)[EPT], T* __restrict__ base, int64_t slice0,
                                           int64_t n, int tid) {
-  constexpr int U = kEpt / VEC;
+  constexpr int U = EPT / VEC;
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int64_t off = slice0 + (int64_t)(u * (int)blockDim.x + tid) * VEC;
@@ -70,7 +70,7 @@ constexpr int kRedG = 8;  // lanes per coefficient in the multi-coefficient prol
 // K-dots: partial[b][j][blk] = sum_{i in slice} rows[b][j][i] * x[b][i],  j < m
 //   forward  h = Q^T w            (arnoldi.py:87)      adjoint  P lam, z^T Q   (arnoldi.py:204,212)
 // ------------------------------------------------------------------------------------------------
-template <typename T, int VEC>
+template <typename T, int VEC, int EPT>
 __global__ __launch_bounds__(kBlock) void k_dots(const T* __restrict__ rows, int64_t rows_ldb,
                                                  int64_t row_stride, int m,
                                                  const T* __restrict__ x, int64_t ldx, int64_t n,
@@ -79,31 +79,31 @@ __global__ __launch_bounds__(kBlock) void k_dots(const T* __restrict__ rows, int
   T* sm = reinterpret_cast<T*>(smem_raw);  // [4][m]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int b = blockIdx.y, blk = blockIdx.x;
-  const int64_t slice0 = (int64_t)blk * ((int64_t)blockDim.x * kEpt);
-  T xr[kEpt];
+  const int64_t slice0 = (int64_t)blk * ((int64_t)blockDim.x * EPT);
+  T xr[EPT];
   load_own<T, VEC>(xr, x + (int64_t)b * ldx, slice0, n, tid);
   const T* rb = rows + (int64_t)b * rows_ldb;
-  constexpr int JT = 4;  // rows in flight per thread: 4 x 8 elements of loads before the first use
+  constexpr int JT = EPT <= 4 ? 8 : 4;  // rows in flight per thread: >= 16 B x 8 of loads before the first use
   int j = 0;
   for (; j + JT <= m; j += JT) {
-    T rr[JT][kEpt];
+    T rr[JT][EPT];
 #pragma unroll
     for (int q = 0; q < JT; ++q) load_own<T, VEC>(rr[q], rb + (int64_t)(j + q) * row_stride, slice0, n, tid);
 #pragma unroll
     for (int q = 0; q < JT; ++q) {
       T acc = T(0);
 #pragma unroll
-      for (int e = 0; e < kEpt; ++e) acc += rr[q][e] * xr[e];
+      for (int e = 0; e < EPT; ++e) acc += rr[q][e] * xr[e];
       acc = wave_sum(acc);
       if (lane == 0) sm[wid * m + j + q] = acc;
     }
   }
   for (; j < m; ++j) {
-    T rr[kEpt];
+    T rr[EPT];
     load_own<T, VEC>(rr, rb + (int64_t)j * row_stride, slice0, n, tid);
     T acc = T(0);
 #pragma unroll
-    for (int e = 0; e < kEpt; ++e) acc += rr[e] * xr[e];
+    for (int e = 0; e < EPT; ++e) acc += rr[e] * xr[e];
     acc = wave_sum(acc);
     if (lane == 0) sm[wid * m + j] = acc;
   }
@@ -146,14 +146,14 @@ struct UpdateArgs {
   int nblk_in;  // slices of partial_in (1 when the partials were summed over the row shards, see Ctx::comm)
 };
 
-template <typename T, int VEC, bool DOTS, bool NORM>
+template <typename T, int VEC, bool DOTS, bool NORM, int EPT>
 __global__ __launch_bounds__(kBlock) void k_update(UpdateArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* coef = reinterpret_cast<T*>(smem_raw);  // [m]
   T* sm = coef + a.m;                         // [4][m] (DOTS) ; [4] (NORM) after that
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int b = blockIdx.y, blk = blockIdx.x;
-  const int64_t slice0 = (int64_t)blk * ((int64_t)blockDim.x * kEpt);
+  const int64_t slice0 = (int64_t)blk * ((int64_t)blockDim.x * EPT);
   const int m = a.m;
   for (int idx = tid; idx < m * kRedG; idx += (int)blockDim.x) {  // kRedG lanes per coefficient
     const int j = idx / kRedG, g = idx % kRedG;
@@ -167,34 +167,34 @@ __global__ __launch_bounds__(kBlock) void k_update(UpdateArgs<T> a) {
     }
   }
   __syncthreads();
-  T xr[kEpt];
+  T xr[EPT];
   if (a.x) {
     load_own<T, VEC>(xr, a.x + (int64_t)b * a.ldx, slice0, a.n, tid);
   } else {
 #pragma unroll
-    for (int e = 0; e < kEpt; ++e) xr[e] = T(0);
+    for (int e = 0; e < EPT; ++e) xr[e] = T(0);
   }
   const T* rb = a.rows + (int64_t)b * a.rows_ldb;
-  constexpr int JT = 4;  // rows in flight per thread
+  constexpr int JT = EPT <= 4 ? 8 : 4;  // rows in flight per thread
   {
     int j = 0;
     for (; j + JT <= m; j += JT) {
-      T rr[JT][kEpt];
+      T rr[JT][EPT];
 #pragma unroll
       for (int q = 0; q < JT; ++q) load_own<T, VEC>(rr[q], rb + (int64_t)(j + q) * a.row_stride, slice0, a.n, tid);
 #pragma unroll
       for (int q = 0; q < JT; ++q) {
         const T c = coef[j + q];
 #pragma unroll
-        for (int e = 0; e < kEpt; ++e) xr[e] -= c * rr[q][e];
+        for (int e = 0; e < EPT; ++e) xr[e] -= c * rr[q][e];
       }
     }
     for (; j < m; ++j) {
-      T rr[kEpt];
+      T rr[EPT];
       load_own<T, VEC>(rr, rb + (int64_t)j * a.row_stride, slice0, a.n, tid);
       const T c = coef[j];
 #pragma unroll
-      for (int e = 0; e < kEpt; ++e) xr[e] -= c * rr[e];
+      for (int e = 0; e < EPT; ++e) xr[e] -= c * rr[e];
     }
   }
   store_own<T, VEC>(xr, a.y + (int64_t)b * a.ldy, slice0, a.n, tid);
@@ -202,24 +202,24 @@ __global__ __launch_bounds__(kBlock) void k_update(UpdateArgs<T> a) {
   if constexpr (DOTS) {
     int j = 0;
     for (; j + JT <= m; j += JT) {
-      T rr[JT][kEpt];
+      T rr[JT][EPT];
 #pragma unroll
       for (int q = 0; q < JT; ++q) load_own<T, VEC>(rr[q], rb + (int64_t)(j + q) * a.row_stride, slice0, a.n, tid);
 #pragma unroll
       for (int q = 0; q < JT; ++q) {
         T acc = T(0);
 #pragma unroll
-        for (int e = 0; e < kEpt; ++e) acc += rr[q][e] * xr[e];
+        for (int e = 0; e < EPT; ++e) acc += rr[q][e] * xr[e];
         acc = wave_sum(acc);
         if (lane == 0) sm[wid * m + j + q] = acc;
       }
     }
     for (; j < m; ++j) {
-      T rr[kEpt];
+      T rr[EPT];
       load_own<T, VEC>(rr, rb + (int64_t)j * a.row_stride, slice0, a.n, tid);
       T acc = T(0);
 #pragma unroll
-      for (int e = 0; e < kEpt; ++e) acc += rr[e] * xr[e];
+      for (int e = 0; e < EPT; ++e) acc += rr[e] * xr[e];
       acc = wave_sum(acc);
       if (lane == 0) sm[wid * m + j] = acc;
     }
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(kBlock) void k_update(UpdateArgs<T> a) {
     T* smn = sm + (DOTS ? 4 * m : 0);
     T acc = T(0);
 #pragma unroll
-    for (int e = 0; e < kEpt; ++e) acc += xr[e] * xr[e];
+    for (int e = 0; e < EPT; ++e) acc += xr[e] * xr[e];
     acc = wave_sum(acc);
     if (lane == 0) smn[wid] = acc;
     __syncthreads();
@@ -250,17 +250,17 @@ __global__ __launch_bounds__(kBlock) void k_update(UpdateArgs<T> a) {
 // ------------------------------------------------------------------------------------------------
 // K-sumsq: partial_norm[b][blk] = sum x^2          (arnoldi.py:67, lanczos.py:222)
 // ------------------------------------------------------------------------------------------------
-template <typename T, int VEC>
+template <typename T, int VEC, int EPT>
 __global__ __launch_bounds__(kBlock) void k_sumsq(const T* __restrict__ x, int64_t ldx, int64_t n,
                                                   T* __restrict__ partial_norm, int nblk) {
   __shared__ T smn[4];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int b = blockIdx.y, blk = blockIdx.x;
-  T xr[kEpt];
-  load_own<T, VEC>(xr, x + (int64_t)b * ldx, (int64_t)blk * ((int64_t)blockDim.x * kEpt), n, tid);
+  T xr[EPT];
+  load_own<T, VEC>(xr, x + (int64_t)b * ldx, (int64_t)blk * ((int64_t)blockDim.x * EPT), n, tid);
   T acc = T(0);
 #pragma unroll
-  for (int e = 0; e < kEpt; ++e) acc += xr[e] * xr[e];
+  for (int e = 0; e < EPT; ++e) acc += xr[e] * xr[e];
   acc = wave_sum(acc);
   if (lane == 0) smn[wid] = acc;
   __syncthreads();
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(kBlock) void k_sumsq(const T* __restrict__ x, int64
 //   mode 0: f = 1/len   (normalise: arnoldi.py:80, lanczos.py:258)      mode 1: f = scale[b]      mode 2: f = -1
 //   optional scalar outputs: len_out[b*ld] = len, inv_out[b] = 1/len.  y may be null (scalars only).
 // ------------------------------------------------------------------------------------------------
-template <typename T, int VEC>
+template <typename T, int VEC, int EPT>
 __global__ __launch_bounds__(kBlock) void k_scale(const T* __restrict__ x, int64_t ldx,
                                                   T* __restrict__ y, int64_t ldy, int64_t n,
                                                   const T* __restrict__ partial_norm, int nblk,
@@ -305,11 +305,11 @@ __global__ __launch_bounds__(kBlock) void k_scale(const T* __restrict__ x, int64
   __syncthreads();
   if (!y) return;
   const T f = f_sh;
-  T xr[kEpt];
-  load_own<T, VEC>(xr, x + (int64_t)b * ldx, (int64_t)blk * ((int64_t)blockDim.x * kEpt), n, tid);
+  T xr[EPT];
+  load_own<T, VEC>(xr, x + (int64_t)b * ldx, (int64_t)blk * ((int64_t)blockDim.x * EPT), n, tid);
 #pragma unroll
-  for (int e = 0; e < kEpt; ++e) xr[e] *= f;
-  store_own<T, VEC>(xr, y + (int64_t)b * ldy, (int64_t)blk * ((int64_t)blockDim.x * kEpt), n, tid);
+  for (int e = 0; e < EPT; ++e) xr[e] *= f;
+  store_own<T, VEC>(xr, y + (int64_t)b * ldy, (int64_t)blk * ((int64_t)blockDim.x * EPT), n, tid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -330,6 +330,23 @@ static int pick_vec(int64_t n, std::initializer_list<const void*> ptrs) {
     __VA_ARGS__;                                \
   } else {                                      \
     constexpr int VEC = 1;                      \
+    __VA_ARGS__;                                \
+  }
+
+// VEC and the elements per thread EPT: kEpt (2048-element slices), or -- Ctx::fine -- one 16-byte load per thread and row
+// (512 / 1024-element slices) when the coarse slicing leaves most CUs idle
+#define MFX_VEC_EPT_SWITCH(c, ...)              \
+  if ((c).vec > 1 && (c).ept != kEpt) {         \
+    constexpr int VEC = VecWidth<T>::value;     \
+    constexpr int EPT = VEC;                    \
+    __VA_ARGS__;                                \
+  } else if ((c).vec > 1) {                     \
+    constexpr int VEC = VecWidth<T>::value;     \
+    constexpr int EPT = kEpt;                   \
+    __VA_ARGS__;                                \
+  } else {                                      \
+    constexpr int VEC = 1;                      \
+    constexpr int EPT = kEpt;                   \
     __VA_ARGS__;                                \
   }
 
@@ -358,6 +375,7 @@ template <typename T>
 struct Ctx {
   int64_t n, k, p;
   int wg, nblk, kmax, vec;
+  int ept = kEpt;  // elements per thread of the kernels launched through MFX_VEC_EPT_SWITCH
   hipStream_t stream;
   const mfx_comm* comm = nullptr;  // row-sharded mode
   T* stage = nullptr;              // (p, kmax, nblk) producer scratch of the sharded mode
@@ -365,6 +383,15 @@ struct Ctx {
   Ctx(int64_t n_, int64_t k_, int64_t p_, int vec_, hipStream_t s)
       : n(n_), k(k_), p(p_), wg(pick_wg(n_, p_)), nblk((int)((n_ + (int64_t)wg * kEpt - 1) / ((int64_t)wg * kEpt))),
         kmax((int)(k_ + 1)), vec(vec_), stream(s), nblk_in(nblk) {}
+  // Finer slices (one 16-byte load per thread and row) when the 2048-element slicing gives fewer than 128 workgroups: the
+  // vector kernels are bandwidth-bound PER CU (measured on config 3, n = 102400, one vector: 50 workgroups stream 1.4 TB/s).
+  // Only drivers whose every kernel goes through MFX_VEC_EPT_SWITCH may call this (the partial layout changes with nblk).
+  void fine() {
+    if (vec <= 1 || wg != kBlock || (int64_t)nblk * p >= 128) return;
+    ept = VecWidth<T>::value;
+    nblk = (int)((n + (int64_t)wg * ept - 1) / ((int64_t)wg * ept));
+    if (!comm) nblk_in = nblk;
+  }
   void shard(const mfx_comm* cm, T* stage_) {
     comm = cm;
     stage = stage_;
@@ -389,7 +416,7 @@ static int launch_dots(const Ctx<T>& c, const T* rows, int64_t rows_ldb, int64_t
                        const T* x, int64_t ldx, T* partial) {
   if (m <= 0) return MFX_OK;
   const size_t sh = (size_t)4 * m * sizeof(T);
-  MFX_VEC_SWITCH(c.vec, (k_dots<T, VEC><<<c.grid(), c.wg, sh, c.stream>>>(
+  MFX_VEC_EPT_SWITCH(c, (k_dots<T, VEC, EPT><<<c.grid(), c.wg, sh, c.stream>>>(
                             rows, rows_ldb, row_stride, m, x, ldx, c.n, c.producer(partial), c.kmax, c.nblk)));
   MFX_CHECK_LAUNCH();
   return c.finish(partial, c.kmax, m);
@@ -408,13 +435,13 @@ static int launch_update(const Ctx<T>& c, UpdateArgs<T> a, bool dots, bool norm)
   if (norm) a.partial_norm = c.producer(want_norm);
   const size_t sh = (size_t)(a.m + (dots ? 4 * a.m : 0) + 4) * sizeof(T);
   if (dots && norm) {
-    MFX_VEC_SWITCH(c.vec, (k_update<T, VEC, true, true><<<c.grid(), c.wg, sh, c.stream>>>(a)));
+    MFX_VEC_EPT_SWITCH(c, (k_update<T, VEC, true, true, EPT><<<c.grid(), c.wg, sh, c.stream>>>(a)));
   } else if (dots) {
-    MFX_VEC_SWITCH(c.vec, (k_update<T, VEC, true, false><<<c.grid(), c.wg, sh, c.stream>>>(a)));
+    MFX_VEC_EPT_SWITCH(c, (k_update<T, VEC, true, false, EPT><<<c.grid(), c.wg, sh, c.stream>>>(a)));
   } else if (norm) {
-    MFX_VEC_SWITCH(c.vec, (k_update<T, VEC, false, true><<<c.grid(), c.wg, sh, c.stream>>>(a)));
+    MFX_VEC_EPT_SWITCH(c, (k_update<T, VEC, false, true, EPT><<<c.grid(), c.wg, sh, c.stream>>>(a)));
   } else {
-    MFX_VEC_SWITCH(c.vec, (k_update<T, VEC, false, false><<<c.grid(), c.wg, sh, c.stream>>>(a)));
+    MFX_VEC_EPT_SWITCH(c, (k_update<T, VEC, false, false, EPT><<<c.grid(), c.wg, sh, c.stream>>>(a)));
   }
   MFX_CHECK_LAUNCH();
   if (dots) MFX_TRY(c.finish(want_dots, c.kmax, a.m));
@@ -424,7 +451,7 @@ static int launch_update(const Ctx<T>& c, UpdateArgs<T> a, bool dots, bool norm)
 
 template <typename T>
 static int launch_sumsq(const Ctx<T>& c, const T* x, int64_t ldx, T* partial_norm) {
-  MFX_VEC_SWITCH(c.vec, (k_sumsq<T, VEC><<<c.grid(), c.wg, 0, c.stream>>>(x, ldx, c.n, c.producer(partial_norm), c.nblk)));
+  MFX_VEC_EPT_SWITCH(c, (k_sumsq<T, VEC, EPT><<<c.grid(), c.wg, 0, c.stream>>>(x, ldx, c.n, c.producer(partial_norm), c.nblk)));
   MFX_CHECK_LAUNCH();
   return c.finish(partial_norm, 1, 1);
 }
@@ -433,7 +460,7 @@ template <typename T>
 static int launch_scale(const Ctx<T>& c, const T* x, int64_t ldx, T* y, int64_t ldy, const T* partial_norm,
                         const T* scale, int mode, T* len_out, int64_t len_ld, T* inv_out) {
   dim3 grid = y ? c.grid() : dim3(1, (unsigned)c.p);
-  MFX_VEC_SWITCH(c.vec, (k_scale<T, VEC><<<grid, c.wg, 0, c.stream>>>(x, ldx, y, ldy, c.n, partial_norm, c.nblk_in,
+  MFX_VEC_EPT_SWITCH(c, (k_scale<T, VEC, EPT><<<grid, c.wg, 0, c.stream>>>(x, ldx, y, ldy, c.n, partial_norm, c.nblk_in,
                                                                         scale, mode, len_out, len_ld, inv_out)));
   MFX_CHECK_LAUNCH();
   return MFX_OK;
