@@ -2,6 +2,8 @@
 // Included by the Krylov drivers (mfx_krylov.hip) and the CG / preconditioner drivers (mfx_cg.hip): every
 // kernel uses grid = (ceil(n / 2048), p) and per-slice partials, see the header comment of mfx_krylov.hip.
 #pragma once
+#include <stdlib.h>
+
 #include <initializer_list>
 
 #include "mfx_internal.h"
@@ -386,8 +388,12 @@ struct Ctx {
   // Finer slices (one 16-byte load per thread and row) when the 2048-element slicing gives fewer than 128 workgroups: the
   // vector kernels are bandwidth-bound PER CU (measured on config 3, n = 102400, one vector: 50 workgroups stream 1.4 TB/s).
   // Only drivers whose every kernel goes through MFX_VEC_EPT_SWITCH may call this (the partial layout changes with nblk).
+  // MEASURED (profiles/r02g_*): no net gain on config 3 -- k_dots' worst case drops from 30 to 20 us, but every consumer re-reduces
+  // 4x more partials in its prologue (update + norm 7.4 -> 14.7 us); forward 2.84 -> 2.91 ms, forward + adjoint 8.7 -> 8.0 ms, within
+  // box-to-box noise.  Off unless MFX_FINE_SLICES=1.
   void fine() {
-    if (vec <= 1 || wg != kBlock || (int64_t)nblk * p >= 128) return;
+    static const bool on = [] { const char* e = getenv("MFX_FINE_SLICES"); return e && atoi(e) != 0; }();
+    if (!on || vec <= 1 || wg != kBlock || (int64_t)nblk * p >= 128) return;
     ept = VecWidth<T>::value;
     nblk = (int)((n + (int64_t)wg * ept - 1) / ((int64_t)wg * ept));
     if (!comm) nblk_in = nblk;
