@@ -1182,7 +1182,7 @@ __global__ void k_global_scale(const float* __restrict__ amax, int64_t rows, flo
 
 // Pseudo-random sign of column i of a packed gradient-GEMM operand (salt: which operand).  Column i of L carries sigma_i,
 // column j of R carries tau_j, so the accumulator of S_ij holds sigma_i tau_j S_ij and the epilogue undoes the sign.
-// Why: the f16 MFMA's floor bias (see kGChunk below) is the SAME sign in every accumulator; with the operands' columns signed
+// Why: the f16 MFMA's floor bias (see the note above k_rbf_mfma_grad_h) is the SAME sign in every accumulator; with the operands' columns signed
 // at random it enters S_ij as -sigma_i tau_j beta ulp -- sign-random over (i, j), uncorrelated with dK_ij/dtheta -- and
 // sums like noise (~ |dK|_F) instead of coherently (~ sum_ij dK_ij, n times larger).  Measured: profiles/r02a_*.
 __host__ __device__ __forceinline__ bool grad_col_sign(int64_t i, uint32_t salt) {
@@ -1197,7 +1197,6 @@ __host__ __device__ __forceinline__ bool grad_col_sign(int64_t i, uint32_t salt)
 constexpr uint32_t kSaltL = 0x51ED270Bu, kSaltR = 0xB5297A4Du;
 
 // hi/lo packs: out[(kb * npad + i) * 8 + q] = piece of (+-) scale * x[8 kb + q][i], sign per column i = grad_col_sign(i, salt)
-// sign_period > 0: rows of every other block of `sign_period` batch rows are additionally stored NEGATED (see kGChunk)
 // inner > 1: the source rows come as (batch / inner) groups of `inner` rows -- (probe, Krylov step) -- and are packed
 // TRANSPOSED, (step, probe): the 16 rows that meet in one MFMA then belong to the same step of different probes and have
 // similar magnitudes.  Why it matters: the f16 MFMA aligns the 16 products of an output element to the largest of them and
@@ -1205,14 +1204,12 @@ constexpr uint32_t kSaltL = 0x51ED270Bu, kSaltR = 0xB5297A4Du;
 // magnitude -- with (probe, step) order every small product lost bits, always in the direction that shrinks its contribution,
 // a sign-symmetric bias that no sign alternation can cancel (1.6e-4 / 4.3e-4 gradient error at n = 65536).
 __global__ __launch_bounds__(256) void k_pack_f16(const float* __restrict__ x, int64_t ldx, int64_t batch, int64_t n,
-                                                  int64_t npad, const float* __restrict__ scale, int sign_period,
-                                                  uint32_t salt, int64_t inner, _Float16* __restrict__ hi,
-                                                  _Float16* __restrict__ lo) {
+                                                  int64_t npad, const float* __restrict__ scale, uint32_t salt, int64_t inner,
+                                                  _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t kb = blockIdx.y;
   if (i >= npad) return;
   float s = scale[0];
-  if (sign_period > 0 && ((kb * 8 / sign_period) & 1)) s = -s;
   if (grad_col_sign(i, salt)) s = -s;
   half8 h, l;
 #pragma unroll
@@ -1235,35 +1232,40 @@ __global__ __launch_bounds__(256) void k_pack_f16(const float* __restrict__ x, i
 constexpr int kHM = 256;
 constexpr int kHLd = kHM + 4;
 
-template <int DPAD>
+// NBW = 32-column blocks per wave: the workgroup tile is 256 rows x (2 NBW 32) columns, 8 waves as 4 x 2 of 64 x (NBW 32).
+//   NBW = 2: 256 x 128 (round 1);  NBW = 4: 256 x 256 -- (256 + 256) instead of 2 x (256 + 128) operand columns through L2 -> LDS
+//   per stage and per 256 x 256 of S, i.e. a third less of the traffic this kernel is bound by.  Its 128 accumulator registers
+//   fit since the fp32 master accumulators are gone (see the note on the floor bias below).
+template <int DPAD, int NBW>
 struct GradSmemH {
+  static constexpr int TN = 2 * NBW * 32;  // columns of the workgroup tile
   union {
     struct {
       _Float16 a_hi[4][2][kHM][8];  // [ring slot][kb within the 16-row stage][i][8]
       _Float16 a_lo[4][2][kHM][8];
-      _Float16 b_hi[4][2][kGN][8];
-      _Float16 b_lo[4][2][kGN][8];
+      _Float16 b_hi[4][2][TN][8];
+      _Float16 b_lo[4][2][TN][8];
     } st;
-    float s_t[kGN][kHLd];
+    float s_t[kGN][kHLd];  // S^T of ONE 128-column pass of the epilogue
   } u;
   float xi[kHM][DPAD];
   float sqi[kHM];
   float xj[kGN][DPAD];
   float sqj[kGN];
-  float sgj[kGN];  // tau_j of the staged column tile (+-1)
+  float sgj[kGN];  // tau_j of the staged columns (+-1)
   double red[8][DPAD + 2];
 };
 
 
 // The f16 MFMA truncates its internal sum towards -infinity: a bias of a fraction of an ulp per MFMA, invisible in
 // any single accumulator but COHERENT across all n^2 accumulators of S, and the gradient sum_ij S_ij dK_ij/dtheta
-// cancels to ~1e-4..1e-5 of its terms -- measured as a 0.1-1 % gradient error.  Cure at zero cost: the L operand of
-// every other K-chunk (kGChunk stages = 256 batch rows) is packed NEGATED and that chunk's accumulator is
-// SUBTRACTED from the fp32 master accumulator (round-to-nearest VALU adds), so the floor bias enters with
-// alternating sign and cancels.
-constexpr int kGChunk = 8;
+// cancels to ~1e-4..1e-5 of its terms -- measured as a 0.1-1 % gradient error.  Round 1 cured it with alternating-sign
+// K-chunks folded into fp32 master accumulators (64 more registers, 128 VALU instructions per chunk).  The pseudo-random
+// column signs of the packed operands (grad_col_sign) do the same job for free: with them and WITHOUT the chunks the C4
+// gradient is 9.8e-6 / 3.0e-5 off fp64, without either 2.2e-2 / 5.6e-2 (profiles/r02h_*) -- so the chunks and the master
+// accumulators are gone, which is what makes room for the 256 x 256 tile.
 
-template <int DPAD>
+template <int DPAD, int NBW>
 __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restrict__ xs, const float* __restrict__ sq,
                                                             int64_t n, int64_t npad_l, int64_t npad_r, int ard, int kind,
                                                             const _Float16* __restrict__ Lh, const _Float16* __restrict__ Ll,
@@ -1272,8 +1274,10 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
                                                             uint32_t salt_l, uint32_t salt_r, double* __restrict__ partial,
                                                             int64_t row0, int64_t nrow) {
   // rows: the nrow points row0 .. of X that the L operand covers (a row shard, or all n); columns: all n points
+  using Smem = GradSmemH<DPAD, NBW>;
+  constexpr int TN = Smem::TN;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  GradSmemH<DPAD>& sm = *reinterpret_cast<GradSmemH<DPAD>*>(smem_raw);
+  Smem& sm = *reinterpret_cast<Smem*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5;
@@ -1281,7 +1285,7 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
   // blockIdx.x = XCD label (workgroups are dealt to XCDs round-robin in linear order); within an XCD, blockIdx.y
   // enumerates (row block, column sub-range) with the sub-range fastest, see kGSub
   const int64_t i0 = (int64_t)(blockIdx.y / kGSub) * kHM;
-  const int64_t ntj = (n + kGN - 1) / kGN;
+  const int64_t ntj = (n + TN - 1) / TN;
   const int64_t tj_begin = ((int64_t)blockIdx.x * kGSub + blockIdx.y % kGSub) * tiles_per_block;
   int64_t tj_end = tj_begin + tiles_per_block;
   if (tj_end > ntj) tj_end = ntj;
@@ -1296,45 +1300,47 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
 #pragma unroll
   for (int c = 0; c < DPAD + 2; ++c) gsum[c] = 0.0;
 
-  // staging by LDS-DMA: per stage 4 kb-groups x 128 columns x 16 B per operand piece = 512 chunks, chunk c lives
-  // at byte 16 c of its piece: wave w copies chunks [64 w + 256 u, +64), u = 0, 1 -- no staging registers.
-  // Addresses are 32-bit byte offsets from the (scalar) piece bases, advanced by one constant per stage: the 64-bit
-  // per-stage address arithmetic was a quarter of this kernel's VALU instructions, and VALU time adds to MFMA time.
-  // Ring of FOUR 16-row stages, three of them in flight: a stage's DMA has three stages of MFMAs (>= 1100 cycles) to land, where
-  // the two-buffer scheme of 32-row stages gave it one -- and its barrier waited for the L2/MALL latency every stage (SQ_WAIT_ANY
-  // 26 %).  Per stage: wait for MY pieces of stage st (counted vmcnt: the later stages stay in flight), barrier (everybody's
-  // pieces landed AND everybody is done reading stage st - 1), refill the slot of stage st - 1 with stage st + 3, compute.
-  // Pieces per stage (1 KiB = one wave-instruction): L hi / lo 2 kb-groups x 256 columns = 8 each, R hi / lo 2 x 128 = 4 each;
-  // wave w copies L-hi piece w, L-lo piece w and one R piece (waves 0-3: hi, 4-7: lo): 3 glds per thread and stage.
+  // staging by LDS-DMA: per stage 2 kb-groups x (256 | TN) columns x 16 B per operand piece, chunk c lives at byte 16 c of its
+  // piece: no staging registers.  Addresses are 32-bit byte offsets from the (scalar) piece bases, advanced by one constant
+  // per stage.  Ring of FOUR 16-row stages, three of them in flight.  Per stage: wait for MY pieces of stage st (counted
+  // vmcnt: the later stages stay in flight), barrier (everybody's pieces landed AND everybody is done reading stage st - 1),
+  // refill the slot of stage st - 1 with stage st + 3, compute.
+  // Pieces per stage (1 KiB = one wave-instruction): L hi / lo 2 x 256 columns = 8 each (wave w: piece w of both);
+  // R hi / lo 2 x TN columns: TN = 128: 4 each (waves 0-3 hi, 4-7 lo); TN = 256: 8 each (wave w: piece w of both).
+  constexpr int kRPieces = TN / 32;              // 1-KiB pieces of R hi (and of R lo) per stage
+  constexpr int kGlds = kRPieces == 8 ? 4 : 3;   // glds per thread and stage
   const int64_t nstage = nkb / 2;
   const uint32_t stage_bytes_l = (uint32_t)(2 * npad_l * 16);  // 2 kb-groups of npad columns x 8 halves
   const uint32_t stage_bytes_r = (uint32_t)(2 * npad_r * 16);
   const int cwa = wid * 64 + lane;                          // my chunk of an L piece: kb-group cwa >> 8, column cwa & 255
-  const int cwb = (wid & 3) * 64 + lane;                    // my chunk of an R piece: kb-group cwb >> 7, column cwb & 127
+  const int cwb = (kRPieces == 8 ? wid : (wid & 3)) * 64 + lane;  // my chunk of an R piece: kb-group cwb / TN, column cwb % TN
   const uint32_t offL = (uint32_t)((((int64_t)(cwa >> 8) * npad_l) + i0 + (cwa & 255)) * 16);
-  const uint32_t offR0 = (uint32_t)((((int64_t)(cwb >> 7) * npad_r) + (cwb & 127)) * 16);
+  const uint32_t offR0 = (uint32_t)((((int64_t)(cwb / TN) * npad_r) + (cwb % TN)) * 16);
   const char* Lhb = reinterpret_cast<const char*>(Lh);
   const char* Llb = reinterpret_cast<const char*>(Ll);
-  const char* Rxb = reinterpret_cast<const char*>(wid < 4 ? Rh : Rl);
-  const int ca = wid * 64, cb = (wid & 3) * 64;  // first chunks of this wave's instructions (wave-uniform)
+  const char* Rhb = reinterpret_cast<const char*>(Rh);
+  const char* Rlb = reinterpret_cast<const char*>(Rl);
+  const int ca = wid * 64, cb = (kRPieces == 8 ? wid : (wid & 3)) * 64;  // first chunks of this wave's instructions (wave-uniform)
   auto issue_stage = [&](uint32_t l_off, uint32_t r_off, int slot) {
     glds16(Lhb + l_off, &sm.u.st.a_hi[slot][ca >> 8][ca & 255][0]);
     glds16(Llb + l_off, &sm.u.st.a_lo[slot][ca >> 8][ca & 255][0]);
-    glds16(Rxb + r_off, wid < 4 ? &sm.u.st.b_hi[slot][cb >> 7][cb & 127][0] : &sm.u.st.b_lo[slot][cb >> 7][cb & 127][0]);
+    if constexpr (kRPieces == 8) {
+      glds16(Rhb + r_off, &sm.u.st.b_hi[slot][cb / TN][cb % TN][0]);
+      glds16(Rlb + r_off, &sm.u.st.b_lo[slot][cb / TN][cb % TN][0]);
+    } else {
+      glds16((wid < 4 ? Rhb : Rlb) + r_off, wid < 4 ? &sm.u.st.b_hi[slot][cb / TN][cb % TN][0] : &sm.u.st.b_lo[slot][cb / TN][cb % TN][0]);
+    }
   };
 
   for (int64_t tj = tj_begin; tj < tj_end; ++tj) {
-    const int64_t j0 = tj * kGN;
-    floatx16 acc[2][2], master[2][2];
+    const int64_t j0 = tj * TN;
+    floatx16 acc[2][NBW];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < NBW; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          acc[a][b][r] = 0.f;
-          master[a][b][r] = 0.f;
-        }
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     uint32_t ol = offL, orr = offR0 + (uint32_t)(j0 * 16);
     __syncthreads();  // previous tile's epilogue reads of the overlaid S^T tile are done
@@ -1346,12 +1352,12 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
     }
     for (int64_t st = 0; st < nstage; ++st) {
       const int slot = (int)(st & 3);
-      // 3 glds per stage and thread; stages st + 1, st + 2 may stay in flight
+      // kGlds glds per stage and thread; stages st + 1, st + 2 may stay in flight
       const int64_t later = nstage - 1 - st;
       if (later >= 2) {
-        __builtin_amdgcn_s_waitcnt(0x0F76);  // vmcnt(6)
+        if constexpr (kGlds == 4) __builtin_amdgcn_s_waitcnt(0x0F78); else __builtin_amdgcn_s_waitcnt(0x0F76);  // vmcnt(8 | 6)
       } else if (later == 1) {
-        __builtin_amdgcn_s_waitcnt(0x0F73);  // vmcnt(3)
+        if constexpr (kGlds == 4) __builtin_amdgcn_s_waitcnt(0x0F74); else __builtin_amdgcn_s_waitcnt(0x0F73);  // vmcnt(4 | 3)
       } else {
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
       }
@@ -1360,62 +1366,55 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
       ol += stage_bytes_l;
       orr += stage_bytes_r;
       {
-        half8 ah[2], al[2], bh[2], bl[2];
+        half8 ah[2], al[2], bh[NBW], bl[NBW];
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
           ah[a] = *reinterpret_cast<const half8*>(&sm.u.st.a_hi[slot][lhi][wm * 64 + a * 32 + l31][0]);
           al[a] = *reinterpret_cast<const half8*>(&sm.u.st.a_lo[slot][lhi][wm * 64 + a * 32 + l31][0]);
         }
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          bh[b] = *reinterpret_cast<const half8*>(&sm.u.st.b_hi[slot][lhi][wn * 64 + b * 32 + l31][0]);
-          bl[b] = *reinterpret_cast<const half8*>(&sm.u.st.b_lo[slot][lhi][wn * 64 + b * 32 + l31][0]);
+        for (int b = 0; b < NBW; ++b) {
+          bh[b] = *reinterpret_cast<const half8*>(&sm.u.st.b_hi[slot][lhi][wn * (NBW * 32) + b * 32 + l31][0]);
+          bl[b] = *reinterpret_cast<const half8*>(&sm.u.st.b_lo[slot][lhi][wn * (NBW * 32) + b * 32 + l31][0]);
         }
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-          for (int b = 0; b < 2; ++b) {
+          for (int b = 0; b < NBW; ++b) {
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
           }
       }
-      constexpr int kFold = 2 * kGChunk;  // 16-row stages per sign chunk
-      if ((st % kFold) == kFold - 1 || st + 1 == nstage) {
-        const float sgn = ((st / kFold) & 1) ? -1.f : 1.f;  // odd chunks hold -L
+    }
+    // ---- epilogue, in passes of 128 columns (the S^T overlay holds one pass): the waves whose blocks lie in the pass
+    //      dump them, then thread = row i walks 64 of the pass's columns (as in k_rbf_mfma_grad) -------------------------
+#pragma unroll
+    for (int pass = 0; pass < TN / kGN; ++pass) {
+      __syncthreads();  // all waves are done with the ring (pass 0) / with the previous pass's S^T
+#pragma unroll
+      for (int b = 0; b < NBW; ++b) {
+        const int blk = wn * NBW + b;  // 32-column block of the tile
+        if (blk / 4 != pass) continue;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-          for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              master[a][b][r] = fmaf(sgn, acc[a][b][r], master[a][b][r]);
-              acc[a][b][r] = 0.f;
-            }
+          for (int g = 0; g < 4; ++g) {
+            float4 q;
+            q.x = acc[a][b][4 * g + 0]; q.y = acc[a][b][4 * g + 1]; q.z = acc[a][b][4 * g + 2]; q.w = acc[a][b][4 * g + 3];
+            *reinterpret_cast<float4*>(&sm.u.s_t[(blk & 3) * 32 + l31][wm * 64 + a * 32 + 8 * g + 4 * lhi]) = q;
+          }
       }
-    }
-    __syncthreads();  // all waves are done with the ring before the S^T overlay is written
-    // ---- epilogue (as in k_rbf_mfma_grad) -------------------------------------------------------
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float4 q;
-          q.x = master[a][b][4 * g + 0]; q.y = master[a][b][4 * g + 1]; q.z = master[a][b][4 * g + 2]; q.w = master[a][b][4 * g + 3];
-          *reinterpret_cast<float4*>(&sm.u.s_t[wn * 64 + b * 32 + l31][wm * 64 + a * 32 + 8 * g + 4 * lhi]) = q;
-        }
-    for (int t = tid; t < kGN * DPAD; t += 512) {
-      const int64_t g = j0 * DPAD + t;
-      (&sm.xj[0][0])[t] = g < n * DPAD ? xs[g] : 0.f;
-    }
-    if (tid < kGN) {
-      sm.sqj[tid] = (j0 + tid < n) ? sq[j0 + tid] : 0.f;
-      sm.sgj[tid] = grad_col_sign(j0 + tid, salt_r) ? -1.f : 1.f;
-    }
-    __syncthreads();
-    {
+      const int64_t jp = j0 + pass * kGN;
+      for (int t = tid; t < kGN * DPAD; t += 512) {
+        const int64_t g = jp * DPAD + t;
+        (&sm.xj[0][0])[t] = g < n * DPAD ? xs[g] : 0.f;
+      }
+      if (tid < kGN) {
+        sm.sqj[tid] = (jp + tid < n) ? sq[jp + tid] : 0.f;
+        sm.sgj[tid] = grad_col_sign(jp + tid, salt_r) ? -1.f : 1.f;
+      }
+      __syncthreads();
       const int il = tid & (kHM - 1), jh = (tid >> 8) * 64;
       const int64_t i = row0 + i0 + il;  // the point; L / the packs are indexed by the local row i0 + il
       const float sgi = grad_col_sign(i0 + il, salt_l) ? -1.f : 1.f;  // sigma_i: the accumulators hold sigma_i tau_j S_ij
@@ -1432,7 +1431,7 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
 #pragma unroll 2
       for (int jj = 0; jj < 64; ++jj) {
         const int jl = jh + jj;
-        const int64_t j = j0 + jl;
+        const int64_t j = jp + jl;
         float xjv[DPAD];
 #pragma unroll
         for (int c = 0; c < DPAD; c += 4) {
@@ -1487,11 +1486,39 @@ int64_t rbf_grad_h_ws_bytes(int64_t n, int64_t batch) {
   return 4 * bpad * npad * (int64_t)sizeof(_Float16) + 2 * bpad * (int64_t)sizeof(float) + 1024;
 }
 
+// column-tile width of the split gradient GEMM: 256 (NBW = 4) by default, MFX_GRAD_TILE=128 for the round-1 tile (A/B)
+static bool grad_wide_tile() {
+  static const int v = [] {
+    const char* e = getenv("MFX_GRAD_TILE");
+    return e ? atoi(e) : 256;
+  }();
+  return v != 128;
+}
+
+template <int DPAD, int NBW>
+static int launch_grad_h_t(const mfx_operator* op, const float* xs, const float* sq, int64_t n, int64_t npad_l, int64_t npad,
+                           const _Float16* Lh, const _Float16* Ll, const _Float16* Rh, const _Float16* Rl, int64_t bpad,
+                           uint32_t salt_l, uint32_t salt_r, double* partial, int64_t* nblocks_out, hipStream_t stream) {
+  constexpr int TN = GradSmemH<DPAD, NBW>::TN;
+  const int64_t row0 = op_row0(op), nrow = op_nrows(op);
+  const int64_t nti = (nrow + kHM - 1) / kHM, ntj = (n + TN - 1) / TN;
+  const int tiles_per_block = (int)((ntj + kGSplit * kGSub - 1) / (kGSplit * kGSub));
+  const dim3 grid(kGSplit, (unsigned)(nti * kGSub));
+  const size_t sh = sizeof(GradSmemH<DPAD, NBW>);
+  MFX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rbf_mfma_grad_h<DPAD, NBW>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+  k_rbf_mfma_grad_h<DPAD, NBW><<<grid, 512, sh, stream>>>(xs, sq, n, npad_l, npad, op->ard, op->kernel_fn, Lh, Ll, Rh, Rl, bpad / 8,
+                                                          tiles_per_block, salt_l, salt_r, partial, row0, nrow);
+  MFX_CHECK_LAUNCH();
+  *nblocks_out = nti * kGSub * kGSplit;
+  return MFX_OK;
+}
+
 template <int DPAD>
 static int launch_grad_h(const mfx_operator* op, const float* xs, const float* sq, const float* L, int64_t ldl,
                          const float* R, int64_t ldr, int64_t batch, int64_t inner, double* partial, int64_t* nblocks_out,
                          void* hws, hipStream_t stream) {
-  const int64_t n = op->n, row0 = op_row0(op), nrow = op_nrows(op);
+  const int64_t n = op->n, nrow = op_nrows(op);
   const int64_t npad = (n + kHM - 1) / kHM * kHM, npad_l = (nrow + kHM - 1) / kHM * kHM, bpad = (batch + 31) / 32 * 32;
   if (inner < 1 || batch % inner != 0) inner = 1;
   char* base = static_cast<char*>(hws);
@@ -1510,20 +1537,14 @@ static int launch_grad_h(const mfx_operator* op, const float* xs, const float* s
   const dim3 pgrid_l((unsigned)((npad_l + 255) / 256), (unsigned)(bpad / 8));
   static const bool signs = [] { const char* e = getenv("MFX_RBF_GRAD_SIGNS"); return e ? atoi(e) != 0 : true; }();
   const uint32_t salt_l = signs ? kSaltL : 0u, salt_r = signs ? kSaltR : 0u;
-  k_pack_f16<<<pgrid_l, 256, 0, stream>>>(L, ldl, batch, nrow, npad_l, scl, kGK * kGChunk, salt_l, inner, Lh, Ll);
-  k_pack_f16<<<pgrid, 256, 0, stream>>>(R, ldr, batch, n, npad, scl + 2, 0, salt_r, inner, Rh, Rl);
+  k_pack_f16<<<pgrid_l, 256, 0, stream>>>(L, ldl, batch, nrow, npad_l, scl, salt_l, inner, Lh, Ll);
+  k_pack_f16<<<pgrid, 256, 0, stream>>>(R, ldr, batch, n, npad, scl + 2, salt_r, inner, Rh, Rl);
   MFX_CHECK_LAUNCH();
-  const int64_t nti = (nrow + kHM - 1) / kHM, ntj = (n + kGN - 1) / kGN;
-  const int tiles_per_block = (int)((ntj + kGSplit * kGSub - 1) / (kGSplit * kGSub));
-  const dim3 grid(kGSplit, (unsigned)(nti * kGSub));
-  const size_t sh = sizeof(GradSmemH<DPAD>);
-  MFX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rbf_mfma_grad_h<DPAD>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-  k_rbf_mfma_grad_h<DPAD><<<grid, 512, sh, stream>>>(xs, sq, n, npad_l, npad, op->ard, op->kernel_fn, Lh, Ll, Rh, Rl, bpad / 8,
-                                                     tiles_per_block, salt_l, salt_r, partial, row0, nrow);
-  MFX_CHECK_LAUNCH();
-  *nblocks_out = nti * kGSub * kGSplit;
-  return MFX_OK;
+  if constexpr (DPAD <= 8) {  // (DPAD = 12, 16: the epilogue registers on top of 128 accumulators spill)
+    if (grad_wide_tile())
+      return launch_grad_h_t<DPAD, 4>(op, xs, sq, n, npad_l, npad, Lh, Ll, Rh, Rl, bpad, salt_l, salt_r, partial, nblocks_out, stream);
+  }
+  return launch_grad_h_t<DPAD, 2>(op, xs, sq, n, npad_l, npad, Lh, Ll, Rh, Rl, bpad, salt_l, salt_r, partial, nblocks_out, stream);
 }
 
 // returns the device pointer holding [sL, 1/sL, sR, 1/sR] through scales_out
