@@ -189,10 +189,13 @@ def main(argv=None):
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     if world > 1:
+        import datetime
+
+        limit = datetime.timedelta(seconds=600)  # a rank that dies must not leave the others waiting in a collective for long
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm; one rank per GPU
+            dist.init_process_group("nccl", device_id=dev, timeout=limit)  # nccl == RCCL on ROCm; one rank per GPU
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=limit)
 
     from matfree_extensions import _lib, hutchinson, lanczos
     from matfree_extensions.distributed import Layout, reduce_estimate, shard_probes

@@ -184,3 +184,30 @@ def test_c3_full_size_csr_tridiag_and_adjoint_against_the_oracle():
     assert np.allclose(dv.cpu().numpy(), dv_ref, rtol=1e-7, atol=1e-8 * np.abs(dv_ref).max())
     ref = dvals_ref[order.numpy()]
     assert np.allclose(dvals.cpu().numpy(), ref, rtol=1e-7, atol=1e-8 * np.abs(ref).max())
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# C5 at its stated size: wave system on a 1000 x 1000 grid (state 2e6), fp64, Arnoldi depth 30
+# ------------------------------------------------------------------------------------------------------------------------
+def test_c5_full_size_expm_arnoldi_against_the_taylor_series():
+    """exp(dt A) y0 through arnoldi.hessenberg (977 slices of the vector kernels, CSR operator with 6e6 stored values) + the dense
+    30 x 30 expm, against the Taylor series sum_m (dt A)^m y0 / m! evaluated with plain operator applications (dt |A| ~ 0.4: 16
+    terms reach 1e-15); plus linearity of the whole map."""
+    res, k, dt = 1000, 30, 1e-3
+    op, values_fn = pde_util.wave_operator(res, 1.0 / res, boundary="neumann", device=DEV)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    scale = (0.01 * torch.randn((res, res), dtype=torch.float64, device=DEV, generator=g)) ** 2 + 1e-6
+    vals = values_fn(scale)
+    y0 = torch.randn(2 * res * res, dtype=torch.float64, device=DEV, generator=g)
+    y1 = torch.randn(2 * res * res, dtype=torch.float64, device=DEV, generator=g)
+    expm = pde_util.expm_arnoldi(k)
+    with torch.no_grad():
+        out, _ = expm(op, dt, y0, vals)
+        term, series = y0.clone(), y0.clone()
+        for m in range(1, 17):
+            term = op(term, vals) * (dt / m)
+            series += term
+        assert float((out - series).norm() / series.norm()) < 1e-12
+        both, _ = expm(op, dt, 2.0 * y0 - 3.0 * y1, vals)
+        out1, _ = expm(op, dt, y1, vals)
+        assert float((both - (2.0 * out - 3.0 * out1)).norm() / both.norm()) < 1e-12
