@@ -277,3 +277,59 @@ def test_row_sharded_wave_expm_and_its_gradient_equal_the_single_process_result(
     got = torch.load(out)
     assert torch.allclose(got["y1"], y1.detach().cpu(), rtol=1e-10, atol=1e-12)
     assert torch.allclose(got["dscale"], sc.grad.cpu(), rtol=1e-8, atol=1e-10 * sc.grad.abs().max().item())
+
+
+# ---- the C4 shape on two row shards (both ranks on this one GPU) -----------------------------------------------------------------
+def _c4_worker(rank, world, port, out):
+    for p in (ROOT, os.path.join(ROOT, "experiments-lanczos-adjoints_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import datetime
+
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+    from matfree_extensions.distributed import slq_value_and_grad
+
+    op, params, n, k, p = _c4_problem()
+    mean, std, grads = slq_value_and_grad(op, torch.log, k, params, n=n, seed=5, num_probes=p, row_group_size=world,
+                                          dtype=torch.float32, device=_dev())
+    torch.cuda.synchronize()
+    if rank == world - 1:
+        torch.save({"mean": mean.cpu(), "grads": [g.cpu() for g in grads]}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _c4_problem():
+    from matfree_extensions.util import gp_util
+
+    n, d, k, p = 131072, 8, 10, 8
+    gen = torch.Generator().manual_seed(4)
+    X = torch.randn((n, d), generator=gen, dtype=torch.float32).to(_dev())
+    inv = lambda v: float(np.log(np.expm1(v)))  # noqa: E731
+    params = [torch.tensor(inv(v), dtype=torch.float32, device=_dev(), requires_grad=True) for v in (2.0, 1.0, 0.1)]
+    return gp_util.gram_operator(X, precision="f16x3"), params, n, k, p
+
+
+def test_c4_shape_on_two_row_shards_equals_the_single_process_estimate(tmp_path):
+    """n = 131072, d = 8 (config 4's operator; k = 10, 8 probes to keep it short): the matrix-core Gram kernels on a 65536-row
+    block with its own column splits, the 256 x 256 gradient tile on a row block, 32-bit staging offsets at the full column count."""
+    import torch.multiprocessing as mp
+
+    from matfree_extensions.distributed import slq_value_and_grad
+
+    op, params, n, k, p = _c4_problem()
+    mean, _std, grads = slq_value_and_grad(op, torch.log, k, params, n=n, seed=5, num_probes=p, dtype=torch.float32, device=_dev())
+    del op
+    torch.cuda.empty_cache()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "c4.pt")
+    mp.spawn(_c4_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    assert np.isclose(got["mean"].item(), mean.item(), rtol=2e-5)
+    for a, b in zip(got["grads"], grads):
+        assert torch.allclose(a, b.cpu(), rtol=5e-4, atol=5e-4 * b.abs().max().item()), (a, b)
