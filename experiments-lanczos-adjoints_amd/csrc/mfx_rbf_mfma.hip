@@ -294,6 +294,17 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply(const float* __restri
 // at the same tolerances as the fp32-exact path (tests/test_gpu_parity.py).
 // ================================================================================================
 constexpr float kKShift = 15.f;
+// Chains of the pipelined matvec.  The f16 MFMA aligns what it adds to the accumulator with a few guard bits and truncates
+// (tools/mfma_f16_trunc.hip): harmless for sign-mixed sums, but Krylov vectors are dominated by the smooth leading eigenvectors
+// of an all-positive kernel matrix -- the accumulator of a row then grows monotonically over its 24576 MFMAs and the loss grows
+// with the size of the accumulator relative to the products (-8.7e-5 relative on a constant vector at n = 131072; the SLQ
+// gradient was 4.4e-4 off; tools/diag_matvec_bias.py).  What helps is a SMALL accumulator: every kChainTiles tiles the
+// accumulators are folded (fp32 VALU adds, round to nearest) into master accumulators and restart from zero.  The masters of
+// all but one 32 x 32 block live in LDS (lane-private slots: no barrier, no bank conflict), the last block's in 16 of the
+// spare registers: no partial sums through HBM.  (Round 2 first cut the sweep into 16 column splits with partial sums in HBM:
+// same accuracy, +7.6 % per matvec and 1.1 GB of extra traffic per launch; negating the accumulators in registers instead of
+// restarting them did nothing.)
+constexpr int kChainTiles = 128;
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));  // 16-B pack as a native vector (HIP's uint4 struct went to scratch)
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -442,10 +453,15 @@ __global__ __launch_bounds__(64 * H3Waves<PK>::value, PK ? 1 : 2) void k_rbf_mfm
   using Tile = RbfTileH3<DPAD, NB, kTJ, !PK>;
   constexpr int KD = Tile::KD, KS = KD / 2, NKD = Tile::NKD;
   constexpr float cfac = KIND == MFX_KERNEL_RBF ? kNegHalfLog2e : (KIND == MFX_KERNEL_MATERN32 ? 3.f : 1.f) * kLog2e * kLog2e;
-  __shared__ __attribute__((aligned(16))) Tile tile[2];
+  extern __shared__ __attribute__((aligned(16))) char h3_smem[];
+  Tile* const tile = reinterpret_cast<Tile*>(h3_smem);  // [2]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
   constexpr int WV = H3Waves<PK>::value;
+  // master accumulators of the chain folds (PK variant): blocks 0 .. kMI NB - 2 in LDS behind the tiles, the last one in registers
+  constexpr int kBlocks = kMI * NB;
+  float* const master = reinterpret_cast<float*>(h3_smem + 2 * sizeof(Tile)) + ((size_t)wid * (kBlocks - 1) * 16) * 64 + lane;
+  float mreg[16];
   const int64_t i_wave = row0 + (int64_t)blockIdx.x * (WV * kMI * 32) + (int64_t)wid * (kMI * 32);
   const int64_t b0 = (int64_t)blockIdx.y * (NB * 32);
 
@@ -489,6 +505,30 @@ __global__ __launch_bounds__(64 * H3Waves<PK>::value, PK ? 1 : 2) void k_rbf_mfm
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][nb][r] = 0.f;
+  if constexpr (PK) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mreg[r] = 0.f;
+#pragma unroll
+    for (int q = 0; q < (kBlocks - 1) * 16; ++q) master[q * 64] = 0.f;
+  }
+  auto fold_chain = [&]() {  // masters += accumulators; accumulators restart from zero
+#pragma unroll
+    for (int mi = 0; mi < kMI; ++mi)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int idx = mi * NB + nb;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (idx < kBlocks - 1) {
+            float* m = master + (idx * 16 + r) * 64;
+            *m += acc[mi][nb][r];
+          } else {
+            mreg[r] += acc[mi][nb][r];
+          }
+          acc[mi][nb][r] = 0.f;
+        }
+      }
+  };
 
   // ---- PK: both LDS images come PRE-PACKED from k_pack_tiles (once per matvec instead of once per workgroup and tile: the
   //      hi/lo split of the probe tile was 40 of the ~93 VALU instructions per 32x32 block, and VALU time adds to MFMA time).
@@ -528,7 +568,7 @@ __global__ __launch_bounds__(64 * H3Waves<PK>::value, PK ? 1 : 2) void k_rbf_mfm
   for (int u = 0; u < kVPT; ++u) {
     const int f = tid + 256 * u;
     const int64_t b = b0 + f / (kTJ / 4);
-    vs[u] = (f < kF4 && b < p) ? ((blockIdx.z & 1) ? -vscale[2 * b] : vscale[2 * b]) : 0.f;  // odd column splits: negated tile
+    vs[u] = (f < kF4 && b < p) ? vscale[2 * b] : 0.f;
   }
 
   auto load_tile = [&](int64_t j0) {
@@ -661,6 +701,9 @@ __global__ __launch_bounds__(64 * H3Waves<PK>::value, PK ? 1 : 2) void k_rbf_mfm
   __syncthreads();
   for (int64_t t = t_first; t < ntile; ++t) {
     const Tile& tl = tile[t & 1];
+    if constexpr (PK) {
+      if (t > t_first && ((t - t_first) % kChainTiles) == 0) fold_chain();
+    }
     if (t + 1 < ntile) {
       // (PK) the other buffer was last read during tile t - 1, and every wave has passed the barrier that ended it
       if constexpr (PK) issue_tile_dma(t + 1, tile[(t + 1) & 1]); else load_tile((t + 1) * kTJ);
@@ -863,6 +906,16 @@ __global__ __launch_bounds__(64 * H3Waves<PK>::value, PK ? 1 : 2) void k_rbf_mfm
     }
     __syncthreads();  // (also drains the LDS-DMA: vmcnt(0))
   }
+  if constexpr (PK) {
+#pragma unroll
+    for (int mi = 0; mi < kMI; ++mi)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int idx = mi * NB + nb;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][nb][r] += idx < kBlocks - 1 ? master[(idx * 16 + r) * 64] : mreg[r];
+      }
+  }
   const float s = outputscale[0], nz = gridDim.z > 1 ? 0.f : noise[0];
   float* yout = gridDim.z > 1 ? part + (int64_t)blockIdx.z * p * ldpart : y;
   const int64_t ldo = gridDim.z > 1 ? ldpart : ldy;
@@ -901,11 +954,7 @@ __global__ __launch_bounds__(256) void k_split_reduce(const float* __restrict__ 
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;  // local row: the point is row0 + i
   if (i >= nrow) return;
   float acc = 0.f;
-  for (int z = 0; z < nsplit; z += 2) {  // odd splits hold the negated partial sum
-    const float pe = part[((int64_t)z * p + b) * ldpart + i];
-    const float po = z + 1 < nsplit ? part[((int64_t)(z + 1) * p + b) * ldpart + i] : 0.f;
-    acc += pe - po;
-  }
+  for (int z = 0; z < nsplit; ++z) acc += part[((int64_t)z * p + b) * ldpart + i];
   y[b * ldy + i] = fmaf(noise[0], x[b * ldx + row0 + i], acc);
 }
 
@@ -916,19 +965,11 @@ __global__ __launch_bounds__(256) void k_split_reduce(const float* __restrict__ 
 //   column operand pka[tile][j][AROW] : [Ah | Ah | Al | 0] of c [-2 x_j, |x_j|^2 (+ shift or eps), 1], odd 32-column block negated
 // grid (ntile, chunks + 1): blockIdx.y < chunks packs that probe chunk, the last one the column operand.
 // ------------------------------------------------------------------------------------------------
-// column split z owns the tiles [ntile z / nsplit, ntile (z + 1) / nsplit): the split of tile t
-__device__ __forceinline__ int split_of_tile(int64_t t, int64_t ntile, int nsplit) {
-  int z = (int)((t * nsplit) / ntile);
-  while (z + 1 < nsplit && ntile * (z + 1) / nsplit <= t) ++z;
-  while (z > 0 && ntile * z / nsplit > t) --z;
-  return z;
-}
-
 template <int DPAD, int NB, int KIND>
 __global__ __launch_bounds__(256) void k_pack_tiles(const float* __restrict__ xs, const float* __restrict__ sq, int64_t n,
                                                     const float* __restrict__ vscale, const float* __restrict__ x,
                                                     int64_t ldx, int64_t p, uintx4* __restrict__ pkv,
-                                                    uintx4* __restrict__ pka, int* __restrict__ rangeflag, int nsplit) {
+                                                    uintx4* __restrict__ pka, int* __restrict__ rangeflag) {
   constexpr int kTJ = 64;
   using Tile = RbfTileH3<DPAD, NB, kTJ>;
   constexpr int KD = Tile::KD, P = Tile::P, AROW = Tile::AROW;
@@ -946,8 +987,7 @@ __global__ __launch_bounds__(256) void k_pack_tiles(const float* __restrict__ xs
       const int jb = row >> 2, s = (row >> 1) & 1, h = row & 1;
       const int64_t b = b0 + bq;
       half8 hh, ll;
-      // odd column splits sweep the NEGATED probe tile (see the sign note at rbf_split_count)
-      const float vs = b < p ? ((split_of_tile(t, ntile, nsplit) & 1) ? -vscale[2 * b] : vscale[2 * b]) : 0.f;
+      const float vs = b < p ? vscale[2 * b] : 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int64_t j = j0 + 32 * jb + 16 * s + 8 * (e >> 2) + 4 * h + (e & 3);
@@ -985,20 +1025,12 @@ __global__ __launch_bounds__(256) void k_pack_tiles(const float* __restrict__ xs
   }
 }
 
-// column splits of the pipelined matvec.  Two reasons to split the sweep over the n columns (grid.z):
-//  (1) occupancy: too few 512-row workgroups to fill 256 CUs (small n, or a row shard of a large n);
-//  (2) accuracy: the f16 MFMA aligns its addends with a few guard bits and truncates towards -infinity, so an accumulator that
-//      grows monotonically -- Krylov vectors are dominated by the smooth leading eigenvectors of an all-positive kernel matrix --
-//      picks up a bias proportional to the length of its MFMA chain (tools/diag_matvec_bias.py, tools/mfma_f16_trunc.hip:
-//      -8.7e-5 relative for a constant vector over 2048 tiles at n = 131072; the SLQ gradient at that size was 4.4e-4 off).
-//      Chains are therefore cut to <= kMaxChainTiles tiles, and ODD splits sweep the NEGATED probe tile: their partial sums carry
-//      the floor bias with the opposite sign and k_split_reduce subtracts them, so the biases of neighbouring splits cancel.
-constexpr int kMaxChainTiles = 128;
+// column splits of the pipelined matvec (grid.z), for OCCUPANCY: too few 512-row workgroups to fill 256 CUs (small n, or a row
+// shard of a large n).  512-row workgroups of 8 waves, one per CU and round: with s column splits the launch takes
+// ceil(wgs s / 256) rounds of 1/s of the columns each; pick the s (at most 16, at least 8 tiles per split) that minimises
+// rounds / s, plus a small charge per split for the prologue and the partial sums.  (n = 45 730: 90 row blocks -> s = 8, 720
+// workgroups in 3 rounds = 0.375 of an unsplit launch, where "fill one round" (s = 2) gives 0.5.)
 static int rbf_split_count(int64_t nrow, int64_t n, int64_t p) {
-  // 512-row workgroups of 8 waves, one per CU and round.  With s column splits the launch takes ceil(wgs s / 256) rounds of 1/s of the
-  // columns each: pick the s (at most 16, at least 8 tiles per split) that minimises rounds / s, plus a small charge per split for the
-  // prologue and the partial sums.  (n = 45 730: 90 row blocks -> s = 8, 720 workgroups in 3 rounds = 0.375 of an unsplit launch,
-  // where "fill one round" (s = 2) gives 0.5.)
   static const int forced = [] {
     const char* e = getenv("MFX_RBF_SPLIT");  // A/B: force the split count
     return e ? atoi(e) : 0;
@@ -1008,22 +1040,17 @@ static int rbf_split_count(int64_t nrow, int64_t n, int64_t p) {
   int64_t smax = ntile / 8;
   if (forced > 0) return forced <= 16 && forced <= ntile ? forced : 1;
   if (smax > 16) smax = 16;
-  if (smax < 1) return 1;
+  if (smax < 1 || wgs >= 2048) return 1;
   int best = 1;
-  if (wgs < 2048) {
-    double best_cost = 1e30;
-    for (int s = 1; s <= (int)smax; ++s) {
-      const double rounds = (double)((wgs * s + 255) / 256);
-      const double cost = rounds / s + 0.004 * s;
-      if (cost < best_cost - 1e-12) {
-        best_cost = cost;
-        best = s;
-      }
+  double best_cost = 1e30;
+  for (int s = 1; s <= (int)smax; ++s) {
+    const double rounds = (double)((wgs * s + 255) / 256);
+    const double cost = rounds / s + 0.004 * s;
+    if (cost < best_cost - 1e-12) {
+      best_cost = cost;
+      best = s;
     }
   }
-  const int64_t s_acc = (ntile + kMaxChainTiles - 1) / kMaxChainTiles;  // reason (2)
-  if (best < s_acc) best = (int)(s_acc < smax ? s_acc : smax);
-  if (best > 1 && (best & 1) && best < smax) ++best;  // pairs of (+, -) splits
   return best;
 }
 
@@ -1086,17 +1113,24 @@ static int launch_apply_h3k(const mfx_operator* op, const float* xs, const float
   if (pack) {
     pkv = static_cast<uintx4*>(pk);
     pka = reinterpret_cast<uintx4*>(static_cast<char*>(pk) + off_a);
-    k_pack_tiles<DPAD, NB, KIND><<<dim3((unsigned)ntile, chunks + 1), 256, 0, stream>>>(xs, sq, n, vscale, x, ldx, p, pkv, pka, rangeflag, nsplit);
+    k_pack_tiles<DPAD, NB, KIND><<<dim3((unsigned)ntile, chunks + 1), 256, 0, stream>>>(xs, sq, n, vscale, x, ldx, p, pkv, pka, rangeflag);
     MFX_CHECK_LAUNCH();
   }
+  // LDS: the two tile buffers + (pre-packed variant) the chain masters of 8 waves x (2 NB - 1) blocks x 16 registers x 64 lanes
 #define MFX_H3_LAUNCH(V4, DHV, PKV, FLAG)                                                                            \
-  k_rbf_mfma_apply_h3<DPAD, NB, V4, KIND, DHV, PKV><<<(PKV) ? grid_pk : grid3, 64 * H3Waves<PKV>::value, 0, stream>>>(xs, sq, n, (const float*)op->outputscale, \
-                                                                                (const float*)op->noise, vscale, x, ldx, y, ldy, p, pkv, pka, part, FLAG, ldpart, row0, rend)
+  {                                                                                                                  \
+    constexpr size_t kSm = 2 * sizeof(RbfTileH3<DPAD, NB, 64, !(PKV)>) + ((PKV) ? (size_t)8 * (2 * NB - 1) * 16 * 64 * 4 : 0); \
+    if (kSm > 64 * 1024)                                                                                             \
+      MFX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rbf_mfma_apply_h3<DPAD, NB, V4, KIND, DHV, PKV>), \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSm));                       \
+    k_rbf_mfma_apply_h3<DPAD, NB, V4, KIND, DHV, PKV><<<(PKV) ? grid_pk : grid3, 64 * H3Waves<PKV>::value, kSm, stream>>>( \
+        xs, sq, n, (const float*)op->outputscale, (const float*)op->noise, vscale, x, ldx, y, ldy, p, pkv, pka, part, FLAG, ldpart, row0, rend); \
+  }
   if (pack) {
-    if (vec4) MFX_H3_LAUNCH(true, true, true, rangeflag); else MFX_H3_LAUNCH(false, true, true, rangeflag);
-    if (vec4) MFX_H3_LAUNCH(true, false, false, rangeflag); else MFX_H3_LAUNCH(false, false, false, rangeflag);  // runs only if flagged
+    if (vec4) MFX_H3_LAUNCH(true, true, true, rangeflag) else MFX_H3_LAUNCH(false, true, true, rangeflag)
+    if (vec4) MFX_H3_LAUNCH(true, false, false, rangeflag) else MFX_H3_LAUNCH(false, false, false, rangeflag)  // runs only if flagged
   } else {  // MFX_RBF_DIST=0 / MFX_RBF_PACK=0 (or no pack workspace): fp32-MFMA distances, in-kernel split of the probe tiles
-    if (vec4) MFX_H3_LAUNCH(true, false, false, nullptr); else MFX_H3_LAUNCH(false, false, false, nullptr);
+    if (vec4) MFX_H3_LAUNCH(true, false, false, nullptr) else MFX_H3_LAUNCH(false, false, false, nullptr)
   }
 #undef MFX_H3_LAUNCH
   MFX_CHECK_LAUNCH();
