@@ -329,15 +329,6 @@ __global__ __launch_bounds__(kBlock) void k_lz_adj_dvec(const T* __restrict__ x0
 }
 
 
-// mfx_fused.hip: the k-loops as one cooperative kernel (dense / CSR operators, co-resident grids); 1 = done, 0 = not applicable
-template <typename T>
-int arnoldi_forward_fused(const mfx_operator* op, const T* v0, int64_t n, int64_t k, int64_t p, int second_pass, T* Q, T* H,
-                          T* r, T* cinv, T* xbuf, T* P1, T* P2, T* PN, int vec, hipStream_t stream);
-template <typename T>
-int arnoldi_adjoint_fused(const mfx_operator* op, int64_t n, int64_t k, int64_t p, const T* Q, const T* H, const T* r,
-                          const T* cinv, const T* dQ, const T* dH, const T* pig, const T* eta, int reortho, T* lam0, T* Lam,
-                          T* Gam, T* dv, T* P1, T* P2, int vec, hipStream_t stream);
-
 struct KrylovWs {
   void *w, *p1, *p2, *pn, *small, *opws;
   int64_t opws_bytes;
@@ -438,12 +429,6 @@ static int arnoldi_forward_t(const mfx_operator* op, const T* v0, int64_t n, int
   T* P2 = static_cast<T*>(ws.p2);
   T* PN = static_cast<T*>(ws.pn);
   const int64_t ldq = k * n;
-  if (!comm) {  // launch-bound shapes: the whole loop as one cooperative kernel
-    ScopedTimer t(2, stream);
-    const int rc = arnoldi_forward_fused<T>(op, v0, n, k, p, second_pass, Q, H, r, cinv, static_cast<T*>(ws.w), P1, P2, PN, c.vec, stream);
-    if (rc < 0) return rc;
-    if (rc == 1) return MFX_OK;
-  }
   MFX_CHECK_HIP(hipMemsetAsync(H, 0, sizeof(T) * p * k * k, stream));
   {
     ScopedTimer t(2, stream);
@@ -518,15 +503,7 @@ static int arnoldi_adjoint_t(const mfx_operator* op, int64_t n, int64_t k, int64
     a.x = dr; a.ldx = n; a.y = lam; a.ldy = n;
     MFX_TRY(launch_update<T>(c, a, false, false));
   }
-  bool fused = false;
-  if (!comm) {
-    ScopedTimer t(2, stream);
-    const int rc = arnoldi_adjoint_fused<T>(op, n, k, p, Q, H, r, cinv, dQ, dH, pig, eta, reortho, lam, Lam, Gam, dv, P1,
-                                            static_cast<T*>(ws.p2), c.vec, stream);
-    if (rc < 0) return rc;
-    fused = rc == 1;
-  }
-  for (int64_t idx = fused ? -1 : k - 1; idx >= 0; --idx) {
+  for (int64_t idx = k - 1; idx >= 0; --idx) {
     T* lam_idx = Lam + idx * n;  // Lambda[:, idx] (arnoldi.py:216), leading dimension ldq
     {
       ScopedTimer t(2, stream);
@@ -557,7 +534,7 @@ static int arnoldi_adjoint_t(const mfx_operator* op, int64_t n, int64_t k, int64
     MFX_VEC_EPT_SWITCH(c, (k_adj_combine<T, VEC, EPT><<<c.grid(), c.wg, sh, stream>>>(ca)));
     MFX_CHECK_LAUNCH();
   }
-  if (!fused) {
+  {
     ScopedTimer t(2, stream);
     MFX_TRY(launch_scale<T>(c, lam, n, dv, n, nullptr, cinv, 1, nullptr, 0, nullptr));  // dv = lambda c
   }

@@ -164,7 +164,7 @@ def test_pde_wave_reference_targets_through_expm_arnoldi(dtype, tol):
 # ------------------------------------------------------------------------------------------------------------------------
 def test_c3_full_size_csr_tridiag_and_adjoint_against_the_oracle():
     """50 slices x 1 vector, forward and adjoint with cotangents on every output and the gradient w.r.t. ALL stored values
-    (benchmark.py:57-121); with MFX_FUSED=1 in the environment this runs the cooperative kernels of csrc/mfx_fused.hip."""
+    (benchmark.py:57-121)."""
     r, c, vals, n = orc.laplacian_2d_plus_identity(320)
     k = 50
     rng = np.random.default_rng(3)
