@@ -41,13 +41,15 @@ __global__ void k_adj_setup(const T* __restrict__ H, const T* __restrict__ dH, c
 }
 
 // Pi_gamma[b][col][j] -= (dQ[:,col] . Q[:,j])  from dots partials   (arnoldi.py:128, "- dQ.T @ Q")
+// grid (p, cols of this batch): column col0 + blockIdx.y from the partials at partial + blockIdx.y * part_zstride
 template <typename T>
-__global__ void k_pig_sub(T* __restrict__ pig, int k, int col, const T* __restrict__ partial, int kmax,
-                          int nblk) {
-  const int b = blockIdx.x;
+__global__ void k_pig_sub(T* __restrict__ pig, int k, int col0, const T* __restrict__ partial, int kmax,
+                          int nblk, int64_t part_zstride) {
+  const int b = blockIdx.x, col = col0 + (int)blockIdx.y;
+  const T* part = partial + (int64_t)blockIdx.y * part_zstride;
   for (int idx = threadIdx.x; idx < k * kRedG; idx += blockDim.x) {
     const int j = idx / kRedG, g = idx % kRedG;
-    const T v = reduce_partials_group<T, kRedG>(partial + ((int64_t)b * kmax + j) * nblk, nblk, g);
+    const T v = reduce_partials_group<T, kRedG>(part + ((int64_t)b * kmax + j) * nblk, nblk, g);
     if (g == 0) pig[((int64_t)b * k + col) * k + j] -= v;
   }
 }
@@ -117,45 +119,17 @@ __global__ __launch_bounds__(kBlock) void k_adj_combine(CombineArgs<T> a) {
 #pragma unroll
     for (int e = 0; e < EPT; ++e) acc[e] += t[e];
   }
-  constexpr int JT = EPT <= 4 ? 8 : 4;  // rows in flight per thread
-  {
-    int j = 0;
-    for (; j + JT <= k; j += JT) {
-      T rr[JT][EPT];
+  constexpr int JT = RowsInFlight<EPT>::value;
+  sweep_rows<T, VEC, EPT, JT>(Qb, n, 0, k, slice0, n, tid, [&](int j, const T (&row)[EPT]) {
+    const T gj = g[j];
 #pragma unroll
-      for (int q = 0; q < JT; ++q) load_own<T, VEC>(rr[q], Qb + (int64_t)(j + q) * n, slice0, n, tid);
+    for (int e = 0; e < EPT; ++e) acc[e] += gj * row[e];
+  });
+  sweep_rows<T, VEC, EPT, JT>(Lb, n, idx + 1, k, slice0, n, tid, [&](int j, const T (&row)[EPT]) {
+    const T hj = hp[j];
 #pragma unroll
-      for (int q = 0; q < JT; ++q) {
-        const T gj = g[j + q];
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) acc[e] += gj * rr[q][e];
-      }
-    }
-    for (; j < k; ++j) {
-      load_own<T, VEC>(t, Qb + (int64_t)j * n, slice0, n, tid);
-      const T gj = g[j];
-#pragma unroll
-      for (int e = 0; e < EPT; ++e) acc[e] += gj * t[e];
-    }
-    j = idx + 1;
-    for (; j + JT <= k; j += JT) {
-      T rr[JT][EPT];
-#pragma unroll
-      for (int q = 0; q < JT; ++q) load_own<T, VEC>(rr[q], Lb + (int64_t)(j + q) * n, slice0, n, tid);
-#pragma unroll
-      for (int q = 0; q < JT; ++q) {
-        const T hj = hp[j + q];
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) acc[e] -= hj * rr[q][e];
-      }
-    }
-    for (; j < k; ++j) {
-      load_own<T, VEC>(t, Lb + (int64_t)j * n, slice0, n, tid);
-      const T hj = hp[j];
-#pragma unroll
-      for (int e = 0; e < EPT; ++e) acc[e] -= hj * t[e];
-    }
-  }
+    for (int e = 0; e < EPT; ++e) acc[e] -= hj * row[e];
+  });
   const T inv = T(1) / bminus;
 #pragma unroll
   for (int e = 0; e < EPT; ++e) acc[e] *= inv;
@@ -331,10 +305,20 @@ __global__ __launch_bounds__(kBlock) void k_lz_adj_dvec(const T* __restrict__ x0
 
 struct KrylovWs {
   void *w, *p1, *p2, *pn, *small, *opws;
+  void* pb;  // partials of a batch of dQ columns (adjoint, few-slice problems), null when the columns go one by one
   int64_t opws_bytes;
   // row-sharded drivers only
   void *stage, *send, *gathered, *xfull;
 };
+
+// Columns of dQ projected onto the basis per launch (arnoldi.py:128, dQ^T Q): one when a single column already fills the
+// chip, up to k when there are few slices (one vector, n ~ 1e5: k launches of 50 workgroups were 1 ms of config 3's adjoint).
+static int64_t dq_batch_cols(int64_t n, int64_t k, int64_t p, const mfx_comm* comm) {
+  if (comm) return 1;
+  const int64_t wgs = num_slices(n) * p;
+  const int64_t cb = 1024 / (wgs > 0 ? wgs : 1);
+  return cb < 1 ? 1 : (cb > k ? k : cb);
+}
 
 // n = length of the vectors this process holds (the operator size, or the rows of its shard: comm != NULL)
 static int64_t carve_ws(const mfx_operator* op, int64_t n, int64_t k, int64_t p, void* ws, int64_t ws_bytes,
@@ -351,6 +335,8 @@ static int64_t carve_ws(const mfx_operator* op, int64_t n, int64_t k, int64_t p,
   r.small = cv.take((2 * p * k * k + 4 * p * k + 8 * p) * es);  // Gamma, Pi_gamma, eta, coefficients
   r.opws_bytes = op_workspace_bytes(op, p * (k + 1), p);  // the deferred gradient sweep batches all (probe, step) pairs
   r.opws = cv.take(r.opws_bytes);
+  const int64_t cb = dq_batch_cols(n, k, p, comm);
+  r.pb = cb > 1 ? cv.take(cb * p * kmax * nblk * es) : nullptr;
   if (comm) {
     r.stage = cv.take(p * kmax * nblk * es);                 // producers' per-slice partials before the all-reduce
     r.send = cv.take(p * comm->nloc * es);                   // this rank's (p, nloc) iterate, zero padded
@@ -490,9 +476,13 @@ static int arnoldi_adjoint_t(const mfx_operator* op, int64_t n, int64_t k, int64
     k_adj_setup<T><<<(unsigned)p, 256, 0, stream>>>(H, dH, cinv, dc, dr ? P1 : nullptr, c.kmax, c.nblk_in, (int)k, eta, pig);
     MFX_CHECK_LAUNCH();
     if (dQ) {
-      for (int64_t col = 0; col < k; ++col) {
-        MFX_TRY(launch_dots<T>(c, Q, ldq, n, (int)k, dQ + col * n, ldq, P1));
-        k_pig_sub<T><<<(unsigned)p, 512, 0, stream>>>(pig, (int)k, (int)col, P1, c.kmax, c.nblk_in);  // latency-bound: 8 lanes per coefficient
+      const int64_t cb = ws.pb ? dq_batch_cols(n, k, p, comm) : 1;
+      T* PB = ws.pb ? static_cast<T*>(ws.pb) : P1;
+      const int64_t pstride = p * (int64_t)c.kmax * c.nblk;
+      for (int64_t col = 0; col < k; col += cb) {
+        const int nc = (int)(col + cb <= k ? cb : k - col);
+        MFX_TRY(launch_dots<T>(c, Q, ldq, n, (int)k, dQ + col * n, ldq, PB, nc, n, pstride));
+        k_pig_sub<T><<<dim3((unsigned)p, (unsigned)nc), 512, 0, stream>>>(pig, (int)k, (int)col, PB, c.kmax, c.nblk_in, pstride);  // latency-bound: 8 lanes per coefficient
         MFX_CHECK_LAUNCH();
       }
     }

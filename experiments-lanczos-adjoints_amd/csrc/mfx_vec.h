@@ -61,60 +61,134 @@ __device__ __forceinline__ T reduce_partials(const T* __restrict__ part, int nbl
 template <typename T, int G>
 __device__ __forceinline__ T reduce_partials_group(const T* __restrict__ part, int nblk, int g) {
   double acc = 0.0;
-  for (int q = g; q < nblk; q += G) acc += (double)part[q];
+  constexpr int U = 8;  // loads in flight per lane: the prologues are a chain of L2 round trips otherwise
+  for (int q0 = g; q0 < nblk; q0 += U * G) {
+    T v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = (q0 + u * G < nblk) ? part[q0 + u * G] : T(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc += (double)v[u];  // same order as a plain lane-strided loop
+  }
 #pragma unroll
   for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, G);
   return (T)acc;
 }
 constexpr int kRedG = 8;  // lanes per coefficient in the multi-coefficient prologues
 
+// Rows j0 <= j < j1 of a (rows, n) panel, this thread's elements of the slice, in order, f(j, row[EPT]) per row --
+// double-buffered: the loads of the next JT rows are issued before the current JT are consumed, so a sweep is
+// ceil(rows / JT) overlapped round trips instead of that many serial ones (what bounds these kernels when there
+// are few workgroups: one vector, n ~ 1e5).  Every load is issued on every path -- rows past the end re-read the
+// last row, lanes past n re-read element 0 and are zeroed by a select -- because a load under a branch or an exec
+// mask makes the compiler fall back to s_waitcnt vmcnt(0), which serialises the two buffers again.
+template <typename T, int VEC, int EPT, int JT, typename F>
+__device__ __forceinline__ void sweep_rows(const T* __restrict__ rb, int64_t row_stride, int j0, int j1,
+                                           int64_t slice0, int64_t n, int tid, F&& f) {
+  if (j0 >= j1) return;
+  constexpr int U = EPT / VEC;
+  int64_t off[U];
+  bool ok[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t o = slice0 + (int64_t)(u * (int)blockDim.x + tid) * VEC;
+    ok[u] = o < n;
+    off[u] = ok[u] ? o : 0;
+  }
+  auto load = [&](T (&dst)[JT][EPT], int j) {
+#pragma unroll
+    for (int q = 0; q < JT; ++q) {
+      const int jj = (j + q < j1) ? j + q : j1 - 1;
+      const T* row = rb + (int64_t)jj * row_stride;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        Pack<T, VEC> pk = load_pack<T, VEC>(row + off[u]);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) dst[q][u * VEC + e] = pk.v[e];
+      }
+    }
+  };
+  auto use = [&](T (&src)[JT][EPT], int j) {
+#pragma unroll
+    for (int q = 0; q < JT; ++q)
+      if (j + q < j1) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) src[q][u * VEC + e] = ok[u] ? src[q][u * VEC + e] : T(0);
+        f(j + q, src[q]);
+      }
+  };
+  T ra[JT][EPT];
+  if (j1 - j0 <= JT) {
+    load(ra, j0);
+    use(ra, j0);
+    return;
+  }
+  T rc[JT][EPT];
+  int j = j0;
+  load(ra, j);
+  for (;;) {
+    load(rc, j + JT);
+    use(ra, j);
+    j += JT;
+    if (j >= j1) break;
+    load(ra, j + JT);
+    use(rc, j);
+    j += JT;
+    if (j >= j1) break;
+  }
+}
+template <int EPT>
+struct RowsInFlight {
+  static constexpr int value = EPT <= 4 ? 16 : 4;  // per buffer; two buffers in flight
+};
+
 // ------------------------------------------------------------------------------------------------
 // K-dots: partial[b][j][blk] = sum_{i in slice} rows[b][j][i] * x[b][i],  j < m
 //   forward  h = Q^T w            (arnoldi.py:87)      adjoint  P lam, z^T Q   (arnoldi.py:204,212)
 // ------------------------------------------------------------------------------------------------
-template <typename T, int VEC, int EPT>
+template <typename T, int VEC, int EPT, int CT>
 __global__ __launch_bounds__(kBlock) void k_dots(const T* __restrict__ rows, int64_t rows_ldb,
                                                  int64_t row_stride, int m,
                                                  const T* __restrict__ x, int64_t ldx, int64_t n,
-                                                 T* __restrict__ partial, int kmax, int nblk) {
+                                                 T* __restrict__ partial, int kmax, int nblk,
+                                                 int jchunk, int ngroups, int ncols, int64_t x_zstride,
+                                                 int64_t part_zstride) {
+  // blockIdx.z = ctile * ngroups + group: `group` owns rows [group * jchunk, +jchunk) (more workgroups, shorter sweeps when
+  // there are few slices); `ctile` selects CT of the ncols right-hand vectors x + col * x_zstride of the same probe (the
+  // dQ^T Q projection of the adjoint: every row that is loaded meets CT vectors), partials at partial + col * part_zstride.
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  T* sm = reinterpret_cast<T*>(smem_raw);  // [4][m]
+  T* sm = reinterpret_cast<T*>(smem_raw);  // [4][CT][jchunk]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int b = blockIdx.y, blk = blockIdx.x;
+  const int col0 = ((int)blockIdx.z / ngroups) * CT, grp = (int)blockIdx.z % ngroups;
+  const int j0 = grp * jchunk, j1 = (j0 + jchunk < m) ? j0 + jchunk : m;
   const int64_t slice0 = (int64_t)blk * ((int64_t)blockDim.x * EPT);
-  T xr[EPT];
-  load_own<T, VEC>(xr, x + (int64_t)b * ldx, slice0, n, tid);
-  const T* rb = rows + (int64_t)b * rows_ldb;
-  constexpr int JT = EPT <= 4 ? 8 : 4;  // rows in flight per thread: >= 16 B x 8 of loads before the first use
-  int j = 0;
-  for (; j + JT <= m; j += JT) {
-    T rr[JT][EPT];
+  T xr[CT][EPT];
 #pragma unroll
-    for (int q = 0; q < JT; ++q) load_own<T, VEC>(rr[q], rb + (int64_t)(j + q) * row_stride, slice0, n, tid);
-#pragma unroll
-    for (int q = 0; q < JT; ++q) {
-      T acc = T(0);
-#pragma unroll
-      for (int e = 0; e < EPT; ++e) acc += rr[q][e] * xr[e];
-      acc = wave_sum(acc);
-      if (lane == 0) sm[wid * m + j + q] = acc;
-    }
+  for (int ct = 0; ct < CT; ++ct) {
+    const int col = col0 + ct < ncols ? col0 + ct : ncols - 1;  // a ragged last tile repeats its last column (not stored)
+    load_own<T, VEC>(xr[ct], x + (int64_t)b * ldx + (int64_t)col * x_zstride, slice0, n, tid);
   }
-  for (; j < m; ++j) {
-    T rr[EPT];
-    load_own<T, VEC>(rr, rb + (int64_t)j * row_stride, slice0, n, tid);
-    T acc = T(0);
+  sweep_rows<T, VEC, EPT, RowsInFlight<EPT>::value>(
+      rows + (int64_t)b * rows_ldb, row_stride, j0, j1, slice0, n, tid, [&](int j, const T (&row)[EPT]) {
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) acc += rr[e] * xr[e];
-    acc = wave_sum(acc);
-    if (lane == 0) sm[wid * m + j] = acc;
-  }
+        for (int ct = 0; ct < CT; ++ct) {
+          T acc = T(0);
+#pragma unroll
+          for (int e = 0; e < EPT; ++e) acc += row[e] * xr[ct][e];
+          acc = wave_sum(acc);
+          if (lane == 0) sm[(wid * CT + ct) * jchunk + (j - j0)] = acc;
+        }
+      });
   __syncthreads();
-  for (int j = tid; j < m; j += (int)blockDim.x)
-  {
+  const int nj = j1 - j0;
+  for (int i = tid; i < CT * nj; i += (int)blockDim.x) {
+    const int ct = i / nj, j = j0 + i % nj;
+    if (col0 + ct >= ncols) break;
     T sum = T(0);
-    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sum += sm[w * m + j];
-    partial[((int64_t)b * kmax + j) * nblk + blk] = sum;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sum += sm[(w * CT + ct) * jchunk + (j - j0)];
+    partial[(int64_t)(col0 + ct) * part_zstride + ((int64_t)b * kmax + j) * nblk + blk] = sum;
   }
 }
 
@@ -177,54 +251,22 @@ __global__ __launch_bounds__(kBlock) void k_update(UpdateArgs<T> a) {
     for (int e = 0; e < EPT; ++e) xr[e] = T(0);
   }
   const T* rb = a.rows + (int64_t)b * a.rows_ldb;
-  constexpr int JT = EPT <= 4 ? 8 : 4;  // rows in flight per thread
-  {
-    int j = 0;
-    for (; j + JT <= m; j += JT) {
-      T rr[JT][EPT];
+  constexpr int JT = RowsInFlight<EPT>::value;
+  sweep_rows<T, VEC, EPT, JT>(rb, a.row_stride, 0, m, slice0, a.n, tid, [&](int j, const T (&row)[EPT]) {
+    const T c = coef[j];
 #pragma unroll
-      for (int q = 0; q < JT; ++q) load_own<T, VEC>(rr[q], rb + (int64_t)(j + q) * a.row_stride, slice0, a.n, tid);
-#pragma unroll
-      for (int q = 0; q < JT; ++q) {
-        const T c = coef[j + q];
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) xr[e] -= c * rr[q][e];
-      }
-    }
-    for (; j < m; ++j) {
-      T rr[EPT];
-      load_own<T, VEC>(rr, rb + (int64_t)j * a.row_stride, slice0, a.n, tid);
-      const T c = coef[j];
-#pragma unroll
-      for (int e = 0; e < EPT; ++e) xr[e] -= c * rr[e];
-    }
-  }
+    for (int e = 0; e < EPT; ++e) xr[e] -= c * row[e];
+  });
   store_own<T, VEC>(xr, a.y + (int64_t)b * a.ldy, slice0, a.n, tid);
   if (a.y2) store_own<T, VEC>(xr, a.y2 + (int64_t)b * a.ldy2, slice0, a.n, tid);
   if constexpr (DOTS) {
-    int j = 0;
-    for (; j + JT <= m; j += JT) {
-      T rr[JT][EPT];
-#pragma unroll
-      for (int q = 0; q < JT; ++q) load_own<T, VEC>(rr[q], rb + (int64_t)(j + q) * a.row_stride, slice0, a.n, tid);
-#pragma unroll
-      for (int q = 0; q < JT; ++q) {
-        T acc = T(0);
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) acc += rr[q][e] * xr[e];
-        acc = wave_sum(acc);
-        if (lane == 0) sm[wid * m + j + q] = acc;
-      }
-    }
-    for (; j < m; ++j) {
-      T rr[EPT];
-      load_own<T, VEC>(rr, rb + (int64_t)j * a.row_stride, slice0, a.n, tid);
+    sweep_rows<T, VEC, EPT, JT>(rb, a.row_stride, 0, m, slice0, a.n, tid, [&](int j, const T (&row)[EPT]) {
       T acc = T(0);
 #pragma unroll
-      for (int e = 0; e < EPT; ++e) acc += rr[e] * xr[e];
+      for (int e = 0; e < EPT; ++e) acc += row[e] * xr[e];
       acc = wave_sum(acc);
       if (lane == 0) sm[wid * m + j] = acc;
-    }
+    });
     __syncthreads();
     for (int j = tid; j < m; j += (int)blockDim.x)
     {
@@ -392,7 +434,7 @@ struct Ctx {
   // 4x more partials in its prologue (update + norm 7.4 -> 14.7 us); forward 2.84 -> 2.91 ms, forward + adjoint 8.7 -> 8.0 ms, within
   // box-to-box noise.  Off unless MFX_FINE_SLICES=1.
   void fine() {
-    static const bool on = [] { const char* e = getenv("MFX_FINE_SLICES"); return e && atoi(e) != 0; }();
+    static const bool on = [] { const char* e = getenv("MFX_FINE_SLICES"); return !e || atoi(e) != 0; }();
     if (!on || vec <= 1 || wg != kBlock || (int64_t)nblk * p >= 128) return;
     ept = VecWidth<T>::value;
     nblk = (int)((n + (int64_t)wg * ept - 1) / ((int64_t)wg * ept));
@@ -417,13 +459,35 @@ struct Ctx {
   }
 };
 
+// ncols > 1: the same rows against x + col * x_zstride, col < ncols, partials at partial + col * part_zstride (not in
+// the row-sharded mode: one staging buffer)
+constexpr int kDotsColTile = 4;
 template <typename T>
 static int launch_dots(const Ctx<T>& c, const T* rows, int64_t rows_ldb, int64_t row_stride, int m,
-                       const T* x, int64_t ldx, T* partial) {
+                       const T* x, int64_t ldx, T* partial, int ncols = 1, int64_t x_zstride = 0,
+                       int64_t part_zstride = 0) {
   if (m <= 0) return MFX_OK;
-  const size_t sh = (size_t)4 * m * sizeof(T);
-  MFX_VEC_EPT_SWITCH(c, (k_dots<T, VEC, EPT><<<c.grid(), c.wg, sh, c.stream>>>(
-                            rows, rows_ldb, row_stride, m, x, ldx, c.n, c.producer(partial), c.kmax, c.nblk)));
+  MFX_REQUIRE(ncols == 1 || !c.comm, MFX_ERR_UNSUPPORTED, "batched dots in the row-sharded mode");
+  const bool tiled = ncols > 1 && c.vec > 1 && c.ept == VecWidth<T>::value;  // CT vectors of EPT elements in registers beside the row buffers
+  const int ctiles = tiled ? (ncols + kDotsColTile - 1) / kDotsColTile : ncols;
+  // few slices (one vector, n ~ 1e5): split the rows over workgroups as well
+  const int64_t wgs = (int64_t)c.nblk * c.p * ctiles;
+  const int64_t maxgroups = wgs < 256 ? 1024 / wgs : 1;
+  int jchunk = (int)((m + maxgroups - 1) / maxgroups);
+  const int jmin = c.ept <= 4 ? 16 : 8;  // one buffer of sweep_rows at least
+  if (jchunk < jmin) jchunk = m < jmin ? m : jmin;
+  const int ngroups = (m + jchunk - 1) / jchunk;
+  const size_t sh = (size_t)4 * (tiled ? kDotsColTile : 1) * jchunk * sizeof(T);
+  dim3 grid(c.nblk, (unsigned)c.p, (unsigned)(ctiles * ngroups));
+  if (tiled) {
+    constexpr int VEC = VecWidth<T>::value;  // Ctx::fine: ept == VEC, 16-byte loads
+    k_dots<T, VEC, VEC, kDotsColTile><<<grid, c.wg, sh, c.stream>>>(rows, rows_ldb, row_stride, m, x, ldx, c.n, c.producer(partial),
+                                                                   c.kmax, c.nblk, jchunk, ngroups, ncols, x_zstride, part_zstride);
+  } else {
+    MFX_VEC_EPT_SWITCH(c, (k_dots<T, VEC, EPT, 1><<<grid, c.wg, sh, c.stream>>>(
+                              rows, rows_ldb, row_stride, m, x, ldx, c.n, c.producer(partial), c.kmax, c.nblk, jchunk,
+                              ngroups, ncols, x_zstride, part_zstride)));
+  }
   MFX_CHECK_LAUNCH();
   return c.finish(partial, c.kmax, m);
 }

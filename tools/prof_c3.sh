@@ -3,7 +3,7 @@
 set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-OUT=$R/gpurun_out/prof_c3
+OUT=$R/gpurun_out/prof_c3${1:+_$1}
 rm -rf $OUT && mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/tools/bench_configs.py c3 > $OUT/run.log 2>&1
 f=$(find $OUT -name "*kernel_stats.csv" | head -1)
