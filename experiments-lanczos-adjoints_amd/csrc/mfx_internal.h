@@ -89,17 +89,88 @@ int op_cross_apply(const mfx_operator* op, const void* xnew, int64_t m, const vo
 
 #ifdef __HIPCC__
 // ---- wave64 / workgroup reductions -------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  return v;  // valid in lane 0
+// DPP cross-lane moves (no LDS round trip like ds_bpermute behind __shfl_*): quad permutes, mirrors within a row of
+// 16 lanes, then row_bcast15 / row_bcast31 carry the row sums across the four rows; lane 63 ends with the total, which
+// v_readlane broadcasts.  A wave_sum is ~10 (fp32) / ~20 (fp64) full-rate VALU instructions instead of 6 dependent
+// LDS-latency shuffles -- the dots kernels do one per row and slice.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float wave_bcast63(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
+__device__ __forceinline__ double wave_bcast63(double v) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 template <typename T>
 __device__ __forceinline__ T wave_sum_all(T v) {
+  v += dpp_mov<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141, 0xF>(v);  // row_half_mirror
+  v += dpp_mov<0x140, 0xF>(v);  // row_mirror: every lane holds its row's sum
+  v += dpp_mov<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
+  v += dpp_mov<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3
+  return wave_bcast63(v);       // valid in every lane
+}
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+  return wave_sum_all(v);
+}
+
+// JT (1, 2, 4, 8 or 16) values per lane -> their sums over each ROW of 16 lanes, transposed: the return value of a lane is
+// the row total of value number row16_index<JT>(lane).  log2(JT) "halving" steps (a lane keeps half of its values and
+// hands the other half to its partner: JT - 1 adds altogether instead of 4 JT), then plain butterfly steps on the one
+// value left.  Partners: row_mirror, row_half_mirror, quad xor 2, quad xor 1 -- in THIS order every partner shares the
+// side bits used so far (lane bits 3, 2, 1, 0), so both hold the same subset of values.
+template <int STEP, typename T>
+__device__ __forceinline__ T row16_partner(T v) {
+  if constexpr (STEP == 0) return dpp_mov<0x140, 0xF>(v);       // row_mirror       i <-> 15 - i
+  else if constexpr (STEP == 1) return dpp_mov<0x141, 0xF>(v);  // row_half_mirror  i <-> 7 - i (within 8)
+  else if constexpr (STEP == 2) return dpp_mov<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  else return dpp_mov<0xB1, 0xF>(v);                            // quad_perm [1,0,3,2]
+}
+template <int N, int STEP, typename T>
+__device__ __forceinline__ void row16_halve(T* v, int lane) {
+  if constexpr (N > 1) {
+    const bool side = (lane >> (3 - STEP)) & 1;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;  // valid in every lane
+    for (int i = 0; i < N / 2; ++i) {
+      const T keep = side ? v[i + N / 2] : v[i];
+      const T send = side ? v[i] : v[i + N / 2];
+      v[i] = keep + row16_partner<STEP>(send);
+    }
+    row16_halve<N / 2, STEP + 1>(v, lane);
+  } else if constexpr (STEP < 4) {
+    v[0] += row16_partner<STEP>(v[0]);
+    row16_halve<1, STEP + 1>(v, lane);
+  }
+}
+template <int JT, typename T>
+__device__ __forceinline__ T row16_sums(T (&v)[JT], int lane) {
+  static_assert(JT == 1 || JT == 2 || JT == 4 || JT == 8 || JT == 16, "values per lane");
+  row16_halve<JT, 0>(v, lane);
+  return v[0];
+}
+// the same over the whole wave: the four row totals are added with two LDS-path shuffles (per JT values, not per value)
+template <int JT, typename T>
+__device__ __forceinline__ T wave_sums(T (&v)[JT], int lane) {
+  T r = row16_sums<JT>(v, lane);
+  r += __shfl_xor(r, 16, 64);
+  r += __shfl_xor(r, 32, 64);
+  return r;  // every lane: the wave total of value number row16_index<JT>(lane)
+}
+template <int JT>
+__device__ __forceinline__ int row16_index(int lane) {  // which of the JT values this lane's row16_sums result belongs to
+  return JT == 16 ? (lane & 15) : JT == 8 ? ((lane >> 1) & 7) : JT == 4 ? ((lane >> 2) & 3) : JT == 2 ? ((lane >> 3) & 1) : 0;
+}
+template <int JT>
+__device__ __forceinline__ bool wave_sums_writer(int lane) {  // one lane of the wave per value
+  return lane < 16 && (lane & (16 / JT - 1)) == 0;
 }
 
 // 16-byte vector access: VEC elements of T (float x4, double x2) or scalar fallback (VEC = 1)

@@ -22,21 +22,23 @@ template <typename T>
 __global__ void k_adj_setup(const T* __restrict__ H, const T* __restrict__ dH, const T* __restrict__ c,
                             const T* __restrict__ dc, const T* __restrict__ part_qtdr, int kmax,
                             int nblk, int k, T* __restrict__ eta, T* __restrict__ pig) {
-  const int b = blockIdx.x;
+  // grid (p, k): workgroup (b, i) owns row i of Pi_gamma; the workgroups of row 0 also write eta
+  const int b = blockIdx.x, i = blockIdx.y;
   const T* Hb = H + (int64_t)b * k * k;
   const T* dHb = dH + (int64_t)b * k * k;
-  for (int idx = threadIdx.x; idx < k * kRedG; idx += blockDim.x) {
-    const int j = idx / kRedG, g = idx % kRedG;
-    T e = dHb[(int64_t)j * k + (k - 1)];
-    if (part_qtdr) e -= reduce_partials_group<T, kRedG>(part_qtdr + ((int64_t)b * kmax + j) * nblk, nblk, g);
-    if (g == 0) eta[(int64_t)b * k + j] = e;
+  if (i == 0) {
+    for (int idx = threadIdx.x; idx < k * kRedG; idx += blockDim.x) {
+      const int j = idx / kRedG, g = idx % kRedG;
+      T e = dHb[(int64_t)j * k + (k - 1)];
+      if (part_qtdr) e -= reduce_partials_group<T, kRedG>(part_qtdr + ((int64_t)b * kmax + j) * nblk, nblk, g);
+      if (g == 0) eta[(int64_t)b * k + j] = e;
+    }
   }
-  for (int ij = threadIdx.x; ij < k * k; ij += blockDim.x) {
-    const int i = ij / k, j = ij % k;
+  for (int j = threadIdx.x; j < k; j += blockDim.x) {
     double acc = 0.0;
     for (int l = 0; l < k; ++l) acc += (double)Hb[(int64_t)i * k + l] * (double)dHb[(int64_t)j * k + l];
     if (i == 0 && j == 0 && dc) acc -= (double)dc[b] * (double)c[b];
-    pig[(int64_t)b * k * k + ij] = (T)acc;
+    pig[(int64_t)b * k * k + (int64_t)i * k + j] = (T)acc;
   }
 }
 
@@ -120,15 +122,21 @@ __global__ __launch_bounds__(kBlock) void k_adj_combine(CombineArgs<T> a) {
     for (int e = 0; e < EPT; ++e) acc[e] += t[e];
   }
   constexpr int JT = RowsInFlight<EPT>::value;
-  sweep_rows<T, VEC, EPT, JT>(Qb, n, 0, k, slice0, n, tid, [&](int j, const T (&row)[EPT]) {
-    const T gj = g[j];
+  sweep_rows<T, VEC, EPT, JT>(Qb, n, 0, k, slice0, n, tid, [&](int j, const T (&row)[JT][EPT], int nvalid) {
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) acc[e] += gj * row[e];
+    for (int q = 0; q < JT; ++q) {
+      const T gj = q < nvalid ? g[j + q] : T(0);
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) acc[e] += gj * row[q][e];
+    }
   });
-  sweep_rows<T, VEC, EPT, JT>(Lb, n, idx + 1, k, slice0, n, tid, [&](int j, const T (&row)[EPT]) {
-    const T hj = hp[j];
+  sweep_rows<T, VEC, EPT, JT>(Lb, n, idx + 1, k, slice0, n, tid, [&](int j, const T (&row)[JT][EPT], int nvalid) {
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) acc[e] -= hj * row[e];
+    for (int q = 0; q < JT; ++q) {
+      const T hj = q < nvalid ? hp[j + q] : T(0);
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) acc[e] -= hj * row[q][e];
+    }
   });
   const T inv = T(1) / bminus;
 #pragma unroll
@@ -473,7 +481,7 @@ static int arnoldi_adjoint_t(const mfx_operator* op, int64_t n, int64_t k, int64
   {
     ScopedTimer t(2, stream);
     if (dr) MFX_TRY(launch_dots<T>(c, Q, ldq, n, (int)k, dr, n, P1));
-    k_adj_setup<T><<<(unsigned)p, 256, 0, stream>>>(H, dH, cinv, dc, dr ? P1 : nullptr, c.kmax, c.nblk_in, (int)k, eta, pig);
+    k_adj_setup<T><<<dim3((unsigned)p, (unsigned)k), 64, 0, stream>>>(H, dH, cinv, dc, dr ? P1 : nullptr, c.kmax, c.nblk_in, (int)k, eta, pig);
     MFX_CHECK_LAUNCH();
     if (dQ) {
       const int64_t cb = ws.pb ? dq_batch_cols(n, k, p, comm) : 1;

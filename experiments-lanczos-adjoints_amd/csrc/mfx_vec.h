@@ -58,6 +58,19 @@ __device__ __forceinline__ T reduce_partials(const T* __restrict__ part, int nbl
 // within the group); result in every lane of the group.  The consumers' prologues run in EVERY slice workgroup, so with one
 // lane per coefficient they cost nblk serial reads each -- 977 at n = 2e6 (BASELINE config 5), where they dominated the
 // vector kernels.  Fixed lane-strided order + xor tree: deterministic.
+// sum over an aligned group of G = 8 or 64 lanes, result in every lane of the group (DPP, see wave_sum_all)
+template <int G>
+__device__ __forceinline__ double group_sum_all(double v) {
+  static_assert(G == 8 || G == 64, "group size");
+  if constexpr (G == 64) {
+    return wave_sum_all(v);
+  } else {
+    v += dpp_mov<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141, 0xF>(v);  // row_half_mirror
+    return v;
+  }
+}
 template <typename T, int G>
 __device__ __forceinline__ T reduce_partials_group(const T* __restrict__ part, int nblk, int g) {
   double acc = 0.0;
@@ -69,13 +82,12 @@ __device__ __forceinline__ T reduce_partials_group(const T* __restrict__ part, i
 #pragma unroll
     for (int u = 0; u < U; ++u) acc += (double)v[u];  // same order as a plain lane-strided loop
   }
-#pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, G);
-  return (T)acc;
+  return (T)group_sum_all<G>(acc);
 }
 constexpr int kRedG = 8;  // lanes per coefficient in the multi-coefficient prologues
 
-// Rows j0 <= j < j1 of a (rows, n) panel, this thread's elements of the slice, in order, f(j, row[EPT]) per row --
+// Rows j0 <= j < j1 of a (rows, n) panel, this thread's elements of the slice, in order, JT rows at a time:
+// f(j, rows[JT][EPT], nvalid) --
 // double-buffered: the loads of the next JT rows are issued before the current JT are consumed, so a sweep is
 // ceil(rows / JT) overlapped round trips instead of that many serial ones (what bounds these kernels when there
 // are few workgroups: one vector, n ~ 1e5).  Every load is issued on every path -- rows past the end re-read the
@@ -110,13 +122,11 @@ __device__ __forceinline__ void sweep_rows(const T* __restrict__ rb, int64_t row
   auto use = [&](T (&src)[JT][EPT], int j) {
 #pragma unroll
     for (int q = 0; q < JT; ++q)
-      if (j + q < j1) {
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+      for (int u = 0; u < U; ++u)
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) src[q][u * VEC + e] = ok[u] ? src[q][u * VEC + e] : T(0);
-        f(j + q, src[q]);
-      }
+        for (int e = 0; e < VEC; ++e) src[q][u * VEC + e] = ok[u] ? src[q][u * VEC + e] : T(0);
+    f(j, src, (j1 - j < JT) ? j1 - j : JT);  // rows j .. j + nvalid - 1 (the others repeat the last row)
   };
   T ra[JT][EPT];
   if (j1 - j0 <= JT) {
@@ -170,15 +180,21 @@ __global__ __launch_bounds__(kBlock) void k_dots(const T* __restrict__ rows, int
     const int col = col0 + ct < ncols ? col0 + ct : ncols - 1;  // a ragged last tile repeats its last column (not stored)
     load_own<T, VEC>(xr[ct], x + (int64_t)b * ldx + (int64_t)col * x_zstride, slice0, n, tid);
   }
-  sweep_rows<T, VEC, EPT, RowsInFlight<EPT>::value>(
-      rows + (int64_t)b * rows_ldb, row_stride, j0, j1, slice0, n, tid, [&](int j, const T (&row)[EPT]) {
+  constexpr int JT = RowsInFlight<EPT>::value;
+  sweep_rows<T, VEC, EPT, JT>(
+      rows + (int64_t)b * rows_ldb, row_stride, j0, j1, slice0, n, tid, [&](int j, const T (&row)[JT][EPT], int nvalid) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
-          T acc = T(0);
+          T acc[JT];  // all rows of the buffer in one block of straight-line code: the JT reductions interleave
 #pragma unroll
-          for (int e = 0; e < EPT; ++e) acc += row[e] * xr[ct][e];
-          acc = wave_sum(acc);
-          if (lane == 0) sm[(wid * CT + ct) * jchunk + (j - j0)] = acc;
+          for (int q = 0; q < JT; ++q) {
+            acc[q] = T(0);
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) acc[q] += row[q][e] * xr[ct][e];
+          }
+          const T wsum = wave_sums<JT>(acc, lane);
+          const int q = row16_index<JT>(lane);
+          if (wave_sums_writer<JT>(lane) && q < nvalid) sm[(wid * CT + ct) * jchunk + (j - j0) + q] = wsum;
         }
       });
   __syncthreads();
@@ -252,20 +268,28 @@ __global__ __launch_bounds__(kBlock) void k_update(UpdateArgs<T> a) {
   }
   const T* rb = a.rows + (int64_t)b * a.rows_ldb;
   constexpr int JT = RowsInFlight<EPT>::value;
-  sweep_rows<T, VEC, EPT, JT>(rb, a.row_stride, 0, m, slice0, a.n, tid, [&](int j, const T (&row)[EPT]) {
-    const T c = coef[j];
+  sweep_rows<T, VEC, EPT, JT>(rb, a.row_stride, 0, m, slice0, a.n, tid, [&](int j, const T (&row)[JT][EPT], int nvalid) {
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) xr[e] -= c * row[e];
+    for (int q = 0; q < JT; ++q) {
+      const T c = q < nvalid ? coef[j + q] : T(0);
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) xr[e] -= c * row[q][e];
+    }
   });
   store_own<T, VEC>(xr, a.y + (int64_t)b * a.ldy, slice0, a.n, tid);
   if (a.y2) store_own<T, VEC>(xr, a.y2 + (int64_t)b * a.ldy2, slice0, a.n, tid);
   if constexpr (DOTS) {
-    sweep_rows<T, VEC, EPT, JT>(rb, a.row_stride, 0, m, slice0, a.n, tid, [&](int j, const T (&row)[EPT]) {
-      T acc = T(0);
+    sweep_rows<T, VEC, EPT, JT>(rb, a.row_stride, 0, m, slice0, a.n, tid, [&](int j, const T (&row)[JT][EPT], int nvalid) {
+      T acc[JT];
 #pragma unroll
-      for (int e = 0; e < EPT; ++e) acc += row[e] * xr[e];
-      acc = wave_sum(acc);
-      if (lane == 0) sm[wid * m + j] = acc;
+      for (int q = 0; q < JT; ++q) {
+        acc[q] = T(0);
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) acc[q] += row[q][e] * xr[e];
+      }
+      const T wsum = wave_sums<JT>(acc, lane);
+      const int q = row16_index<JT>(lane);
+      if (wave_sums_writer<JT>(lane) && q < nvalid) sm[wid * m + j + q] = wsum;
     });
     __syncthreads();
     for (int j = tid; j < m; j += (int)blockDim.x)
