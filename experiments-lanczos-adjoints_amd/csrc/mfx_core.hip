@@ -1,5 +1,6 @@
 // libmfx: error reporting, versioning and the hipEvent-based per-class kernel timer.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include <mutex>
 #include <vector>
@@ -45,6 +46,82 @@ ScopedTimer::~ScopedTimer() {
   delete sp;
 }
 
+// ------------------------------------------------------------------------------------------------
+// hipGraph cache (see mfx_internal.h)
+// ------------------------------------------------------------------------------------------------
+struct GraphEntry {
+  std::string key;
+  hipGraphExec_t exec;  // null until the second call with this key
+  bool failed;          // capture or instantiation failed once: always eager
+  uint64_t last_use;
+};
+static std::mutex g_gmutex;
+static std::vector<GraphEntry> g_graphs;
+static uint64_t g_gclock = 0;
+static int64_t g_captured = 0, g_replayed = 0;
+static hipStream_t g_capture_stream = nullptr;  // captures run here: the caller's stream may be the legacy default stream
+constexpr size_t kMaxGraphs = 32;
+
+static bool graphs_enabled() {
+  static const bool on = [] { const char* e = getenv("MFX_GRAPHS"); return !e || atoi(e) != 0; }();
+  return on;
+}
+
+int run_graphed(bool eligible, const GraphKey& key, hipStream_t stream, const std::function<int(hipStream_t)>& fn) {
+  if (!eligible || g_timing || !graphs_enabled()) return fn(stream);
+  std::lock_guard<std::mutex> lock(g_gmutex);
+  GraphEntry* e = nullptr;
+  for (auto& g : g_graphs)
+    if (g.key == key.bytes) e = &g;
+  if (!e) {  // first sighting: run eagerly, remember the key
+    if (g_graphs.size() >= kMaxGraphs) {
+      size_t old = 0;
+      for (size_t i = 1; i < g_graphs.size(); ++i)
+        if (g_graphs[i].last_use < g_graphs[old].last_use) old = i;
+      if (g_graphs[old].exec) (void)hipGraphExecDestroy(g_graphs[old].exec);
+      g_graphs.erase(g_graphs.begin() + (long)old);
+    }
+    g_graphs.push_back(GraphEntry{key.bytes, nullptr, false, ++g_gclock});
+    return fn(stream);
+  }
+  e->last_use = ++g_gclock;
+  if (e->failed) return fn(stream);
+  if (!e->exec) {
+    if (!g_capture_stream && hipStreamCreateWithFlags(&g_capture_stream, hipStreamNonBlocking) != hipSuccess) {
+      e->failed = true;
+      (void)hipGetLastError();
+      return fn(stream);
+    }
+    if (hipStreamBeginCapture(g_capture_stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
+      e->failed = true;
+      (void)hipGetLastError();
+      return fn(stream);
+    }
+    const int rc = fn(g_capture_stream);
+    hipGraph_t graph = nullptr;
+    const hipError_t ec = hipStreamEndCapture(g_capture_stream, &graph);
+    if (rc != MFX_OK) {  // the driver refused its arguments: nothing ran, nothing to replay
+      if (graph) (void)hipGraphDestroy(graph);
+      (void)hipGetLastError();
+      e->failed = true;
+      return rc;
+    }
+    hipGraphExec_t exec = nullptr;
+    if (ec != hipSuccess || !graph || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+      if (graph) (void)hipGraphDestroy(graph);
+      (void)hipGetLastError();
+      e->failed = true;
+      return fn(stream);
+    }
+    (void)hipGraphDestroy(graph);
+    e->exec = exec;
+    ++g_captured;
+  }
+  MFX_CHECK_HIP(hipGraphLaunch(e->exec, stream));
+  ++g_replayed;
+  return MFX_OK;
+}
+
 }  // namespace mfx
 
 extern "C" {
@@ -54,6 +131,13 @@ int mfx_version(void) { return MFX_VERSION; }
 
 int mfx_timing_enable(int enable) {
   mfx::g_timing = enable != 0;
+  return MFX_OK;
+}
+
+int mfx_graph_stats(int64_t* captured, int64_t* replayed) {
+  std::lock_guard<std::mutex> lock(mfx::g_gmutex);
+  if (captured) *captured = mfx::g_captured;
+  if (replayed) *replayed = mfx::g_replayed;
   return MFX_OK;
 }
 

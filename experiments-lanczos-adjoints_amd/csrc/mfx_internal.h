@@ -4,6 +4,9 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <functional>
+#include <string>
+
 #include "mfx.h"
 
 namespace mfx {
@@ -44,6 +47,22 @@ struct ScopedTimer {
   ScopedTimer(int cls, hipStream_t s);
   ~ScopedTimer();
 };
+
+// ---- hipGraph replay of launch-bound driver calls (mfx_core.hip) ---------------------------------
+// A driver call is a fixed sequence of launches determined by its arguments (no host reads of device data), so for
+// small problems -- where the host's ~5 us per launch, not the GPU, sets the pace -- the second call with the same
+// arguments is captured into a hipGraph and every later one is a single hipGraphLaunch.  MFX_GRAPHS=0 disables it.
+struct GraphKey {
+  std::string bytes;
+  template <typename X>
+  GraphKey& add(const X& x) {
+    bytes.append(reinterpret_cast<const char*>(&x), sizeof(X));
+    return *this;
+  }
+};
+// eligible = false (or graphs disabled, or kernel timing on): plain fn(stream).  fn must enqueue everything on the stream
+// it is given and nothing else (no synchronisation, no allocation).
+int run_graphed(bool eligible, const GraphKey& key, hipStream_t stream, const std::function<int(hipStream_t)>& fn);
 
 // ---- geometry of the Krylov vector kernels ------------------------------------------------------
 constexpr int kBlock = 256;  // 4 waves

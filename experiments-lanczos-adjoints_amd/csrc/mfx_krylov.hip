@@ -675,6 +675,19 @@ int mfx_op_vjp_params(const mfx_operator* op, const void* L, int64_t ldl, const 
   return op_vjp_params(op, L, ldl, R, ldr, batch, grads, ws, ws_bytes, s);
 }
 
+// launch-bound regime: few slices and a native operator (a callback enqueues work the capture cannot see)
+static bool graph_eligible(const mfx_operator* op, int64_t n, int64_t p) {
+  return op->kind != MFX_OP_CALLBACK && num_slices(n) * p < 256;
+}
+static GraphKey driver_key(int fn_id, const mfx_operator* op, int64_t n, int64_t k, int64_t p, const mfx_op_grads* grads,
+                           const void* ws, int64_t ws_bytes, const void* stream) {
+  GraphKey key;
+  key.add(fn_id).add(*op).add(n).add(k).add(p).add(ws).add(ws_bytes).add(stream);
+  const mfx_op_grads none{};
+  key.add(grads ? *grads : none).add(grads != nullptr);
+  return key;
+}
+
 #define MFX_DRIVER_PROLOGUE()                                                                   \
   MFX_TRY(check_common(op, n, k, p));                                                           \
   KrylovWs kws;                                                                                 \
@@ -688,9 +701,13 @@ int mfx_arnoldi_forward(const mfx_operator* op, const void* v0, int64_t n, int64
                         void* stream) {
   MFX_REQUIRE(v0 && Q && H && r && c, MFX_ERR_INVALID, "null argument");
   MFX_DRIVER_PROLOGUE();
-  if (op->dtype == MFX_F32)
-    return arnoldi_forward_t<float>(op, (const float*)v0, n, k, p, second_pass, (float*)Q, (float*)H, (float*)r, (float*)c, kws, s);
-  return arnoldi_forward_t<double>(op, (const double*)v0, n, k, p, second_pass, (double*)Q, (double*)H, (double*)r, (double*)c, kws, s);
+  GraphKey key = driver_key(1, op, n, k, p, nullptr, ws, ws_bytes, stream);
+  key.add(v0).add(second_pass).add(Q).add(H).add(r).add(c);
+  return run_graphed(graph_eligible(op, n, p), key, s, [&](hipStream_t st) {
+    if (op->dtype == MFX_F32)
+      return arnoldi_forward_t<float>(op, (const float*)v0, n, k, p, second_pass, (float*)Q, (float*)H, (float*)r, (float*)c, kws, st);
+    return arnoldi_forward_t<double>(op, (const double*)v0, n, k, p, second_pass, (double*)Q, (double*)H, (double*)r, (double*)c, kws, st);
+  });
 }
 
 int mfx_arnoldi_adjoint(const mfx_operator* op, int64_t n, int64_t k, int64_t p, const void* Q, const void* H,
@@ -700,13 +717,17 @@ int mfx_arnoldi_adjoint(const mfx_operator* op, int64_t n, int64_t k, int64_t p,
   MFX_REQUIRE(Q && H && r && c && dH && dv && Lambda, MFX_ERR_INVALID, "null argument");
   MFX_REQUIRE(reortho == MFX_REORTHO_NONE || reortho == MFX_REORTHO_FULL, MFX_ERR_INVALID, "bad reortho flag %d", reortho);
   MFX_DRIVER_PROLOGUE();
-  if (op->dtype == MFX_F32)
-    return arnoldi_adjoint_t<float>(op, n, k, p, (const float*)Q, (const float*)H, (const float*)r, (const float*)c,
-                                    (const float*)dQ, (const float*)dH, (const float*)dr, (const float*)dc, reortho,
-                                    (float*)dv, (float*)Lambda, grads, kws, s);
-  return arnoldi_adjoint_t<double>(op, n, k, p, (const double*)Q, (const double*)H, (const double*)r, (const double*)c,
-                                   (const double*)dQ, (const double*)dH, (const double*)dr, (const double*)dc, reortho,
-                                   (double*)dv, (double*)Lambda, grads, kws, s);
+  GraphKey key = driver_key(2, op, n, k, p, grads, ws, ws_bytes, stream);
+  key.add(Q).add(H).add(r).add(c).add(dQ).add(dH).add(dr).add(dc).add(reortho).add(dv).add(Lambda);
+  return run_graphed(graph_eligible(op, n, p), key, s, [&](hipStream_t st) {
+    if (op->dtype == MFX_F32)
+      return arnoldi_adjoint_t<float>(op, n, k, p, (const float*)Q, (const float*)H, (const float*)r, (const float*)c,
+                                      (const float*)dQ, (const float*)dH, (const float*)dr, (const float*)dc, reortho,
+                                      (float*)dv, (float*)Lambda, grads, kws, st);
+    return arnoldi_adjoint_t<double>(op, n, k, p, (const double*)Q, (const double*)H, (const double*)r, (const double*)c,
+                                     (const double*)dQ, (const double*)dH, (const double*)dr, (const double*)dc, reortho,
+                                     (double*)dv, (double*)Lambda, grads, kws, st);
+  });
 }
 
 static int check_sharded(const mfx_operator* op, const mfx_comm* cm, int64_t n, int64_t k, int64_t p) {
@@ -767,9 +788,13 @@ int mfx_lanczos_forward(const mfx_operator* op, const void* v0, int64_t n, int64
   MFX_REQUIRE(v0 && xs && alpha && beta && vnorm, MFX_ERR_INVALID, "null argument");
   MFX_DRIVER_PROLOGUE();
   MFX_REQUIRE(p <= 1024, MFX_ERR_UNSUPPORTED, "lanczos (reortho none) supports p <= 1024 probes per call");
-  if (op->dtype == MFX_F32)
-    return lanczos_forward_t<float>(op, (const float*)v0, n, k, p, (float*)xs, (float*)alpha, (float*)beta, (float*)vnorm, kws, s);
-  return lanczos_forward_t<double>(op, (const double*)v0, n, k, p, (double*)xs, (double*)alpha, (double*)beta, (double*)vnorm, kws, s);
+  GraphKey key = driver_key(3, op, n, k, p, nullptr, ws, ws_bytes, stream);
+  key.add(v0).add(xs).add(alpha).add(beta).add(vnorm);
+  return run_graphed(graph_eligible(op, n, p), key, s, [&](hipStream_t st) {
+    if (op->dtype == MFX_F32)
+      return lanczos_forward_t<float>(op, (const float*)v0, n, k, p, (float*)xs, (float*)alpha, (float*)beta, (float*)vnorm, kws, st);
+    return lanczos_forward_t<double>(op, (const double*)v0, n, k, p, (double*)xs, (double*)alpha, (double*)beta, (double*)vnorm, kws, st);
+  });
 }
 
 int mfx_lanczos_adjoint(const mfx_operator* op, int64_t n, int64_t k, int64_t p, const void* xs, const void* alpha,
@@ -777,13 +802,17 @@ int mfx_lanczos_adjoint(const mfx_operator* op, int64_t n, int64_t k, int64_t p,
                         void* dv, void* Lambda, const mfx_op_grads* grads, void* ws, int64_t ws_bytes, void* stream) {
   MFX_REQUIRE(xs && alpha && beta && vnorm && dalpha && dbeta && dv && Lambda, MFX_ERR_INVALID, "null argument");
   MFX_DRIVER_PROLOGUE();
-  if (op->dtype == MFX_F32)
-    return lanczos_adjoint_t<float>(op, n, k, p, (const float*)xs, (const float*)alpha, (const float*)beta,
-                                    (const float*)vnorm, (const float*)dxs, (const float*)dalpha, (const float*)dbeta,
-                                    (float*)dv, (float*)Lambda, grads, kws, s);
-  return lanczos_adjoint_t<double>(op, n, k, p, (const double*)xs, (const double*)alpha, (const double*)beta,
-                                   (const double*)vnorm, (const double*)dxs, (const double*)dalpha, (const double*)dbeta,
-                                   (double*)dv, (double*)Lambda, grads, kws, s);
+  GraphKey key = driver_key(4, op, n, k, p, grads, ws, ws_bytes, stream);
+  key.add(xs).add(alpha).add(beta).add(vnorm).add(dxs).add(dalpha).add(dbeta).add(dv).add(Lambda);
+  return run_graphed(graph_eligible(op, n, p), key, s, [&](hipStream_t st) {
+    if (op->dtype == MFX_F32)
+      return lanczos_adjoint_t<float>(op, n, k, p, (const float*)xs, (const float*)alpha, (const float*)beta,
+                                      (const float*)vnorm, (const float*)dxs, (const float*)dalpha, (const float*)dbeta,
+                                      (float*)dv, (float*)Lambda, grads, kws, st);
+    return lanczos_adjoint_t<double>(op, n, k, p, (const double*)xs, (const double*)alpha, (const double*)beta,
+                                     (const double*)vnorm, (const double*)dxs, (const double*)dalpha, (const double*)dbeta,
+                                     (double*)dv, (double*)Lambda, grads, kws, st);
+  });
 }
 
 }  // extern "C"

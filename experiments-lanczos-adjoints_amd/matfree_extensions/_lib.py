@@ -143,6 +143,7 @@ SYMBOLS = {
     "mfx_timing_enable": (_I, [_I]),
     "mfx_timing_reset": (_I, []),
     "mfx_timing_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "mfx_graph_stats": (_I, [C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
 }
 
 _lib = None
@@ -279,3 +280,10 @@ def timing_read(cls: int):
     tot, cnt = C.c_double(0.0), C.c_int64(0)
     check(get().mfx_timing_read(cls, C.byref(tot), C.byref(cnt)))
     return tot.value, cnt.value
+
+
+def graph_stats():
+    """(driver calls captured into a hipGraph, driver calls replayed from one) since the library was loaded."""
+    cap, rep = C.c_int64(0), C.c_int64(0)
+    check(get().mfx_graph_stats(C.byref(cap), C.byref(rep)))
+    return cap.value, rep.value

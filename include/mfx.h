@@ -38,8 +38,8 @@ enum { MFX_REORTHO_NONE = 0, MFX_REORTHO_FULL = 1 };
  *                         split on the f16 pipe, block signs alternating (falls back to fp32-MFMA distances when an
  *                         input exceeds the f16 range); parameter-gradient GEMM exact fp32.
  *   MFX_RBF_F16X3         additionally the parameter-gradient GEMM S = L^T R split the same way; the f16 MFMA's
- *                         round-towards-minus-infinity bias is decorrelated by pseudo-random column signs on both
- *                         operands plus alternating-sign K-chunks.  Fastest mode.
+ *                         truncation bias is decorrelated by pseudo-random column signs on both operands
+ *                         (undone in the epilogue).  Fastest mode.
  * Accuracy of the three modes against the fp64 path at the C4 size: DESIGN.md section 3.2 / profiles/r02a_*. */
 enum { MFX_RBF_FP32 = 0, MFX_RBF_F16X3_MATVEC = 1, MFX_RBF_F16X3 = 2 };
 /* Kernel family of the Gram operator, with s = |x_i/l - x_j/l|^2 clamped at 0 (util/gp_util.py:69-184):
@@ -304,6 +304,14 @@ int mfx_gram_cross_apply(const mfx_operator* op, const void* xnew, int64_t m, co
 int mfx_timing_enable(int enable);
 int mfx_timing_reset(void);
 int mfx_timing_read(int cls, double* total_ms, int64_t* launches);
+
+/* hipGraph replay of launch-bound driver calls.  The Krylov drivers enqueue a fixed sequence of launches that
+ * depends only on their arguments; for small problems (fewer than 256 vector-kernel workgroups, native operator,
+ * timing off) the second call with identical arguments is captured into a hipGraph and later ones are one
+ * hipGraphLaunch on the caller's stream.  The reference's counterpart is jax.jit's compiled executable
+ * (experiments/benchmarks/wall_times_vjp_through_lanczos_arnoldi/suite_sparse/benchmark.py:91-121 times the
+ * jitted function).  Environment MFX_GRAPHS=0 disables it.  Counters since load: calls captured, calls replayed. */
+int mfx_graph_stats(int64_t* captured, int64_t* replayed);
 
 #ifdef __cplusplus
 }
