@@ -266,24 +266,6 @@ __global__ __launch_bounds__(kBlock) void k_lz_adj_xi(const T* __restrict__ dxj,
   store_own<T, VEC>(acc, xi_out + (int64_t)b * n, slice0, n, tid);
 }
 
-// Lanczos forward coefficients: coef[b][0..m) for r = w - a x_i - b_{i-1} x_{i-1} (lanczos.py:281-282)
-// rows = xs[i-1], xs[i] (m = 2) or xs[0] (m = 1): coef = (beta_{i-1}, a) / (a)
-template <typename T>
-__global__ void k_lz_coef(const T* __restrict__ partial, int kmax, int nblk, const T* __restrict__ beta,
-                          int k, int i, T* __restrict__ alpha, T* __restrict__ coef /* (p,2) */) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= gridDim.x * blockDim.x) return;
-  const T a = reduce_partials(partial + ((int64_t)b * kmax) * nblk, nblk);
-  alpha[(int64_t)b * k + i] = a;
-  if (i == 0) {
-    coef[(int64_t)b * 2 + 0] = a;
-  } else {
-    coef[(int64_t)b * 2 + 0] = beta[(int64_t)b * k + i - 1];
-    coef[(int64_t)b * 2 + 1] = a;
-  }
-}
-
-// final Lanczos-adjoint initial-vector gradient: dvec = ((xi.x0) x0 - xi) / |v|  (lanczos.py:311)
 template <typename T, int VEC>
 __global__ __launch_bounds__(kBlock) void k_lz_adj_dvec(const T* __restrict__ x0, int64_t ldxs,
                                                         const T* __restrict__ xi, int64_t n,
@@ -555,10 +537,15 @@ static int lanczos_forward_t(const mfx_operator* op, const T* v0, int64_t n, int
                              T* alpha, T* beta, T* vnorm, const KrylovWs& ws, hipStream_t stream) {
   Ctx<T> c(n, k, p, pick_vec<T>(n, {v0, xs, ws.w}), stream);
   T* P1 = static_cast<T*>(ws.p1);
+  T* P2 = static_cast<T*>(ws.p2);
   T* PN = static_cast<T*>(ws.pn);
   T* w = static_cast<T*>(ws.w);
-  T* coef = static_cast<T*>(ws.small);
   const int64_t ldx = (k + 1) * n;
+  // r = w - a x_i - b_{i-1} x_{i-1} (lanczos.py:281-282) in ONE update over the rows (x_{i-1}, x_i): coefficient 0 is
+  // 0 * partials + beta[i-1], coefficient 1 is the dot a = x_i . w (its partials in row 1 of P1, row 0 stays zero) + beta[i],
+  // which is still zero when step i reads it -- so the three-term step needs no separate scalar kernel.
+  MFX_CHECK_HIP(hipMemsetAsync(beta, 0, sizeof(T) * p * k, stream));
+  MFX_CHECK_HIP(hipMemsetAsync(P1, 0, sizeof(T) * p * c.kmax * c.nblk, stream));
   {
     ScopedTimer t(2, stream);
     MFX_TRY(launch_sumsq<T>(c, v0, n, PN));
@@ -567,13 +554,14 @@ static int lanczos_forward_t(const mfx_operator* op, const T* v0, int64_t n, int
   for (int64_t i = 0; i < k; ++i) {
     MFX_TRY(apply_any(op, 0, xs + i * n, ldx, nullptr, 0, w, n, p, ws.opws, ws.opws_bytes, stream));
     ScopedTimer t(2, stream);
-    MFX_TRY(launch_dots<T>(c, xs + i * n, ldx, n, 1, w, n, P1));  // a = x_i . A x_i
-    k_lz_coef<T><<<1, (unsigned)p, 0, stream>>>(P1, c.kmax, c.nblk, beta, (int)k, (int)i, alpha, coef);
-    MFX_CHECK_LAUNCH();
-    UpdateArgs<T> a{};
     const int m = i == 0 ? 1 : 2;
+    T* P = i == 0 ? P2 : P1;
+    MFX_TRY(launch_dots<T>(c, xs + i * n, ldx, n, 1, w, n, P + (m - 1) * c.nblk));  // a = x_i . A x_i
+    UpdateArgs<T> a{};
     a.rows = xs + (i == 0 ? 0 : (i - 1) * n); a.rows_ldb = ldx; a.row_stride = n; a.m = m;
-    a.extra = coef; a.extra_ldb = 2; a.extra_stride = 1; a.s2 = T(1);
+    a.partial_in = P; a.s1 = T(1);
+    if (i > 0) { a.extra = beta + (i - 1); a.extra_ldb = k; a.extra_stride = 1; a.s2 = T(1); }
+    a.hout = alpha + i; a.hout_ldb = k; a.hout_stride = 0; a.hout_from = m - 1;
     a.x = w; a.ldx = n; a.y = w; a.ldy = n; a.partial_norm = PN;
     MFX_TRY(launch_update<T>(c, a, false, true));
     MFX_TRY(launch_scale<T>(c, w, n, xs + (i + 1) * n, ldx, PN, nullptr, 0, beta + i, k, nullptr));
@@ -787,7 +775,6 @@ int mfx_lanczos_forward(const mfx_operator* op, const void* v0, int64_t n, int64
                         void* alpha, void* beta, void* vnorm, void* ws, int64_t ws_bytes, void* stream) {
   MFX_REQUIRE(v0 && xs && alpha && beta && vnorm, MFX_ERR_INVALID, "null argument");
   MFX_DRIVER_PROLOGUE();
-  MFX_REQUIRE(p <= 1024, MFX_ERR_UNSUPPORTED, "lanczos (reortho none) supports p <= 1024 probes per call");
   GraphKey key = driver_key(3, op, n, k, p, nullptr, ws, ws_bytes, stream);
   key.add(v0).add(xs).add(alpha).add(beta).add(vnorm);
   return run_graphed(graph_eligible(op, n, p), key, s, [&](hipStream_t st) {

@@ -223,8 +223,9 @@ struct UpdateArgs {
   const T* extra;  // null or extra[b*extra_ldb + j*extra_stride]
   int64_t extra_ldb, extra_stride;
   T s2;
-  T* hout;  // null or hout[b*hout_ldb + j*hout_stride]
+  T* hout;  // null or hout[b*hout_ldb + j*hout_stride], j >= hout_from
   int64_t hout_ldb, hout_stride;
+  int hout_from;
   const T* x;  // null = zeros
   int64_t ldx;
   T* y;
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(kBlock) void k_update(UpdateArgs<T> a) {
     if (g == 0) {
       if (a.extra) c += a.s2 * a.extra[(int64_t)b * a.extra_ldb + (int64_t)j * a.extra_stride];
       coef[j] = c;
-      if (a.hout && blk == 0) a.hout[(int64_t)b * a.hout_ldb + (int64_t)j * a.hout_stride] = c;
+      if (a.hout && blk == 0 && j >= a.hout_from) a.hout[(int64_t)b * a.hout_ldb + (int64_t)j * a.hout_stride] = c;
     }
   }
   __syncthreads();
