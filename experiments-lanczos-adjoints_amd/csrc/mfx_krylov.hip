@@ -293,6 +293,136 @@ __global__ __launch_bounds__(kBlock) void k_lz_adj_dvec(const T* __restrict__ x0
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// Fused step head for the native CSR operator (few-launch regime: one vector, n ~ 1e5 -- every launch is 3-5 us of fixed
+// cost there): ONE kernel does what k_scale + k_csr_apply + k_dots do one after the other,
+//   PRE : f = 1 / |x| from the norm partials, qout = f x (the normalised basis vector, arnoldi.py:80 / lanczos.py:258),
+//         len_out = |x|;  the operator is applied to f x
+//   y   = A (f x) for the rows of this workgroup's slice -- each thread computes the rows it owns in the vector
+//         kernels' layout, straight into registers (entries of a row in order, CH at a time so that the index/value
+//         loads and then the gathers of all owned rows are in flight together)
+//   DOTS: partial[b][j][slice] = rows_j . y over the slice, j < m  (h = Q^T w, arnoldi.py:87; a = x_i . A x_i, lanczos.py:279)
+// `perm` (optional) maps a stored position to its slot in val (the transpose structure).  x and y must not overlap
+// (other workgroups gather from all of x).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct CsrStepArgs {
+  const int32_t *crow, *col, *perm;
+  const T* val;
+  const T* x;
+  int64_t ldx;
+  T* y;
+  int64_t ldy;
+  int64_t n;
+  const T* partial_norm;  // PRE: (p, nblk_in)
+  int nblk_in;
+  T* qout;
+  int64_t ldq;
+  T* len_out;
+  int64_t len_ld;
+  const T* rows;  // DOTS
+  int64_t rows_ldb, row_stride;
+  int m;
+  T* partial;
+  int kmax, nblk;
+};
+
+template <typename T, int VEC, int EPT, bool PRE, bool DOTS>
+__global__ __launch_bounds__(kBlock) void k_csr_step(CsrStepArgs<T> a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* sm = reinterpret_cast<T*>(smem_raw);  // [4][m] (DOTS)
+  __shared__ T f_sh;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int b = blockIdx.y, blk = blockIdx.x;
+  const int64_t slice0 = (int64_t)blk * ((int64_t)blockDim.x * EPT);
+  const int64_t n = a.n;
+  T f = T(1);
+  if constexpr (PRE) {
+    if (tid < 64) {
+      const T len = sqrt(reduce_partials_group<T, 64>(a.partial_norm + (int64_t)b * a.nblk_in, a.nblk_in, tid));
+      if (tid == 0) {
+        f_sh = T(1) / len;
+        if (blk == 0 && a.len_out) a.len_out[(int64_t)b * a.len_ld] = len;
+      }
+    }
+    __syncthreads();
+    f = f_sh;
+  }
+  const T* xb = a.x + (int64_t)b * a.ldx;
+  constexpr int U = EPT / VEC;
+  constexpr int CH = EPT >= 8 ? 2 : 16 / EPT;  // entries per owned row and round
+  int32_t s[EPT], t[EPT];
+  int32_t longest = 0;
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const int64_t row = slice0 + (int64_t)(u * (int)blockDim.x + tid) * VEC + e;
+      const int64_t rr = row < n ? row : 0;
+      const int32_t s0 = a.crow[rr], t0 = a.crow[rr + 1];
+      s[u * VEC + e] = s0;
+      t[u * VEC + e] = row < n ? t0 : s0;  // rows past the end are empty
+      longest = max(longest, t[u * VEC + e] - s0);
+    }
+  T yr[EPT];
+#pragma unroll
+  for (int r = 0; r < EPT; ++r) yr[r] = T(0);
+  for (int32_t o = 0; o < longest; o += CH) {
+    int32_t c[EPT][CH];
+    T v[EPT][CH];
+#pragma unroll
+    for (int r = 0; r < EPT; ++r)
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int32_t ee = s[r] + o + i;
+        const bool ok = ee < t[r];
+        const int32_t e1 = ok ? ee : 0;  // entry 0 exists whenever the loop runs
+        c[r][i] = a.col[e1];
+        const T vv = a.perm ? a.val[a.perm[e1]] : a.val[e1];
+        v[r][i] = ok ? vv : T(0);
+      }
+#pragma unroll
+    for (int r = 0; r < EPT; ++r)
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        T xv = xb[c[r][i]];
+        if constexpr (PRE) xv *= f;
+        yr[r] += v[r][i] * xv;
+      }
+  }
+  store_own<T, VEC>(yr, a.y + (int64_t)b * a.ldy, slice0, n, tid);
+  if constexpr (PRE) {
+    T q[EPT];
+    load_own<T, VEC>(q, xb, slice0, n, tid);
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) q[r] *= f;
+    store_own<T, VEC>(q, a.qout + (int64_t)b * a.ldq, slice0, n, tid);
+  }
+  if constexpr (DOTS) {
+    constexpr int JT = RowsInFlight<EPT>::value;
+    const int m = a.m;
+    sweep_rows<T, VEC, EPT, JT>(a.rows + (int64_t)b * a.rows_ldb, a.row_stride, 0, m, slice0, n, tid,
+                                [&](int j, const T (&row)[JT][EPT], int nvalid) {
+                                  T acc[JT];
+#pragma unroll
+                                  for (int q = 0; q < JT; ++q) {
+                                    acc[q] = T(0);
+#pragma unroll
+                                    for (int e = 0; e < EPT; ++e) acc[q] += row[q][e] * yr[e];
+                                  }
+                                  const T wsum = wave_sums<JT>(acc, lane);
+                                  const int q = row16_index<JT>(lane);
+                                  if (wave_sums_writer<JT>(lane) && q < nvalid) sm[wid * m + j + q] = wsum;
+                                });
+    __syncthreads();
+    for (int j = tid; j < m; j += (int)blockDim.x) {
+      T sum = T(0);
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sum += sm[w * m + j];
+      a.partial[((int64_t)b * a.kmax + j) * a.nblk + blk] = sum;
+    }
+  }
+}
+
 struct KrylovWs {
   void *w, *p1, *p2, *pn, *small, *opws;
   void* pb;  // partials of a batch of dQ columns (adjoint, few-slice problems), null when the columns go one by one
@@ -335,6 +465,44 @@ static int64_t carve_ws(const mfx_operator* op, int64_t n, int64_t k, int64_t p,
   }
   if (out) *out = r;
   return cv.off;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused CSR step head (k_csr_step): when it applies, and its launcher
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+static bool csr_fusable(const mfx_operator* op, const Ctx<T>& c, int transpose) {
+  // MFX_CSR_FUSED: 0 = never, 1 = only few-slice problems (launch-bound regime), 2 (default) = every CSR problem
+  static const int mode = [] { const char* e = getenv("MFX_CSR_FUSED"); return e ? atoi(e) : 2; }();
+  if (mode == 0 || op->kind != MFX_OP_CSR || c.comm || op->nrows != 0) return false;
+  if (!op->crow || !op->col || !op->val || op->nnz < 1) return false;
+  if (transpose && !(op->t_crow && op->t_col && op->t_perm)) return false;
+  return mode >= 2 || (int64_t)c.nblk * c.p < 256;
+}
+
+template <typename T>
+static int launch_csr_step(const Ctx<T>& c, const mfx_operator* op, int transpose, CsrStepArgs<T> a, bool pre, bool dots) {
+  a.crow = transpose ? op->t_crow : op->crow;
+  a.col = transpose ? op->t_col : op->col;
+  a.perm = transpose ? op->t_perm : nullptr;
+  a.val = static_cast<const T*>(op->val);
+  a.n = c.n;
+  a.kmax = c.kmax;
+  a.nblk = c.nblk;
+  a.nblk_in = c.nblk_in;
+  ScopedTimer t(0, c.stream);
+  const size_t sh = dots ? (size_t)4 * a.m * sizeof(T) : 0;
+  if (pre && dots) {
+    MFX_VEC_EPT_SWITCH(c, (k_csr_step<T, VEC, EPT, true, true><<<c.grid(), c.wg, sh, c.stream>>>(a)));
+  } else if (pre) {
+    MFX_VEC_EPT_SWITCH(c, (k_csr_step<T, VEC, EPT, true, false><<<c.grid(), c.wg, sh, c.stream>>>(a)));
+  } else if (dots) {
+    MFX_VEC_EPT_SWITCH(c, (k_csr_step<T, VEC, EPT, false, true><<<c.grid(), c.wg, sh, c.stream>>>(a)));
+  } else {
+    MFX_VEC_EPT_SWITCH(c, (k_csr_step<T, VEC, EPT, false, false><<<c.grid(), c.wg, sh, c.stream>>>(a)));
+  }
+  MFX_CHECK_LAUNCH();
+  return MFX_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -412,15 +580,34 @@ static int arnoldi_forward_t(const mfx_operator* op, const T* v0, int64_t n, int
     MFX_TRY(launch_scale<T>(c, v0, n, Q, ldq, PN, nullptr, 0, nullptr, 0, cinv));  // q_0, c = 1/|v|
   }
   T* w = r;  // the running vector lives in the remainder output (arnoldi.py:75 returns it as r)
+  // CSR operator, few slices: normalisation of the previous step, operator application and h = Q^T w in one launch
+  // (k_csr_step).  The un-normalised w of step i - 1 is the input of step i, so w alternates between r and a scratch
+  // vector, arranged so that the last step ends in r.
+  const bool fused = csr_fusable<T>(op, c, 0);
+  T* const scratch_w = static_cast<T*>(ws.w);
   for (int64_t i = 0; i < k; ++i) {
     const int m = (int)(i + 1);
-    if (comm) {
+    if (fused) {
+      T* const w_prev = w;
+      w = (((i ^ (k - 1)) & 1) != 0) ? scratch_w : r;
+      CsrStepArgs<T> cs{};
+      cs.y = w; cs.ldy = n;
+      cs.rows = Q; cs.rows_ldb = ldq; cs.row_stride = n; cs.m = m; cs.partial = P1;
+      if (i == 0) {
+        cs.x = Q; cs.ldx = ldq;
+        MFX_TRY(launch_csr_step<T>(c, op, 0, cs, false, true));
+      } else {  // q_i = w / |w|, H[i][i-1] = |w| (arnoldi.py:80,99) from the norm partials of step i - 1
+        cs.x = w_prev; cs.ldx = n;
+        cs.partial_norm = PN; cs.qout = Q + i * n; cs.ldq = ldq; cs.len_out = H + i * k + (i - 1); cs.len_ld = k * k;
+        MFX_TRY(launch_csr_step<T>(c, op, 0, cs, true, true));
+      }
+    } else if (comm) {
       MFX_TRY(apply_sharded<T>(op, comm, 0, Q + i * n, ldq, w, n, p, Qfull + i * op->n, k * op->n, ws, stream));
     } else {
       MFX_TRY(apply_any(op, 0, Q + i * n, ldq, nullptr, 0, w, n, p, ws.opws, ws.opws_bytes, stream));
     }
     ScopedTimer t(2, stream);
-    MFX_TRY(launch_dots<T>(c, Q, ldq, n, m, w, n, P1));
+    if (!fused) MFX_TRY(launch_dots<T>(c, Q, ldq, n, m, w, n, P1));
     UpdateArgs<T> a{};
     a.rows = Q; a.rows_ldb = ldq; a.row_stride = n; a.m = m;
     a.partial_in = P1; a.s1 = T(1);
@@ -437,7 +624,7 @@ static int arnoldi_forward_t(const mfx_operator* op, const T* v0, int64_t n, int
     } else {
       MFX_TRY(launch_update<T>(c, a, false, true));
     }
-    if (i + 1 < k) {  // Q2: H[k][k-1] does not exist; the last vector stays un-normalised in r
+    if (i + 1 < k && !fused) {  // Q2: H[k][k-1] does not exist; the last vector stays un-normalised in r
       MFX_TRY(launch_scale<T>(c, w, n, Q + (i + 1) * n, ldq, PN, nullptr, 0, H + (i + 1) * k + i, k * k, nullptr));
     }
   }
@@ -459,6 +646,7 @@ static int arnoldi_adjoint_t(const mfx_operator* op, int64_t n, int64_t k, int64
   T* pig = Gam + p * k * k;
   T* eta = pig + p * k * k;
   const int64_t ldq = k * n;
+  const bool fused = csr_fusable<T>(op, c, 1);
   MFX_CHECK_HIP(hipMemsetAsync(Gam, 0, sizeof(T) * p * k * k, stream));
   {
     ScopedTimer t(2, stream);
@@ -502,13 +690,18 @@ static int arnoldi_adjoint_t(const mfx_operator* op, int64_t n, int64_t k, int64
       }
     }
     // z = A^T lambda (+ parameter gradient for callback operators), arnoldi.py:207-209
-    if (comm) {
+    if (fused) {  // z = A^T lambda and z^T Q (arnoldi.py:207-212) in one launch
+      CsrStepArgs<T> cs{};
+      cs.x = lam_idx; cs.ldx = ldq; cs.y = z; cs.ldy = n;
+      cs.rows = Q; cs.rows_ldb = ldq; cs.row_stride = n; cs.m = (int)(idx + 1); cs.partial = P1;
+      MFX_TRY(launch_csr_step<T>(c, op, 1, cs, false, true));
+    } else if (comm) {
       MFX_TRY(apply_sharded<T>(op, comm, 1, lam_idx, ldq, z, n, p, static_cast<T*>(ws.xfull), op->n, ws, stream));
     } else {
       MFX_TRY(apply_any(op, 1, lam_idx, ldq, Q + idx * n, ldq, z, n, p, ws.opws, ws.opws_bytes, stream));
     }
     ScopedTimer t(2, stream);
-    MFX_TRY(launch_dots<T>(c, Q, ldq, n, (int)(idx + 1), z, n, P1));
+    if (!fused) MFX_TRY(launch_dots<T>(c, Q, ldq, n, (int)(idx + 1), z, n, P1));
     CombineArgs<T> ca{Q, Lam, H, pig, eta, r, dQ, z, P1, Gam, lam, n, (int)k, (int)idx, c.kmax, c.nblk_in};
     const size_t sh = (size_t)2 * k * sizeof(T);
     MFX_VEC_EPT_SWITCH(c, (k_adj_combine<T, VEC, EPT><<<c.grid(), c.wg, sh, stream>>>(ca)));
@@ -536,6 +729,7 @@ template <typename T>
 static int lanczos_forward_t(const mfx_operator* op, const T* v0, int64_t n, int64_t k, int64_t p, T* xs,
                              T* alpha, T* beta, T* vnorm, const KrylovWs& ws, hipStream_t stream) {
   Ctx<T> c(n, k, p, pick_vec<T>(n, {v0, xs, ws.w}), stream);
+  c.fine();
   T* P1 = static_cast<T*>(ws.p1);
   T* P2 = static_cast<T*>(ws.p2);
   T* PN = static_cast<T*>(ws.pn);
@@ -551,12 +745,32 @@ static int lanczos_forward_t(const mfx_operator* op, const T* v0, int64_t n, int
     MFX_TRY(launch_sumsq<T>(c, v0, n, PN));
     MFX_TRY(launch_scale<T>(c, v0, n, xs, ldx, PN, nullptr, 0, vnorm, 1, nullptr));
   }
+  // CSR operator, few slices: x_i = w / |w|, b_{i-1} = |w|, A x_i and a = x_i . A x_i in one launch (k_csr_step); w alternates
+  // between the two scratch vectors because the un-normalised w of step i - 1 is the input of step i.
+  const bool fused = csr_fusable<T>(op, c, 0);
+  T* const w0 = w;
   for (int64_t i = 0; i < k; ++i) {
-    MFX_TRY(apply_any(op, 0, xs + i * n, ldx, nullptr, 0, w, n, p, ws.opws, ws.opws_bytes, stream));
-    ScopedTimer t(2, stream);
     const int m = i == 0 ? 1 : 2;
     T* P = i == 0 ? P2 : P1;
-    MFX_TRY(launch_dots<T>(c, xs + i * n, ldx, n, 1, w, n, P + (m - 1) * c.nblk));  // a = x_i . A x_i
+    if (fused) {
+      T* const w_prev = w;
+      w = (i & 1) ? w0 + p * n : w0;
+      CsrStepArgs<T> cs{};
+      cs.y = w; cs.ldy = n;
+      cs.rows = xs + i * n; cs.rows_ldb = ldx; cs.row_stride = n; cs.m = 1; cs.partial = P + (m - 1) * c.nblk;
+      if (i == 0) {
+        cs.x = xs; cs.ldx = ldx;
+        MFX_TRY(launch_csr_step<T>(c, op, 0, cs, false, true));
+      } else {
+        cs.x = w_prev; cs.ldx = n;
+        cs.partial_norm = PN; cs.qout = xs + i * n; cs.ldq = ldx; cs.len_out = beta + (i - 1); cs.len_ld = k;
+        MFX_TRY(launch_csr_step<T>(c, op, 0, cs, true, true));
+      }
+    } else {
+      MFX_TRY(apply_any(op, 0, xs + i * n, ldx, nullptr, 0, w, n, p, ws.opws, ws.opws_bytes, stream));
+    }
+    ScopedTimer t(2, stream);
+    if (!fused) MFX_TRY(launch_dots<T>(c, xs + i * n, ldx, n, 1, w, n, P + (m - 1) * c.nblk));  // a = x_i . A x_i
     UpdateArgs<T> a{};
     a.rows = xs + (i == 0 ? 0 : (i - 1) * n); a.rows_ldb = ldx; a.row_stride = n; a.m = m;
     a.partial_in = P; a.s1 = T(1);
@@ -564,7 +778,7 @@ static int lanczos_forward_t(const mfx_operator* op, const T* v0, int64_t n, int
     a.hout = alpha + i; a.hout_ldb = k; a.hout_stride = 0; a.hout_from = m - 1;
     a.x = w; a.ldx = n; a.y = w; a.ldy = n; a.partial_norm = PN;
     MFX_TRY(launch_update<T>(c, a, false, true));
-    MFX_TRY(launch_scale<T>(c, w, n, xs + (i + 1) * n, ldx, PN, nullptr, 0, beta + i, k, nullptr));
+    if (!fused || i + 1 == k) MFX_TRY(launch_scale<T>(c, w, n, xs + (i + 1) * n, ldx, PN, nullptr, 0, beta + i, k, nullptr));
   }
   return MFX_OK;
 }
