@@ -69,6 +69,10 @@ struct CombineArgs {
   T* out;
   int64_t n;
   int k, idx, kmax, nblk;
+  // fused epilogue: partial_out[b][j][slice] = q_j . out, j < m_out -- the re-projection dots of the NEXT step (arnoldi.py:204),
+  // whose lambda this kernel has just produced; null = none
+  T* partial_out;
+  int m_out, nblk_out;
 };
 
 template <typename T, int VEC, int EPT>
@@ -76,7 +80,8 @@ __global__ __launch_bounds__(kBlock) void k_adj_combine(CombineArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* g = reinterpret_cast<T*>(smem_raw);  // [k]
   T* hp = g + a.k;                         // [k]
-  const int tid = threadIdx.x;
+  T* sm = hp + a.k;                        // [4][m_out] (fused dots)
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int b = blockIdx.y, blk = blockIdx.x;
   const int k = a.k, idx = a.idx;
   const int64_t kk = (int64_t)k * k;
@@ -142,6 +147,27 @@ __global__ __launch_bounds__(kBlock) void k_adj_combine(CombineArgs<T> a) {
 #pragma unroll
   for (int e = 0; e < EPT; ++e) acc[e] *= inv;
   store_own<T, VEC>(acc, a.out + (int64_t)b * n, slice0, n, tid);
+  if (a.partial_out) {
+    const int m = a.m_out;
+    sweep_rows<T, VEC, EPT, JT>(Qb, n, 0, m, slice0, n, tid, [&](int j, const T (&row)[JT][EPT], int nvalid) {
+      T d[JT];
+#pragma unroll
+      for (int q = 0; q < JT; ++q) {
+        d[q] = T(0);
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) d[q] += row[q][e] * acc[e];
+      }
+      const T wsum = wave_sums<JT>(d, lane);
+      const int q = row16_index<JT>(lane);
+      if (wave_sums_writer<JT>(lane) && q < nvalid) sm[wid * m + j + q] = wsum;
+    });
+    __syncthreads();
+    for (int j = tid; j < m; j += (int)blockDim.x) {
+      T sum = T(0);
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sum += sm[w * m + j];
+      a.partial_out[((int64_t)b * a.kmax + j) * a.nblk_out + blk] = sum;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -640,6 +666,7 @@ static int arnoldi_adjoint_t(const mfx_operator* op, int64_t n, int64_t k, int64
   if (comm) c.shard(comm, static_cast<T*>(ws.stage));
   c.fine();
   T* P1 = static_cast<T*>(ws.p1);
+  T* P2 = static_cast<T*>(ws.p2);
   T* lam = static_cast<T*>(ws.w);  // current lambda (p, n)
   T* z = lam + p * n;              // A^T lambda     (p, n)
   T* Gam = static_cast<T*>(ws.small);
@@ -669,15 +696,17 @@ static int arnoldi_adjoint_t(const mfx_operator* op, int64_t n, int64_t k, int64
     a.rows = Q; a.rows_ldb = ldq; a.row_stride = n; a.m = (int)k;
     a.extra = eta; a.extra_ldb = k; a.extra_stride = 1; a.s2 = T(-1);
     a.x = dr; a.ldx = n; a.y = lam; a.ldy = n;
-    MFX_TRY(launch_update<T>(c, a, false, false));
+    // full re-orthogonalisation: whoever produces a lambda also takes its dots with the basis (Q^T lambda, arnoldi.py:204),
+    // the first thing the next step needs -- here for step k - 1 (all k rows), then in the epilogue of k_adj_combine
+    a.partial_out = P1;
+    MFX_TRY(launch_update<T>(c, a, reortho == MFX_REORTHO_FULL, false));
   }
   for (int64_t idx = k - 1; idx >= 0; --idx) {
     T* lam_idx = Lam + idx * n;  // Lambda[:, idx] (arnoldi.py:216), leading dimension ldq
     {
       ScopedTimer t(2, stream);
       if (reortho == MFX_REORTHO_FULL) {
-        const int m = (int)((idx + 2 < k) ? idx + 2 : k);  // rows of P not yet masked (arnoldi.py:201)
-        MFX_TRY(launch_dots<T>(c, Q, ldq, n, m, lam, n, P1));
+        const int m = (int)((idx + 2 < k) ? idx + 2 : k);  // rows of P not yet masked (arnoldi.py:201); their dots are in P1
         UpdateArgs<T> a{};
         a.rows = Q; a.rows_ldb = ldq; a.row_stride = n; a.m = m;
         a.partial_in = P1; a.s1 = T(1);
@@ -693,7 +722,7 @@ static int arnoldi_adjoint_t(const mfx_operator* op, int64_t n, int64_t k, int64
     if (fused) {  // z = A^T lambda and z^T Q (arnoldi.py:207-212) in one launch
       CsrStepArgs<T> cs{};
       cs.x = lam_idx; cs.ldx = ldq; cs.y = z; cs.ldy = n;
-      cs.rows = Q; cs.rows_ldb = ldq; cs.row_stride = n; cs.m = (int)(idx + 1); cs.partial = P1;
+      cs.rows = Q; cs.rows_ldb = ldq; cs.row_stride = n; cs.m = (int)(idx + 1); cs.partial = P2;
       MFX_TRY(launch_csr_step<T>(c, op, 1, cs, false, true));
     } else if (comm) {
       MFX_TRY(apply_sharded<T>(op, comm, 1, lam_idx, ldq, z, n, p, static_cast<T*>(ws.xfull), op->n, ws, stream));
@@ -701,11 +730,16 @@ static int arnoldi_adjoint_t(const mfx_operator* op, int64_t n, int64_t k, int64
       MFX_TRY(apply_any(op, 1, lam_idx, ldq, Q + idx * n, ldq, z, n, p, ws.opws, ws.opws_bytes, stream));
     }
     ScopedTimer t(2, stream);
-    if (!fused) MFX_TRY(launch_dots<T>(c, Q, ldq, n, (int)(idx + 1), z, n, P1));
-    CombineArgs<T> ca{Q, Lam, H, pig, eta, r, dQ, z, P1, Gam, lam, n, (int)k, (int)idx, c.kmax, c.nblk_in};
-    const size_t sh = (size_t)2 * k * sizeof(T);
+    if (!fused) MFX_TRY(launch_dots<T>(c, Q, ldq, n, (int)(idx + 1), z, n, P2));
+    CombineArgs<T> ca{Q, Lam, H, pig, eta, r, dQ, z, P2, Gam, lam, n, (int)k, (int)idx, c.kmax, c.nblk_in, nullptr, 0, c.nblk};
+    if (reortho == MFX_REORTHO_FULL && idx > 0) {  // dots of the lambda of step idx - 1: rows min(idx + 1, k)
+      ca.partial_out = c.producer(P1);
+      ca.m_out = (int)((idx + 1 < k) ? idx + 1 : k);
+    }
+    const size_t sh = (size_t)(2 * k + 4 * ca.m_out) * sizeof(T);
     MFX_VEC_EPT_SWITCH(c, (k_adj_combine<T, VEC, EPT><<<c.grid(), c.wg, sh, stream>>>(ca)));
     MFX_CHECK_LAUNCH();
+    if (ca.partial_out) MFX_TRY(c.finish(P1, c.kmax, ca.m_out));
   }
   {
     ScopedTimer t(2, stream);
