@@ -670,3 +670,28 @@ def test_slq_value_and_gradient_are_bit_reproducible():
         assert torch.equal(outs[0][0], outs[1][0])
         for a, b in zip(outs[0][1], outs[1][1]):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("m", [24, 23])  # n = 576 (16-byte vector loads) and n = 529 (odd: scalar loads)
+@pytest.mark.parametrize("reortho", ["full", "none"])
+@pytest.mark.parametrize("dtype,vtol,gtol", [(torch.float64, 1e-10, 1e-7), (torch.float32, 2e-4, 5e-3)])
+def test_slq_csr_several_probes(m, reortho, dtype, vtol, gtol):
+    """SLQ integrand over a batch of probes on the native CSR operator (fused step head k_csr_step, grid.y = probes):
+    value per probe and the gradient w.r.t. all stored values of the summed estimate, against the oracle probe by probe."""
+    r, c, vals, n = orc.laplacian_2d_plus_identity(m)
+    k, p = 7, 5
+    probes = orc.rademacher(3, p, n)
+    o = orc.CooOp(r, c, n)
+    ref_vals, ref_grad = [], 0.0
+    for v in probes:
+        val, _dv, (dp,) = orc.integrand_spd_value_and_grad(o, k, v, (vals,), reortho=reortho)
+        ref_vals.append(val)
+        ref_grad = ref_grad + dp
+    op, vt, order = CsrOp.from_coo(r, c, vals, n, DEV)
+    vt = vt.to(dtype).requires_grad_(True)
+    integrand = lanczos.integrand_spd(torch.log, k, op, reortho=reortho)
+    out = integrand(T(probes, dtype), vt)
+    assert close(out, np.asarray(ref_vals), vtol)
+    (g,) = torch.autograd.grad(out.sum(), vt)
+    ref = ref_grad[order.numpy()]
+    assert close(g, ref, gtol, atol_rel=gtol)
