@@ -502,6 +502,7 @@ static bool csr_fusable(const mfx_operator* op, const Ctx<T>& c, int transpose) 
   static const int mode = [] { const char* e = getenv("MFX_CSR_FUSED"); return e ? atoi(e) : 2; }();
   if (mode == 0 || op->kind != MFX_OP_CSR || c.comm || op->nrows != 0) return false;
   if (!op->crow || !op->col || !op->val || op->nnz < 1) return false;
+  if (op->nnz > 24 * op->n) return false;  // one thread walks a whole row there: long rows belong to the 8-lanes-per-row kernel
   if (transpose && !(op->t_crow && op->t_col && op->t_perm)) return false;
   return mode >= 2 || (int64_t)c.nblk * c.p < 256;
 }

@@ -1270,7 +1270,7 @@ constexpr int kHLd = kHM + 4;
 //   NBW = 2: 256 x 128 (round 1);  NBW = 4: 256 x 256 -- (256 + 256) instead of 2 x (256 + 128) operand columns through L2 -> LDS
 //   per stage and per 256 x 256 of S, i.e. a third less of the traffic this kernel is bound by.  Its 128 accumulator registers
 //   fit since the fp32 master accumulators are gone (see the note on the floor bias below).
-template <int DPAD, int NBW>
+template <int DPAD, int NBW, bool REGEPI = false>
 struct GradSmemH {
   static constexpr int TN = 2 * NBW * 32;  // columns of the workgroup tile
   union {
@@ -1287,6 +1287,7 @@ struct GradSmemH {
   float xj[kGN][DPAD];
   float sqj[kGN];
   float sgj[kGN];  // tau_j of the staged columns (+-1)
+  float bq[REGEPI ? DPAD + 2 : 1][REGEPI ? TN : 1];  // register epilogue: B' = [x_j, 1, |x_j|^2] of the tile's columns, k-major
   double red[8][DPAD + 2];
 };
 
@@ -1299,7 +1300,7 @@ struct GradSmemH {
 // gradient is 9.8e-6 / 3.0e-5 off fp64, without either 2.2e-2 / 5.6e-2 (profiles/r02h_*) -- so the chunks and the master
 // accumulators are gone, which is what makes room for the 256 x 256 tile.
 
-template <int DPAD, int NBW>
+template <int DPAD, int NBW, bool REGEPI>
 __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restrict__ xs, const float* __restrict__ sq,
                                                             int64_t n, int64_t npad_l, int64_t npad_r, int ard, int kind,
                                                             const _Float16* __restrict__ Lh, const _Float16* __restrict__ Ll,
@@ -1308,7 +1309,7 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
                                                             uint32_t salt_l, uint32_t salt_r, double* __restrict__ partial,
                                                             int64_t row0, int64_t nrow) {
   // rows: the nrow points row0 .. of X that the L operand covers (a row shard, or all n); columns: all n points
-  using Smem = GradSmemH<DPAD, NBW>;
+  using Smem = GradSmemH<DPAD, NBW, REGEPI>;
   constexpr int TN = Smem::TN;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   Smem& sm = *reinterpret_cast<Smem*>(smem_raw);
@@ -1330,9 +1331,10 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
   }
   if (tid < kHM) sm.sqi[tid] = (i0 + tid < nrow) ? sq[row0 + i0 + tid] : 0.f;
 
-  double gsum[DPAD + 2];
+  constexpr int NG = REGEPI ? 3 : DPAD + 2;  // register epilogue: (lengthscale, outputscale, noise)
+  double gsum[NG];
 #pragma unroll
-  for (int c = 0; c < DPAD + 2; ++c) gsum[c] = 0.0;
+  for (int c = 0; c < NG; ++c) gsum[c] = 0.0;
 
   // staging by LDS-DMA: per stage 2 kb-groups x (256 | TN) columns x 16 B per operand piece, chunk c lives at byte 16 c of its
   // piece: no staging registers.  Addresses are 32-bit byte offsets from the (scalar) piece bases, advanced by one constant
@@ -1377,12 +1379,17 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     uint32_t ol = offL, orr = offR0 + (uint32_t)(j0 * 16);
-    __syncthreads();  // previous tile's epilogue reads of the overlaid S^T tile are done
+    if (!REGEPI || tj == tj_begin) {
+      __syncthreads();  // previous tile's epilogue reads of the overlaid S^T tile are done
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      if (q < nstage) issue_stage(ol, orr, q);
-      ol += stage_bytes_l;
-      orr += stage_bytes_r;
+      for (int q = 0; q < 3; ++q) {
+        if (q < nstage) issue_stage(ol, orr, q);
+        ol += stage_bytes_l;
+        orr += stage_bytes_r;
+      }
+    } else {  // REGEPI: the first three stages of this tile were issued before the previous tile's epilogue
+      ol += 3 * stage_bytes_l;
+      orr += 3 * stage_bytes_r;
     }
     for (int64_t st = 0; st < nstage; ++st) {
       const int slot = (int)(st & 3);
@@ -1421,6 +1428,106 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
           }
       }
     }
+    if constexpr (REGEPI) {
+      // Everything below that depends only on the workgroup's rows is invariant over the tile loop; hoisted out of it, it
+      // would sit in registers through the K-loop, which has none to spare (measured: 380 B of spills, one reload per stage,
+      // +14 % run time).  `z` is a zero the compiler cannot see through, renewed per tile.
+      int z;
+      asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+      // ---- register epilogue (one lengthscale): the kernel entries are formed IN THE ACCUMULATOR LAYOUT -- the distance block
+      //      D = A' B'^T with A' = [-2 x_i, |x_i|^2, 1], B' = [x_j, 1, |x_j|^2] on the fp32 MFMA (lane = column j, register r
+      //      <-> row i, exactly like acc) -- so S o dK is 16 elementwise products per block: no S^T through LDS, no barriers,
+      //      and the ring is free, so the next tile's first stages are in flight while this runs.
+      constexpr int KS = (DPAD + 2) / 2;
+      // (bq of the previous tile: every wave has passed at least one K-loop barrier since it read it)
+      uint32_t taub[NBW];
+#pragma unroll
+      for (int b = 0; b < NBW; ++b) taub[b] = grad_col_sign(j0 + wn * (NBW * 32) + b * 32 + l31, salt_r) ? 1u : 0u;
+      for (int t = tid; t < TN * (DPAD + 2); t += 512) {  // B' of the tile's columns (xs is a few MB: L2), BEFORE the prefetch
+        const int col = t % TN, c = t / TN;
+        const int64_t j = j0 + col;
+        float v = 0.f;
+        if (c < DPAD) v = j < n ? xs[j * DPAD + c] : 0.f;
+        else if (c == DPAD) v = 1.f;
+        else v = j < n ? sq[j] : 0.f;
+        sm.bq[c][col] = v;
+      }
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): my bq writes have landed (the DMA counter is left alone)
+      __builtin_amdgcn_s_barrier();        // every wave is done reading the last stages of this tile, and bq is complete
+      if (tj + 1 < tj_end) {
+        uint32_t nl = offL, nr = offR0 + (uint32_t)((j0 + TN) * 16);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          if (q < nstage) issue_stage(nl, nr, q);
+          nl += stage_bytes_l;
+          nr += stage_bytes_r;
+        }
+      }
+      const bool diag_tile = (row0 + i0 < j0 + TN) && (j0 < row0 + i0 + kHM);
+      float gl = 0.f, gs = 0.f, gn = 0.f;
+      // one straight-line copy of the body per (kernel family, tile meets the diagonal): with `kind` and the diagonal test as
+      // run-time branches inside the 256 unrolled entries the compiler spills 1.7 KB per lane
+      auto body = [&](auto kind_c, auto diag_c) {
+        constexpr int KIND = decltype(kind_c)::value;
+        constexpr bool DIAG = decltype(diag_c)::value;
+        int dj[NBW];  // column of block b's lane, relative to the first row of the workgroup's tile
+#pragma unroll
+        for (int b = 0; b < NBW; ++b) dj[b] = (int)(j0 + wn * (NBW * 32) + b * 32 + l31 - (row0 + i0));
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const int il = wm * 64 + a * 32 + l31 + z;
+          float ai[KS];
+#pragma unroll
+          for (int sI = 0; sI < KS; ++sI) {
+            const int c = 2 * sI + lhi;
+            ai[sI] = c < DPAD ? -2.f * sm.xi[il][c < DPAD ? c : 0] : (c == DPAD ? sm.sqi[il] : 1.f);
+          }
+          uint32_t sgbits = 0;  // bit r = sigma of the row of register r
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            sgbits |= (grad_col_sign(i0 + z + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi, salt_l) ? 1u : 0u) << r;
+#pragma unroll
+          for (int b = 0; b < NBW; ++b) {
+            floatx16 D;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) D[r] = 0.f;
+            // one distance block in flight: its first operand waits (through an opaque move) for the sums of the previous
+            // block -- otherwise the optimiser gathers the MFMAs of all blocks up front: 16 live registers each, spills
+            float a0 = ai[0];
+            asm volatile("" : "+v"(a0), "+v"(gs), "+v"(gl));
+#pragma unroll
+            for (int sI = 0; sI < KS; ++sI)
+              D = __builtin_amdgcn_mfma_f32_32x32x2f32(sI == 0 ? a0 : ai[sI], sm.bq[2 * sI + lhi][wn * (NBW * 32) + b * 32 + l31], D, 0,
+                                                       0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              float dist = fmaxf(D[r], 0.f);
+              // sigma_i tau_j S_ij -> S_ij: flip the sign bit
+              const float s_ij = __uint_as_float(__float_as_uint(acc[a][b][r]) ^ ((((sgbits >> r) & 1u) ^ taub[b]) << 31));
+              if constexpr (DIAG) {
+                const bool on = dj[b] == wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                dist = on ? 0.f : dist;
+                gn += on ? s_ij : 0.f;
+              }
+              float kv, wl;
+              grad_weights(KIND, dist, kv, wl);
+              gs = fmaf(s_ij, kv, gs);
+              gl = fmaf(s_ij * wl, dist, gl);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // one distance block at a time: 16 registers, not 16 per block of the tile
+          }
+        }
+      };
+      auto by_kind = [&](auto diag_c) {
+        if (kind == MFX_KERNEL_RBF) body(std::integral_constant<int, MFX_KERNEL_RBF>{}, diag_c);
+        else if (kind == MFX_KERNEL_MATERN32) body(std::integral_constant<int, MFX_KERNEL_MATERN32>{}, diag_c);
+        else body(std::integral_constant<int, MFX_KERNEL_MATERN12>{}, diag_c);
+      };
+      if (diag_tile) by_kind(std::true_type{}); else by_kind(std::false_type{});
+      gsum[0] += (double)gl;
+      gsum[1] += (double)gs;
+      gsum[2] += (double)gn;
+    } else
     // ---- epilogue, in passes of 128 columns (the S^T overlay holds one pass): the waves whose blocks lie in the pass
     //      dump them, then thread = row i walks 64 of the pass's columns (as in k_rbf_mfma_grad) -------------------------
 #pragma unroll
@@ -1502,10 +1609,14 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
       for (int c = 0; c < DPAD + 2; ++c) gsum[c] += (double)gt[c];
     }
   }
+  if (tid < 8 * (DPAD + 2)) (&sm.red[0][0])[tid] = 0.0;
+  __syncthreads();
 #pragma unroll
-  for (int c = 0; c < DPAD + 2; ++c) {
+  for (int c = 0; c < NG; ++c) {
     const double v = wave_sum(gsum[c]);
-    if (lane == 0) sm.red[wid][c] = v;
+    // register epilogue: slots (0, DPAD, DPAD + 1) of the (DPAD + 2)-wide partial row, as the LDS epilogue fills them
+    const int slot = REGEPI ? (c == 0 ? 0 : DPAD - 1 + c) : c;
+    if (lane == 0) sm.red[wid][slot] = v;
   }
   __syncthreads();
   if (tid < DPAD + 2) {
@@ -1538,11 +1649,26 @@ static int launch_grad_h_t(const mfx_operator* op, const float* xs, const float*
   const int64_t nti = (nrow + kHM - 1) / kHM, ntj = (n + TN - 1) / TN;
   const int tiles_per_block = (int)((ntj + kGSplit * kGSub - 1) / (kGSplit * kGSub));
   const dim3 grid(kGSplit, (unsigned)(nti * kGSub));
-  const size_t sh = sizeof(GradSmemH<DPAD, NBW>);
-  MFX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rbf_mfma_grad_h<DPAD, NBW>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-  k_rbf_mfma_grad_h<DPAD, NBW><<<grid, 512, sh, stream>>>(xs, sq, n, npad_l, npad, op->ard, op->kernel_fn, Lh, Ll, Rh, Rl, bpad / 8,
-                                                          tiles_per_block, salt_l, salt_r, partial, row0, nrow);
+  // one lengthscale, d <= 8: the register epilogue (MFX_GRAD_REGEPI=0: the LDS epilogue, A/B)
+  static const bool regepi_on = [] { const char* e = getenv("MFX_GRAD_REGEPI"); return e ? atoi(e) != 0 : true; }();
+  bool launched = false;
+  if constexpr (DPAD <= 8) {
+    if (!op->ard && regepi_on) {
+      const size_t sh = sizeof(GradSmemH<DPAD, NBW, true>);
+      MFX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rbf_mfma_grad_h<DPAD, NBW, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+      k_rbf_mfma_grad_h<DPAD, NBW, true><<<grid, 512, sh, stream>>>(xs, sq, n, npad_l, npad, op->ard, op->kernel_fn, Lh, Ll, Rh, Rl,
+                                                                    bpad / 8, tiles_per_block, salt_l, salt_r, partial, row0, nrow);
+      launched = true;
+    }
+  }
+  if (!launched) {
+    const size_t sh = sizeof(GradSmemH<DPAD, NBW, false>);
+    MFX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rbf_mfma_grad_h<DPAD, NBW, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    k_rbf_mfma_grad_h<DPAD, NBW, false><<<grid, 512, sh, stream>>>(xs, sq, n, npad_l, npad, op->ard, op->kernel_fn, Lh, Ll, Rh, Rl,
+                                                                   bpad / 8, tiles_per_block, salt_l, salt_r, partial, row0, nrow);
+  }
   MFX_CHECK_LAUNCH();
   *nblocks_out = nti * kGSub * kGSplit;
   return MFX_OK;
