@@ -150,14 +150,14 @@ __global__ __launch_bounds__(kBlock) void k_adj_combine(CombineArgs<T> a) {
   if (a.partial_out) {
     const int m = a.m_out;
     sweep_rows<T, VEC, EPT, JT>(Qb, n, 0, m, slice0, n, tid, [&](int j, const T (&row)[JT][EPT], int nvalid) {
-      T d[JT];
+      DotAcc<T> d[JT];
 #pragma unroll
       for (int q = 0; q < JT; ++q) {
-        d[q] = T(0);
+        d[q] = DotAcc<T>(0);
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) d[q] += row[q][e] * acc[e];
+        for (int e = 0; e < EPT; ++e) d[q] += (DotAcc<T>)row[q][e] * (DotAcc<T>)acc[e];
       }
-      const T wsum = wave_sums<JT>(d, lane);
+      const T wsum = (T)wave_sums<JT>(d, lane);
       const int q = row16_index<JT>(lane);
       if (wave_sums_writer<JT>(lane) && q < nvalid) sm[wid * m + j + q] = wsum;
     });
@@ -429,14 +429,14 @@ __global__ __launch_bounds__(kBlock) void k_csr_step(CsrStepArgs<T> a) {
     const int m = a.m;
     sweep_rows<T, VEC, EPT, JT>(a.rows + (int64_t)b * a.rows_ldb, a.row_stride, 0, m, slice0, n, tid,
                                 [&](int j, const T (&row)[JT][EPT], int nvalid) {
-                                  T acc[JT];
+                                  DotAcc<T> acc[JT];
 #pragma unroll
                                   for (int q = 0; q < JT; ++q) {
-                                    acc[q] = T(0);
+                                    acc[q] = DotAcc<T>(0);
 #pragma unroll
-                                    for (int e = 0; e < EPT; ++e) acc[q] += row[q][e] * yr[e];
+                                    for (int e = 0; e < EPT; ++e) acc[q] += (DotAcc<T>)row[q][e] * (DotAcc<T>)yr[e];
                                   }
-                                  const T wsum = wave_sums<JT>(acc, lane);
+                                  const T wsum = (T)wave_sums<JT>(acc, lane);
                                   const int q = row16_index<JT>(lane);
                                   if (wave_sums_writer<JT>(lane) && q < nvalid) sm[wid * m + j + q] = wsum;
                                 });

@@ -86,6 +86,21 @@ __device__ __forceinline__ T reduce_partials_group(const T* __restrict__ part, i
 }
 constexpr int kRedG = 8;  // lanes per coefficient in the multi-coefficient prologues
 
+// Accumulator type of the Gram-Schmidt dot products and norms inside a slice (products, per-thread sums, cross-lane tree): fp64
+// also for fp32 vectors.  The kernels are HBM-bound (C4: +1.3 ms of 48 ms per step), and at the C4 size the worst gradient
+// component against fp64 over four probe sets drops from 3.8e-5 ... 1.25e-4 to 1.2e-5 ... 6.0e-5 (profiles/r02a_accuracy/
+// table_other_probe_sets.log); what remains is the rounding of the fp32-stored vectors themselves.  -DMFX_DOTS_F64=0: fp32 (A/B).
+#ifndef MFX_DOTS_F64
+#define MFX_DOTS_F64 1
+#endif
+#if MFX_DOTS_F64
+template <typename T>
+using DotAcc = double;
+#else
+template <typename T>
+using DotAcc = T;
+#endif
+
 // Rows j0 <= j < j1 of a (rows, n) panel, this thread's elements of the slice, in order, JT rows at a time:
 // f(j, rows[JT][EPT], nvalid) --
 // double-buffered: the loads of the next JT rows are issued before the current JT are consumed, so a sweep is
@@ -185,14 +200,14 @@ __global__ __launch_bounds__(kBlock) void k_dots(const T* __restrict__ rows, int
       rows + (int64_t)b * rows_ldb, row_stride, j0, j1, slice0, n, tid, [&](int j, const T (&row)[JT][EPT], int nvalid) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
-          T acc[JT];  // all rows of the buffer in one block of straight-line code: the JT reductions interleave
+          DotAcc<T> acc[JT];  // all rows of the buffer in one block of straight-line code: the JT reductions interleave
 #pragma unroll
           for (int q = 0; q < JT; ++q) {
-            acc[q] = T(0);
+            acc[q] = DotAcc<T>(0);
 #pragma unroll
-            for (int e = 0; e < EPT; ++e) acc[q] += row[q][e] * xr[ct][e];
+            for (int e = 0; e < EPT; ++e) acc[q] += (DotAcc<T>)row[q][e] * (DotAcc<T>)xr[ct][e];
           }
-          const T wsum = wave_sums<JT>(acc, lane);
+          const T wsum = (T)wave_sums<JT>(acc, lane);
           const int q = row16_index<JT>(lane);
           if (wave_sums_writer<JT>(lane) && q < nvalid) sm[(wid * CT + ct) * jchunk + (j - j0) + q] = wsum;
         }
@@ -281,14 +296,14 @@ __global__ __launch_bounds__(kBlock) void k_update(UpdateArgs<T> a) {
   if (a.y2) store_own<T, VEC>(xr, a.y2 + (int64_t)b * a.ldy2, slice0, a.n, tid);
   if constexpr (DOTS) {
     sweep_rows<T, VEC, EPT, JT>(rb, a.row_stride, 0, m, slice0, a.n, tid, [&](int j, const T (&row)[JT][EPT], int nvalid) {
-      T acc[JT];
+      DotAcc<T> acc[JT];
 #pragma unroll
       for (int q = 0; q < JT; ++q) {
-        acc[q] = T(0);
+        acc[q] = DotAcc<T>(0);
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) acc[q] += row[q][e] * xr[e];
+        for (int e = 0; e < EPT; ++e) acc[q] += (DotAcc<T>)row[q][e] * (DotAcc<T>)xr[e];
       }
-      const T wsum = wave_sums<JT>(acc, lane);
+      const T wsum = (T)wave_sums<JT>(acc, lane);
       const int q = row16_index<JT>(lane);
       if (wave_sums_writer<JT>(lane) && q < nvalid) sm[wid * m + j + q] = wsum;
     });
@@ -302,11 +317,11 @@ __global__ __launch_bounds__(kBlock) void k_update(UpdateArgs<T> a) {
   }
   if constexpr (NORM) {
     T* smn = sm + (DOTS ? 4 * m : 0);
-    T acc = T(0);
+    DotAcc<T> acc = DotAcc<T>(0);
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) acc += xr[e] * xr[e];
+    for (int e = 0; e < EPT; ++e) acc += (DotAcc<T>)xr[e] * (DotAcc<T>)xr[e];
     acc = wave_sum(acc);
-    if (lane == 0) smn[wid] = acc;
+    if (lane == 0) smn[wid] = (T)acc;
     __syncthreads();
     if (tid == 0) {
       T sum = T(0);
@@ -327,11 +342,11 @@ __global__ __launch_bounds__(kBlock) void k_sumsq(const T* __restrict__ x, int64
   const int b = blockIdx.y, blk = blockIdx.x;
   T xr[EPT];
   load_own<T, VEC>(xr, x + (int64_t)b * ldx, (int64_t)blk * ((int64_t)blockDim.x * EPT), n, tid);
-  T acc = T(0);
+  DotAcc<T> acc = DotAcc<T>(0);
 #pragma unroll
-  for (int e = 0; e < EPT; ++e) acc += xr[e] * xr[e];
+  for (int e = 0; e < EPT; ++e) acc += (DotAcc<T>)xr[e] * (DotAcc<T>)xr[e];
   acc = wave_sum(acc);
-  if (lane == 0) smn[wid] = acc;
+  if (lane == 0) smn[wid] = (T)acc;
   __syncthreads();
   if (tid == 0) {
     T sum = T(0);

@@ -43,7 +43,10 @@ def _slq(X, raw, k, probes, precision):
 # ------------------------------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def c4_fp64():
-    n, d, k, p = 131072, 8, 40, 8
+    # the stated config: ALL 64 probes (32 s for the fp64 leg).  With 8 probes the comparison is dominated by the rounding noise of
+    # the fp32 Krylov recurrences, which averages out over the probes: the same build measured 1.4e-4 on dl with 8 probes and
+    # 3.8e-6 with 64 (profiles/r02a_accuracy).
+    n, d, k, p = 131072, 8, 40, 64
     gen = torch.Generator().manual_seed(4)
     X64 = torch.randn((n, d), generator=gen, dtype=torch.float32).double().to(DEV)
     raw = (INV(2.0), INV(1.0), INV(0.1))
@@ -53,8 +56,9 @@ def c4_fp64():
     return X64, raw, k, probes, val, grad
 
 
-# Measured (profiles/r02a_accuracy, 64 probes): value / worst gradient component
-#   f16x3 5.2e-6 / 2.8e-5, f16x3-matvec 5.2e-6 / 5.4e-5, fp32 (exact fp32 MFMA, the arithmetic closest to the reference's fp32) 7.6e-5 / 1.8e-3.
+# Measured (profiles/r02a_accuracy/table_end_of_round.log, 64 probes): value / worst gradient component
+#   f16x3 5.4e-6 / 1.2e-5, f16x3-matvec 5.4e-6 / 5.0e-5, fp32 (exact fp32 MFMA, the arithmetic closest to the reference's fp32) 7.6e-5 / 1.8e-3;
+#   three other probe sets: 1.8e-5 ... 7.2e-5 (table_other_probe_sets.log).
 @pytest.mark.parametrize("precision,vtol,gtol", [("f16x3", 1e-4, 1e-4), ("f16x3-matvec", 1e-4, 1e-4), ("fp32", 2e-4, 5e-3)])
 def test_c4_full_size_accuracy_gate(c4_fp64, precision, vtol, gtol):
     """north_star: "matching [...] to rtol 1e-4" on the C4 log-det value and gradient.  The two modes that run the Gram

@@ -27,6 +27,7 @@ ap.add_argument("--d", type=int, default=8)
 ap.add_argument("--k", type=int, default=40)
 ap.add_argument("--p", type=int, default=64)
 ap.add_argument("--tag", default="")
+ap.add_argument("--seed", type=int, default=0, help="key of the +-1 probes (0 = the committed tables)")
 ap.add_argument("--out", default="")
 ap.add_argument("--table", default="")
 args = ap.parse_args()
@@ -67,7 +68,7 @@ X = X64.to(dtype)
 params = [torch.tensor(v, dtype=dtype, device=dev, requires_grad=True) for v in raw]
 op = gp_util.gram_operator(X, precision="fp32" if args.mode == "f64" else args.mode)
 integrand = lanczos.integrand_spd(torch.log, args.k, op)
-probes = hutchinson.sampler_rademacher(X[:, 0], num=args.p)(0)
+probes = hutchinson.sampler_rademacher(X[:, 0], num=args.p)(args.seed)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 vals = integrand(probes, *params)
