@@ -1465,8 +1465,8 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
       }
       const bool diag_tile = (row0 + i0 < j0 + TN) && (j0 < row0 + i0 + kHM);
       float gl = 0.f, gs = 0.f, gn = 0.f;
-      // one straight-line copy of the body per (kernel family, tile meets the diagonal): with `kind` and the diagonal test as
-      // run-time branches inside the 256 unrolled entries the compiler spills 1.7 KB per lane
+      // one straight-line copy of the body per (tile meets the diagonal or not), kernel family fixed: with `kind` and the diagonal
+      // test as run-time branches inside the 256 unrolled entries the compiler spills 1.7 KB per lane
       auto body = [&](auto kind_c, auto diag_c) {
         constexpr int KIND = decltype(kind_c)::value;
         constexpr bool DIAG = decltype(diag_c)::value;
@@ -1518,12 +1518,10 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
           }
         }
       };
-      auto by_kind = [&](auto diag_c) {
-        if (kind == MFX_KERNEL_RBF) body(std::integral_constant<int, MFX_KERNEL_RBF>{}, diag_c);
-        else if (kind == MFX_KERNEL_MATERN32) body(std::integral_constant<int, MFX_KERNEL_MATERN32>{}, diag_c);
-        else body(std::integral_constant<int, MFX_KERNEL_MATERN12>{}, diag_c);
-      };
-      if (diag_tile) by_kind(std::true_type{}); else by_kind(std::false_type{});
+      // (RBF only: with the two Matern bodies in the same kernel the allocator spills around the branch on EVERY tile --
+      // 2.8 GB of scratch writes per launch in the PMC counters; the Matern kernels keep the LDS epilogue)
+      constexpr std::integral_constant<int, MFX_KERNEL_RBF> rbf_c{};
+      if (diag_tile) body(rbf_c, std::true_type{}); else body(rbf_c, std::false_type{});
       gsum[0] += (double)gl;
       gsum[1] += (double)gs;
       gsum[2] += (double)gn;
@@ -1649,11 +1647,11 @@ static int launch_grad_h_t(const mfx_operator* op, const float* xs, const float*
   const int64_t nti = (nrow + kHM - 1) / kHM, ntj = (n + TN - 1) / TN;
   const int tiles_per_block = (int)((ntj + kGSplit * kGSub - 1) / (kGSplit * kGSub));
   const dim3 grid(kGSplit, (unsigned)(nti * kGSub));
-  // one lengthscale, d <= 8: the register epilogue (MFX_GRAD_REGEPI=0: the LDS epilogue, A/B)
+  // RBF kernel, one lengthscale, d <= 8: the register epilogue (MFX_GRAD_REGEPI=0: the LDS epilogue, A/B)
   static const bool regepi_on = [] { const char* e = getenv("MFX_GRAD_REGEPI"); return e ? atoi(e) != 0 : true; }();
   bool launched = false;
   if constexpr (DPAD <= 8) {
-    if (!op->ard && regepi_on) {
+    if (!op->ard && op->kernel_fn == MFX_KERNEL_RBF && regepi_on) {
       const size_t sh = sizeof(GradSmemH<DPAD, NBW, true>);
       MFX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rbf_mfma_grad_h<DPAD, NBW, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
