@@ -59,7 +59,8 @@ static std::mutex g_gmutex;
 static std::vector<GraphEntry> g_graphs;
 static uint64_t g_gclock = 0;
 static int64_t g_captured = 0, g_replayed = 0;
-static hipStream_t g_capture_stream = nullptr;  // captures run here: the caller's stream may be the legacy default stream
+// captures run on a private stream of the current device: the caller's stream may be the legacy default stream
+static hipStream_t g_capture_stream[16] = {};
 constexpr size_t kMaxGraphs = 32;
 
 static bool graphs_enabled() {
@@ -69,10 +70,14 @@ static bool graphs_enabled() {
 
 int run_graphed(bool eligible, const GraphKey& key, hipStream_t stream, const std::function<int(hipStream_t)>& fn) {
   if (!eligible || g_timing || !graphs_enabled()) return fn(stream);
+  int device = -1;
+  if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 16) return fn(stream);
+  std::string full = key.bytes;  // a graph belongs to the device its kernels were captured for
+  full.append(reinterpret_cast<const char*>(&device), sizeof(device));
   std::lock_guard<std::mutex> lock(g_gmutex);
   GraphEntry* e = nullptr;
   for (auto& g : g_graphs)
-    if (g.key == key.bytes) e = &g;
+    if (g.key == full) e = &g;
   if (!e) {  // first sighting: run eagerly, remember the key
     if (g_graphs.size() >= kMaxGraphs) {
       size_t old = 0;
@@ -81,25 +86,26 @@ int run_graphed(bool eligible, const GraphKey& key, hipStream_t stream, const st
       if (g_graphs[old].exec) (void)hipGraphExecDestroy(g_graphs[old].exec);
       g_graphs.erase(g_graphs.begin() + (long)old);
     }
-    g_graphs.push_back(GraphEntry{key.bytes, nullptr, false, ++g_gclock});
+    g_graphs.push_back(GraphEntry{full, nullptr, false, ++g_gclock});
     return fn(stream);
   }
   e->last_use = ++g_gclock;
   if (e->failed) return fn(stream);
   if (!e->exec) {
-    if (!g_capture_stream && hipStreamCreateWithFlags(&g_capture_stream, hipStreamNonBlocking) != hipSuccess) {
+    hipStream_t& cap = g_capture_stream[device];
+    if (!cap && hipStreamCreateWithFlags(&cap, hipStreamNonBlocking) != hipSuccess) {
       e->failed = true;
       (void)hipGetLastError();
       return fn(stream);
     }
-    if (hipStreamBeginCapture(g_capture_stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
+    if (hipStreamBeginCapture(cap, hipStreamCaptureModeRelaxed) != hipSuccess) {
       e->failed = true;
       (void)hipGetLastError();
       return fn(stream);
     }
-    const int rc = fn(g_capture_stream);
+    const int rc = fn(cap);
     hipGraph_t graph = nullptr;
-    const hipError_t ec = hipStreamEndCapture(g_capture_stream, &graph);
+    const hipError_t ec = hipStreamEndCapture(cap, &graph);
     if (rc != MFX_OK) {  // the driver refused its arguments: nothing ran, nothing to replay
       if (graph) (void)hipGraphDestroy(graph);
       (void)hipGetLastError();
