@@ -1265,6 +1265,9 @@ __global__ __launch_bounds__(256) void k_pack_f16(const float* __restrict__ x, i
 // SIMD as two 128 x 128 workgroups, but (256 + 128) instead of 2 x (128 + 128) operand columns through L2 -> LDS per stage
 constexpr int kHM = 256;
 constexpr int kHLd = kHM + 4;
+#ifndef MFX_GRAD_PINGPONG
+#define MFX_GRAD_PINGPONG 1  // 0: one barrier per stage, all eight waves in lockstep (A/B builds)
+#endif
 
 // NBW = 32-column blocks per wave: the workgroup tile is 256 rows x (2 NBW 32) columns, 8 waves as 4 x 2 of 64 x (NBW 32).
 //   NBW = 2: 256 x 128 (round 1);  NBW = 4: 256 x 256 -- (256 + 256) instead of 2 x (256 + 128) operand columns through L2 -> LDS
@@ -1391,6 +1394,73 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
       ol += 3 * stage_bytes_l;
       orr += 3 * stage_bytes_r;
     }
+#if MFX_GRAD_PINGPONG
+    // PING-PONG: waves w and w + 4 share a SIMD.  With one barrier per stage all eight waves read their fragments from LDS
+    // together (96 KB per stage: ~770 cycles with the matrix pipe idle) and then queue their MFMAs together.  Here the two
+    // halves of the workgroup run half a stage apart: two barriers per stage -- B1 before the fragment reads, B2 before the
+    // MFMAs -- and the upper half takes one extra barrier first, so that while one wave of a SIMD is in its MFMA cluster
+    // (raised priority) the other one is in its read cluster.  Who needs what by when (A = waves 0-3, B = waves 4-7; barrier
+    // numbers in A's count: A.B1(st) = 2 st, A.B2(st) = B.B1(st) = 2 st + 1, B.B2(st) = 2 st + 2):
+    //   * stage st + 1 must have landed for everybody before barrier 2 st + 2 (A reads it after that one): every wave waits
+    //     for ITS pieces of stage st + 1 before its B2(st);  stage 0 before the first barrier;
+    //   * the slot of stage st - 1 is free after barrier 2 st (A read it before 2 st - 1, B before 2 st): every wave refills
+    //     it (stage st + 3) after its B1(st).
+    {
+      const int64_t left0 = nstage - 1;  // stages after stage 0 that are in flight
+      if (left0 >= 2) {
+        if constexpr (kGlds == 4) __builtin_amdgcn_s_waitcnt(0x0F78); else __builtin_amdgcn_s_waitcnt(0x0F76);
+      } else if (left0 == 1) {
+        if constexpr (kGlds == 4) __builtin_amdgcn_s_waitcnt(0x0F74); else __builtin_amdgcn_s_waitcnt(0x0F73);
+      } else {
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+      }
+    }
+    if (wid >= 4) __builtin_amdgcn_s_barrier();  // the half-stage offset of the upper half
+    for (int64_t st = 0; st < nstage; ++st) {
+      const int slot = (int)(st & 3);
+      __builtin_amdgcn_s_barrier();  // B1
+      if (st + 3 < nstage) issue_stage(ol, orr, (int)((st + 3) & 3));
+      ol += stage_bytes_l;
+      orr += stage_bytes_r;
+      half8 ah[2], al[2], bh[NBW], bl[NBW];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        ah[a] = *reinterpret_cast<const half8*>(&sm.u.st.a_hi[slot][lhi][wm * 64 + a * 32 + l31][0]);
+        al[a] = *reinterpret_cast<const half8*>(&sm.u.st.a_lo[slot][lhi][wm * 64 + a * 32 + l31][0]);
+      }
+#pragma unroll
+      for (int b = 0; b < NBW; ++b) {
+        bh[b] = *reinterpret_cast<const half8*>(&sm.u.st.b_hi[slot][lhi][wn * (NBW * 32) + b * 32 + l31][0]);
+        bl[b] = *reinterpret_cast<const half8*>(&sm.u.st.b_lo[slot][lhi][wn * (NBW * 32) + b * 32 + l31][0]);
+      }
+      // my pieces of stage st + 1 (issued three stages ago); stages st + 2, st + 3 stay in flight
+      const int64_t later = nstage - 2 - st;  // stages after st + 1 that have been issued
+      if (st + 1 < nstage) {
+        if (later >= 2) {
+          if constexpr (kGlds == 4) __builtin_amdgcn_s_waitcnt(0x0F78); else __builtin_amdgcn_s_waitcnt(0x0F76);  // vmcnt(8 | 6)
+        } else if (later == 1) {
+          if constexpr (kGlds == 4) __builtin_amdgcn_s_waitcnt(0x0F74); else __builtin_amdgcn_s_waitcnt(0x0F73);  // vmcnt(4 | 3)
+        } else {
+          __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the fragments are in registers
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();  // B2
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NBW; ++b) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
+        }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (wid < 4) __builtin_amdgcn_s_barrier();  // the lower half catches up: both halves have taken 2 nstage + 1 barriers
+#else
     for (int64_t st = 0; st < nstage; ++st) {
       const int slot = (int)(st & 3);
       // kGlds glds per stage and thread; stages st + 1, st + 2 may stay in flight
@@ -1428,6 +1498,7 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
           }
       }
     }
+#endif
     if constexpr (REGEPI) {
       // Everything below that depends only on the workgroup's rows is invariant over the tile loop; hoisted out of it, it
       // would sit in registers through the K-loop, which has none to spare (measured: 380 B of spills, one reload per stage,
