@@ -1,5 +1,5 @@
 """The A/B switches of DESIGN.md §3.8 select real alternative code paths (the un-fused CSR step, 2048-element slices, eager
-launches instead of hipGraph replay, the earlier pipelined Gram matvec, the 256 x 128 gradient-GEMM tile).  They are read once
+launches instead of hipGraph replay, the earlier pipelined Gram matvec, the 256 x 128 gradient-GEMM tile with the LDS epilogue).  They are read once
 per process, so ONE child process re-runs the parity tests of the operators and Krylov drivers with all of them flipped."""
 
 import os
@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 def test_parity_subset_with_every_switch_flipped():
     env = dict(os.environ)
-    env.update(MFX_CSR_FUSED="0", MFX_FINE_SLICES="0", MFX_GRAPHS="0", MFX_RBF_PACK="0", MFX_GRAD_TILE="128")
+    env.update(MFX_CSR_FUSED="0", MFX_FINE_SLICES="0", MFX_GRAPHS="0", MFX_RBF_PACK="0", MFX_GRAD_TILE="128", MFX_GRAD_REGEPI="0")
     keep = "csr or dense_op or hessenberg or tridiag or arnoldi_adjoint or integrand_spd or rbf_op or downsized"
     out = subprocess.run(
         [sys.executable, "-m", "pytest", os.path.join(HERE, "test_gpu_parity.py"), "-m", "gpu", "-x", "-q", "-k", keep,
