@@ -1,12 +1,13 @@
 // libmfx: the Krylov inner loops -- Arnoldi/Lanczos forward recurrences and their adjoints.
 //
 // Layout: a batch of p vectors is (p, n) row-major; the basis is (p, k, n).  Every HBM-bound kernel
-// below uses grid = (ceil(n / 2048), p): one workgroup (4 waves) owns a 2048-element slice of ONE
-// probe's vectors, each thread owns 8 elements (2 x float4 / 4 x double2, 16-B coalesced loads) and
-// keeps them in registers across the whole multi-row sweep.  Dot products are reduced
-// lane -> wave (shuffles) -> workgroup (LDS) and written as per-slice partials (p, kmax, nslices);
-// the consumer kernel re-reduces the partials in its prologue (deterministic, no atomics, and no
-// host round trip: the whole k-loop is enqueued on one stream).
+// below uses grid = (slices, p): one workgroup (4 waves) owns a slice of ONE probe's vectors -- 2048 elements,
+// 8 per thread, or 512 / 1024 (one 16-byte load per thread and row) when that leaves most CUs idle (Ctx::fine) --
+// and keeps its elements in registers across the whole multi-row sweep (double-buffered, mfx_vec.h: sweep_rows).
+// Dot products are accumulated in fp64, reduced lane -> wave (DPP, several rows at once: wave_sums) -> workgroup (LDS)
+// and written as per-slice partials (p, kmax, nslices); the consumer kernel re-reduces the partials in its
+// prologue (deterministic, no atomics, and no host round trip: the whole k-loop is enqueued on one stream,
+// and replayed from a hipGraph when the call repeats: mfx_core.hip).
 //
 // Reference: arnoldi.py:57-101 (forward), :104-220 (adjoint); lanczos.py:215-285, :288-335.
 #include "mfx_vec.h"

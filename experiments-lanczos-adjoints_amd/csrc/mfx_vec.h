@@ -1,6 +1,6 @@
 // libmfx: the shared HBM-bound vector kernels (dots / update / sumsq / scale) and their launch helpers.
 // Included by the Krylov drivers (mfx_krylov.hip) and the CG / preconditioner drivers (mfx_cg.hip): every
-// kernel uses grid = (ceil(n / 2048), p) and per-slice partials, see the header comment of mfx_krylov.hip.
+// kernel uses grid = (slices, p) and per-slice partials, see the header comment of mfx_krylov.hip.
 #pragma once
 #include <stdlib.h>
 
@@ -470,9 +470,9 @@ struct Ctx {
   // Finer slices (one 16-byte load per thread and row) when the 2048-element slicing gives fewer than 128 workgroups: the
   // vector kernels are bandwidth-bound PER CU (measured on config 3, n = 102400, one vector: 50 workgroups stream 1.4 TB/s).
   // Only drivers whose every kernel goes through MFX_VEC_EPT_SWITCH may call this (the partial layout changes with nblk).
-  // MEASURED (profiles/r02g_*): no net gain on config 3 -- k_dots' worst case drops from 30 to 20 us, but every consumer re-reduces
-  // 4x more partials in its prologue (update + norm 7.4 -> 14.7 us); forward 2.84 -> 2.91 ms, forward + adjoint 8.7 -> 8.0 ms, within
-  // box-to-box noise.  Off unless MFX_FINE_SLICES=1.
+  // First measured WITHOUT the other changes of DESIGN.md section 3.1 (profiles/r02g_*): no net gain -- every consumer re-reduced 4x more
+  // partials in a serial prologue.  With the pipelined partial sums, the double-buffered sweeps and the DPP reductions it pays
+  // (config 3: forward + adjoint 8.2 -> 3.6 ms altogether, profiles/r02k_*).  MFX_FINE_SLICES=0 switches it off.
   void fine() {
     static const bool on = [] { const char* e = getenv("MFX_FINE_SLICES"); return !e || atoi(e) != 0; }();
     if (!on || vec <= 1 || wg != kBlock || (int64_t)nblk * p >= 128) return;
