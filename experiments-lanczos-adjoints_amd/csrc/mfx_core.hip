@@ -47,6 +47,40 @@ ScopedTimer::~ScopedTimer() {
 }
 
 // ------------------------------------------------------------------------------------------------
+// fills / copies as kernels (see mfx_internal.h)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_zero_words(uint32_t* __restrict__ p, size_t nwords) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < nwords) p[i] = 0u;
+}
+__global__ __launch_bounds__(256) void k_copy_rows_words(uint32_t* __restrict__ dst, size_t dst_pitch_w,
+                                                         const uint32_t* __restrict__ src, size_t src_pitch_w, size_t width_w) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+  if (i < width_w) dst[r * dst_pitch_w + i] = src[r * src_pitch_w + i];
+}
+
+int zero_async(void* dst, size_t bytes, hipStream_t stream) {
+  if (bytes == 0) return MFX_OK;
+  MFX_REQUIRE(bytes % 4 == 0 && reinterpret_cast<uintptr_t>(dst) % 4 == 0, MFX_ERR_INVALID, "zero_async: 4-byte granularity");
+  const size_t nw = bytes / 4;
+  k_zero_words<<<(unsigned)((nw + 255) / 256), 256, 0, stream>>>(static_cast<uint32_t*>(dst), nw);
+  MFX_CHECK_LAUNCH();
+  return MFX_OK;
+}
+
+int copy_rows_async(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width, size_t rows,
+                    hipStream_t stream) {
+  if (width == 0 || rows == 0) return MFX_OK;
+  MFX_REQUIRE(width % 4 == 0 && dst_pitch % 4 == 0 && src_pitch % 4 == 0 && rows <= 65535, MFX_ERR_INVALID,
+              "copy_rows_async: 4-byte granularity, at most 65535 rows");
+  const size_t ww = width / 4;
+  k_copy_rows_words<<<dim3((unsigned)((ww + 255) / 256), (unsigned)rows), 256, 0, stream>>>(
+      static_cast<uint32_t*>(dst), dst_pitch / 4, static_cast<const uint32_t*>(src), src_pitch / 4, ww);
+  MFX_CHECK_LAUNCH();
+  return MFX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // hipGraph cache (see mfx_internal.h)
 // ------------------------------------------------------------------------------------------------
 struct GraphEntry {

@@ -64,6 +64,14 @@ struct GraphKey {
 // it is given and nothing else (no synchronisation, no allocation).
 int run_graphed(bool eligible, const GraphKey& key, hipStream_t stream, const std::function<int(hipStream_t)>& fn);
 
+// ---- device fills / copies as KERNELS -------------------------------------------------------------
+// hipMemsetAsync / hipMemcpy2DAsync become memset / memcpy NODES when a driver call is captured into a hipGraph, and the memset
+// node of this ROCm release writes garbage on the second launch of an instantiated graph (measured: H of the Arnoldi
+// forward came back with 0x1'00000000 patterns below its sub-diagonal; tests/test_gpu_graphs.py).  Kernel nodes replay fine.
+int zero_async(void* dst, size_t bytes, hipStream_t stream);                       // bytes % 4 == 0
+int copy_rows_async(void* dst, size_t dst_pitch, const void* src, size_t src_pitch,  // `rows` rows of `width` bytes (% 4 == 0)
+                    size_t width, size_t rows, hipStream_t stream);
+
 // ---- geometry of the Krylov vector kernels ------------------------------------------------------
 constexpr int kBlock = 256;  // 4 waves
 constexpr int kEpt = 8;      // elements owned by one thread

@@ -601,7 +601,7 @@ static int arnoldi_forward_t(const mfx_operator* op, const T* v0, int64_t n, int
   T* P2 = static_cast<T*>(ws.p2);
   T* PN = static_cast<T*>(ws.pn);
   const int64_t ldq = k * n;
-  MFX_CHECK_HIP(hipMemsetAsync(H, 0, sizeof(T) * p * k * k, stream));
+  MFX_TRY(zero_async(H, sizeof(T) * p * k * k, stream));
   {
     ScopedTimer t(2, stream);
     MFX_TRY(launch_sumsq<T>(c, v0, n, PN));
@@ -676,7 +676,7 @@ static int arnoldi_adjoint_t(const mfx_operator* op, int64_t n, int64_t k, int64
   T* eta = pig + p * k * k;
   const int64_t ldq = k * n;
   const bool fused = csr_fusable<T>(op, c, 1);
-  MFX_CHECK_HIP(hipMemsetAsync(Gam, 0, sizeof(T) * p * k * k, stream));
+  MFX_TRY(zero_async(Gam, sizeof(T) * p * k * k, stream));
   {
     ScopedTimer t(2, stream);
     if (dr) MFX_TRY(launch_dots<T>(c, Q, ldq, n, (int)k, dr, n, P1));
@@ -716,8 +716,7 @@ static int arnoldi_adjoint_t(const mfx_operator* op, int64_t n, int64_t k, int64
         a.x = lam; a.ldx = n; a.y = lam_idx; a.ldy = ldq;
         MFX_TRY(launch_update<T>(c, a, false, false));
       } else {
-        MFX_CHECK_HIP(hipMemcpy2DAsync(lam_idx, sizeof(T) * ldq, lam, sizeof(T) * n, sizeof(T) * n, p,
-                                       hipMemcpyDeviceToDevice, stream));
+        MFX_TRY(copy_rows_async(lam_idx, sizeof(T) * ldq, lam, sizeof(T) * n, sizeof(T) * n, p, stream));
       }
     }
     // z = A^T lambda (+ parameter gradient for callback operators), arnoldi.py:207-209
@@ -774,8 +773,8 @@ static int lanczos_forward_t(const mfx_operator* op, const T* v0, int64_t n, int
   // r = w - a x_i - b_{i-1} x_{i-1} (lanczos.py:281-282) in ONE update over the rows (x_{i-1}, x_i): coefficient 0 is
   // 0 * partials + beta[i-1], coefficient 1 is the dot a = x_i . w (its partials in row 1 of P1, row 0 stays zero) + beta[i],
   // which is still zero when step i reads it -- so the three-term step needs no separate scalar kernel.
-  MFX_CHECK_HIP(hipMemsetAsync(beta, 0, sizeof(T) * p * k, stream));
-  MFX_CHECK_HIP(hipMemsetAsync(P1, 0, sizeof(T) * p * c.kmax * c.nblk, stream));
+  MFX_TRY(zero_async(beta, sizeof(T) * p * k, stream));
+  MFX_TRY(zero_async(P1, sizeof(T) * p * c.kmax * c.nblk, stream));
   {
     ScopedTimer t(2, stream);
     MFX_TRY(launch_sumsq<T>(c, v0, n, PN));
@@ -834,7 +833,7 @@ static int lanczos_adjoint_t(const mfx_operator* op, int64_t n, int64_t k, int64
   if (dxs) {
     MFX_TRY(launch_scale<T>(c, dxs + k * n, ldx, xi, n, nullptr, nullptr, 2, nullptr, 0, nullptr));
   } else {
-    MFX_CHECK_HIP(hipMemsetAsync(xi, 0, sizeof(T) * p * n, stream));
+    MFX_TRY(zero_async(xi, sizeof(T) * p * n, stream));
   }
   for (int64_t j = k - 1; j >= 0; --j) {
     const T* xj = xs + j * n;

@@ -353,7 +353,7 @@ __global__ void k_row_scale_from_bits(const unsigned* __restrict__ amax_bits, in
 // scale (rows, 2) = [s, 1/s]; the amax bit patterns live right behind it in the caller's buffer
 static int row_scales(const float* x, int64_t ldx, int64_t n, int64_t rows, float* scale, hipStream_t stream) {
   unsigned* bits = reinterpret_cast<unsigned*>(scale + 2 * rows);
-  MFX_CHECK_HIP(hipMemsetAsync(bits, 0, sizeof(unsigned) * (rows + 1), stream));  // + the f16 range flag behind them
+  MFX_TRY(zero_async(bits, sizeof(unsigned) * (rows + 1), stream));  // + the f16 range flag behind them
   int64_t gx = (n + 8191) / 8192;
   if (gx > 64) gx = 64;
   k_row_amax_bits<<<dim3((unsigned)gx, (unsigned)rows), 256, 0, stream>>>(x, ldx, n, bits);

@@ -74,3 +74,36 @@ def test_graph_replay_sees_new_data_csr():
     _tridiag_rounds(op, orc.CooOp(r, c, n), k, v_buf, p_buf, inputs, "full", to_param=lambda a: np.asarray(a)[order.numpy()])
     cap1, rep1 = _lib.graph_stats()
     assert cap1 - cap0 >= 2 and rep1 - rep0 >= 4
+
+
+@pytest.mark.parametrize("reortho", ["full", "none"])
+def test_graph_replay_hessenberg_matches_the_eager_first_call(reortho):
+    """arnoldi.hessenberg forward + adjoint called five times on the same buffers: the first call runs eagerly, the second is
+    captured, the rest are replays (the reortho="none" adjoint has a 2-D device copy per step inside the capture)."""
+    from matfree_extensions import arnoldi
+
+    n, k = 80, 7
+    rng = np.random.default_rng(9)
+    A = torch.tensor(rng.standard_normal((n, n)) / np.sqrt(n) + 2.0 * np.eye(n), dtype=torch.float64, device=DEV, requires_grad=True)
+    v = torch.tensor(rng.standard_normal(n), dtype=torch.float64, device=DEV, requires_grad=True)
+    alg = arnoldi.hessenberg(DenseOp(), k, reortho=reortho)
+    cot = None
+    first = None
+    cap0, rep0 = _lib.graph_stats()
+    for it in range(5):
+        Q, H, r, c = alg(v, A)
+        if cot is None:
+            g = torch.Generator(device=DEV).manual_seed(1)
+            cot = [torch.randn(t.shape, dtype=torch.float64, device=DEV, generator=g) for t in (Q, H, r, c)]
+        dv, dA = torch.autograd.grad((Q, H, r, c), (v, A), cot)
+        got = [t.detach().clone() for t in (Q, H, r, c, dv, dA)]
+        if first is None:
+            first = got
+            Qo, Ho, ro, co = orc.arnoldi_forward(orc.DenseOp(), k, v.detach().cpu().numpy(), A.detach().cpu().numpy(), reortho=reortho)
+            assert np.allclose(H.detach().cpu().numpy(), Ho, rtol=1e-9, atol=1e-12)
+        else:
+            for a, b in zip(got, first):
+                assert torch.equal(a, b)
+        del Q, H, r, c, dv, dA, got
+    cap1, rep1 = _lib.graph_stats()
+    assert cap1 - cap0 >= 1 and rep1 - rep0 >= 2  # (which calls repeat an address pattern is the allocator's business)
