@@ -109,6 +109,9 @@ class RowComm:
         self.nloc = rows_per_rank(self.n, self.world)
         self.row0 = self.rank * self.nloc
         self.nrows = min(self.nloc, self.n - self.row0)
+        # run the collectives even in a one-rank group (they are no-ops then): lets ONE GPU exercise the RCCL code path of the
+        # callbacks -- tensor views of the workspace, stream ordering -- which gloo-through-the-host tests cannot
+        self.force_collectives = False
 
     # ---- host-side helpers ---------------------------------------------------------------------
     def rows(self, t):
@@ -116,7 +119,7 @@ class RowComm:
         return t[..., self.row0 : self.row0 + self.nrows].contiguous()
 
     def all_reduce_(self, t):
-        if self.world > 1:
+        if self.world > 1 or (self.force_collectives and dist.is_available() and dist.is_initialized()):
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
@@ -183,6 +186,7 @@ class RowComm:
         base, nbytes = ws.data_ptr(), ws.numel()
         failure = []
         world, group = self.world, self.group
+        collective = world > 1 or (self.force_collectives and dist.is_available() and dist.is_initialized())
         regs = [(ws.data_ptr(), ws.numel(), ws)] + [(t.data_ptr(), t.numel() * t.element_size(), t.view(-1).view(torch.uint8))
                                                    for t in tensors if t is not None]
 
@@ -213,7 +217,7 @@ class RowComm:
 
         def allreduce(_ctx, buf, count, dtype_code, _stream):
             try:
-                if world > 1:
+                if collective:
                     dist.all_reduce(view(buf, count, dtype_code), op=dist.ReduceOp.SUM, group=group)
                 return 0
             except Exception as exc:  # never let an exception cross the C boundary
@@ -223,7 +227,7 @@ class RowComm:
         def allgather(_ctx, inp, out, count, dtype_code, _stream):
             try:
                 tin, tout = view(inp, count, dtype_code), view(out, count * world, dtype_code)
-                if world > 1:
+                if collective:
                     dist.all_gather_into_tensor(tout, tin, group=group)
                 else:
                     tout.copy_(tin)

@@ -1,0 +1,55 @@
+"""Child process of tests/test_gpu_sharded.py::test_rccl_one_rank_group_runs_the_collective_callbacks: a ONE-rank "nccl" (= RCCL)
+process group on the one GPU of the box, the row-sharded SLQ value-and-gradient with the collectives forced through it, against
+the single-device drivers.  Exit code 0 = equal."""
+import datetime
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "experiments-lanczos-adjoints_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def main():
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", sys.argv[1])
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(seconds=120))
+    from matfree_extensions import hutchinson, lanczos
+    from matfree_extensions.distributed import RowComm
+    from matfree_extensions.operators import RowShardedOp
+    from matfree_extensions.util import gp_util
+
+    n, d, k, p = 2304, 8, 12, 8
+    g = torch.Generator().manual_seed(7)
+    X = torch.randn((n, d), generator=g, dtype=torch.float32).to(dev)
+    op = gp_util.gram_operator(X, precision="f16x3")
+    params = [torch.tensor(v, dtype=torch.float32, device=dev) for v in (0.5, 0.2, -1.0)]
+    probes = hutchinson.sampler_rademacher(torch.empty(n, dtype=torch.float32, device=dev), num=p)(3)
+
+    def run(matvec):
+        ps = [q.clone().requires_grad_(True) for q in params]
+        vals = lanczos.integrand_spd(torch.log, k, matvec)(probes, *ps)
+        return vals.detach(), torch.autograd.grad(vals.sum(), ps)
+
+    v0, g0 = run(op)
+    comm = RowComm(n)
+    comm.force_collectives = True
+    assert comm.world == 1
+    v1, g1 = run(RowShardedOp(op, comm))
+    torch.cuda.synchronize()
+    ok = torch.allclose(v0, v1, rtol=2e-5)
+    for a, b in zip(g0, g1):
+        ok = ok and torch.allclose(a, b, rtol=5e-4, atol=5e-4 * a.abs().max().item())
+    print("values", v0[:3].tolist(), v1[:3].tolist(), "ok", ok)
+    dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

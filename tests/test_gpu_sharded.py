@@ -333,3 +333,21 @@ def test_c4_shape_on_two_row_shards_equals_the_single_process_estimate(tmp_path)
     assert np.isclose(got["mean"].item(), mean.item(), rtol=2e-5)
     for a, b in zip(got["grads"], grads):
         assert torch.allclose(a, b.cpu(), rtol=5e-4, atol=5e-4 * b.abs().max().item()), (a, b)
+
+
+def test_rccl_one_rank_group_runs_the_collective_callbacks():
+    """RCCL needs one GPU per rank, so the multi-rank runs of this file go through gloo and the host.  What a one-GPU box CAN
+    check of the RCCL path: a one-rank "nccl" group with the collectives forced through it -- all_reduce / all_gather_into_tensor on
+    views of the libmfx workspace, issued from the C callbacks, ordered with the kernels on the current stream."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k_ in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k_, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rccl_one_rank.py"), str(port)], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
