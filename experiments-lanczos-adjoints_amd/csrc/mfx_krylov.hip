@@ -520,6 +520,7 @@ static int launch_csr_step(const Ctx<T>& c, const mfx_operator* op, int transpos
   a.nblk_in = c.nblk_in;
   ScopedTimer t(0, c.stream);
   const size_t sh = dots ? (size_t)4 * a.m * sizeof(T) : 0;
+  MFX_REQUIRE(sh <= 64 * 1024, MFX_ERR_UNSUPPORTED, "Krylov depth %d too large for the fused CSR step (%zu B of LDS > 64 KiB)", a.m, sh);
   if (pre && dots) {
     MFX_VEC_EPT_SWITCH(c, (k_csr_step<T, VEC, EPT, true, true><<<c.grid(), c.wg, sh, c.stream>>>(a)));
   } else if (pre) {
@@ -738,6 +739,8 @@ static int arnoldi_adjoint_t(const mfx_operator* op, int64_t n, int64_t k, int64
       ca.m_out = (int)((idx + 1 < k) ? idx + 1 : k);
     }
     const size_t sh = (size_t)(2 * k + 4 * ca.m_out) * sizeof(T);
+    MFX_REQUIRE(sh <= 64 * 1024, MFX_ERR_UNSUPPORTED, "Krylov depth %lld too large for the adjoint combine kernel (%zu B of LDS > 64 KiB)",
+                (long long)k, sh);
     MFX_VEC_EPT_SWITCH(c, (k_adj_combine<T, VEC, EPT><<<c.grid(), c.wg, sh, stream>>>(ca)));
     MFX_CHECK_LAUNCH();
     if (ca.partial_out) MFX_TRY(c.finish(P1, c.kmax, ca.m_out));

@@ -516,6 +516,7 @@ static int launch_dots(const Ctx<T>& c, const T* rows, int64_t rows_ldb, int64_t
   int jchunk = (int)((m + maxgroups - 1) / maxgroups);
   const int jmin = c.ept <= 4 ? 16 : 8;  // one buffer of sweep_rows at least
   if (jchunk < jmin) jchunk = m < jmin ? m : jmin;
+  if (jchunk > 256) jchunk = 256;  // the per-wave partials in LDS: 4 x CT x jchunk values (deep bases just get more row groups)
   const int ngroups = (m + jchunk - 1) / jchunk;
   const size_t sh = (size_t)4 * (tiled ? kDotsColTile : 1) * jchunk * sizeof(T);
   dim3 grid(c.nblk, (unsigned)c.p, (unsigned)(ctiles * ngroups));
@@ -544,6 +545,8 @@ static int launch_update(const Ctx<T>& c, UpdateArgs<T> a, bool dots, bool norm)
   if (dots) a.partial_out = c.producer(want_dots);
   if (norm) a.partial_norm = c.producer(want_norm);
   const size_t sh = (size_t)(a.m + (dots ? 4 * a.m : 0) + 4) * sizeof(T);
+  MFX_REQUIRE(sh <= 64 * 1024, MFX_ERR_UNSUPPORTED, "Krylov depth %d too large for the update kernels' coefficient buffers (%zu B of LDS > 64 KiB)",
+              a.m, sh);
   if (dots && norm) {
     MFX_VEC_EPT_SWITCH(c, (k_update<T, VEC, true, true, EPT><<<c.grid(), c.wg, sh, c.stream>>>(a)));
   } else if (dots) {
