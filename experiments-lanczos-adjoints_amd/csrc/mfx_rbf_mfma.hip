@@ -20,11 +20,9 @@
 #include <type_traits>
 
 #include "mfx_internal.h"
+#include "mfx_rbf_common.h"
 
 namespace mfx {
-
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef float floatx2 __attribute__((ext_vector_type(2)));
 
 // geometry of the parameter-gradient GEMM (both the fp32 and the 3 x f16 variant)
 constexpr int kGM = 128, kGN = 128, kGK = 32, kGSplit = 8;
@@ -36,34 +34,8 @@ constexpr int kGSub = 8;
 constexpr int kGLd = kGM + 4;  // padded row of the transposed S tile: conflict-free ds_write_b128
 
 
-// -log2(e)/2: exp(-dist/2) = exp2(kNegHalfLog2e * dist)
-constexpr float kNegHalfLog2e = -0.72134752044448170368f;
-
-// Matern kernels: the distance product is scaled by log2(e)^2 (x 3 for nu = 3/2), so that r' = sqrt(t) is already
-// log2(e) * r:  K = exp2(-r') [nu = 1/2],  (1 + r'/log2(e)) exp2(-r') [nu = 3/2]   (util/gp_util.py:69-148)
-constexpr float kLog2e = 1.44269504088896340736f;
-constexpr float kLn2 = 0.69314718055994530942f;
-constexpr float kEpsF32 = 1.1920928955078125e-7f;
 __device__ __forceinline__ float dist_factor(int kind) {  // multiplies the squared distance inside the MFMA product
   return kind == MFX_KERNEL_RBF ? -0.72134752044448170368f : (kind == MFX_KERNEL_MATERN32 ? 3.f : 1.f) * kLog2e * kLog2e;
-}
-// K / outputscale from t = factor * dist (un-clamped), shift = log2 of an optional power-of-two scale of K
-// sqrt as ONE v_sqrt_f32 (1 ulp): __builtin_sqrtf expands to a 16-instruction correctly-rounded sequence, which made
-// the Matern Gram matvec 2.5x the RBF one (every VALU instruction per kernel entry is paid in full here).
-template <int KIND>
-__device__ __forceinline__ float matern_from_t(float t, float shift) {
-  const float rp = __builtin_amdgcn_sqrtf(fmaxf(t, 0.f) + kEpsF32 * kLog2e * kLog2e);
-  const float e = __builtin_amdgcn_exp2f(shift - rp);
-  return KIND == MFX_KERNEL_MATERN32 ? fmaf(e * rp, kLn2, e) : e;
-}
-// the same from te = t + eps log2(e)^2 (the eps rides in the distance product): max(t, 0) + eps' == max(t + eps', eps'),
-// so clamp and offset are one v_med3; `scale` = 2^shift is folded into the polynomial factor (no v_sub before the exp2)
-constexpr float kEpsC = kEpsF32 * kLog2e * kLog2e;
-template <int KIND>
-__device__ __forceinline__ float matern_from_te(float te, float scale) {
-  const float rp = __builtin_amdgcn_sqrtf(__builtin_amdgcn_fmed3f(te, kEpsC, 3.0e38f));
-  const float e = __builtin_amdgcn_exp2f(-rp);
-  return KIND == MFX_KERNEL_MATERN32 ? e * fmaf(rp, kLn2 * scale, scale) : e * scale;
 }
 
 // epilogue of the gradient GEMMs: K_ij / outputscale and the lengthscale weight from the clamped squared distance
@@ -293,32 +265,6 @@ __global__ __launch_bounds__(256, 2) void k_rbf_mfma_apply(const float* __restri
 // Accuracy: |error| <= ~4 eps_fp32 per product, fp32 accumulation -- validated against the fp64 oracle
 // at the same tolerances as the fp32-exact path (tests/test_gpu_parity.py).
 // ================================================================================================
-constexpr float kKShift = 15.f;
-// Chains of the pipelined matvec.  The f16 MFMA aligns what it adds to the accumulator with a few guard bits and truncates
-// (tools/mfma_f16_trunc.hip): harmless for sign-mixed sums, but Krylov vectors are dominated by the smooth leading eigenvectors
-// of an all-positive kernel matrix -- the accumulator of a row then grows monotonically over its 24576 MFMAs and the loss grows
-// with the size of the accumulator relative to the products (-8.7e-5 relative on a constant vector at n = 131072; the SLQ
-// gradient was 4.4e-4 off; tools/diag_matvec_bias.py).  What helps is a SMALL accumulator: every kChainTiles tiles the
-// accumulators are folded (fp32 VALU adds, round to nearest) into master accumulators and restart from zero.  The masters of
-// all but one 32 x 32 block live in LDS (lane-private slots: no barrier, no bank conflict), the last block's in 16 of the
-// spare registers: no partial sums through HBM.  (Round 2 first cut the sweep into 16 column splits with partial sums in HBM:
-// same accuracy, +7.6 % per matvec and 1.1 GB of extra traffic per launch; negating the accumulators in registers instead of
-// restarting them did nothing.)
-constexpr int kChainTiles = 128;
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));  // 16-B pack as a native vector (HIP's uint4 struct went to scratch)
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-
-// hi = x rounded to 11 significant bits (round-half-up on the magnitude: add half an f16 ulp to the
-// bit pattern, clear the low 13 mantissa bits -- a carry ripples into the exponent correctly), so hi is
-// exactly an f16 and |lo| = |x - hi| <= 2^-12 |x| (exact in fp32).  Rounding instead of truncating
-// keeps the dropped lo*lo term at 2^-24 relative AND sign-random (truncation made it a coherent bias).
-__device__ __forceinline__ void split_hi_lo(float x, float& hi, float& lo) {
-  hi = __uint_as_float((__float_as_uint(x) + 0x1000u) & 0xFFFFE000u);
-  lo = x - hi;
-}
-
 // per-row power-of-two scale: 2^(14 - e) for |max| = f 2^e  (1 for an all-zero row).  Two tiny kernels instead of
 // one workgroup per row (98 us at n = 131072): slice maxima -> atomicMax on the bit pattern of the non-negative
 // float (monotone as an integer), then the scales.
@@ -372,42 +318,11 @@ struct RbfTileH {
   _Float16 vlo[(kTJ / 32) * 4][ROW];
 };
 
-// The reference clamps the squared distance at 0 before the exponential (util/gp_util.py:173).  In fp32 a computed squared
-// distance is negative only by round-off (|t| <~ 1e-6 of the operands' squares), so the clamp changes K_ij by at most that
-// round-off -- the same size as the error of every other entry -- while costing one VALU instruction per entry (7 % of the
-// RBF matvec).  MFX_RBF_CLAMP=1 at build time restores it; 2^15 K cannot overflow f16 either way (arg <= 15 + 1e-5).
-#ifndef MFX_RBF_CLAMP
-#define MFX_RBF_CLAMP 0
-#endif
-constexpr bool kClampRbf = MFX_RBF_CLAMP != 0;
 // schedule of the pipelined kernel's block loop (see do_tile): 1 = exp/split spread over the whole block, 0 = two-phase
 #ifndef MFX_RBF_WIDE
 #define MFX_RBF_WIDE 1
 #endif
 constexpr bool kWideSched = MFX_RBF_WIDE != 0;
-
-// async global -> LDS copy of 16 bytes per lane (global_load_lds_dwordx4): the destination is
-// wave-uniform base + lane * 16 (1 KiB per wave-instruction), no staging registers
-__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
-// tile of the pipelined kernel: RbfTileH plus the f16 hi/lo image of the distance operand (DH variant).
-// PADROW: the in-kernel split stores 8-byte pieces from many rows at once and needs the row pad; the pre-packed path copies the image
-// by LDS-DMA in 1 KiB pieces and wants [ajh | vhi | vlo] contiguous (the b128 fragment reads are conflict-free either way).
-template <int DPAD, int NB, int kTJ, bool PADROW = true>
-struct RbfTileH3 {
-  static constexpr int KD = DPAD + 2;
-  static constexpr int NKD = (3 * KD + 15) / 16;  // f16 MFMAs (K = 16) per block for hi.hi + hi.lo + lo.hi
-  static constexpr int AROW = NKD * 16 + 8;       // halves per column, padded: conflict-free ds_read_b128
-  static constexpr int P = NB * 32;
-  static constexpr int ROW = P * 8 + (PADROW ? 8 : 0);
-  float aj[KD][kTJ];
-  _Float16 ajh[kTJ][AROW];
-  _Float16 vhi[(kTJ / 32) * 4][ROW];
-  _Float16 vlo[(kTJ / 32) * 4][ROW];
-};
 
 // ================================================================================================
 // Pipelined 3 x f16 kernel ("h3"): the production fp32 RBF Gram matvec.
@@ -425,13 +340,14 @@ struct RbfTileH3 {
 // ================================================================================================
 // waves per workgroup: the pre-packed variant runs 8 waves (512 rows) on ONE staged tile -- the same two waves per SIMD as two
 // 4-wave workgroups, but half the L2 -> LDS traffic and half the LDS tile copies
-template <bool PK>
+// MI = 4 ("fat waves", pre-packed variant only): FOUR waves of 128 rows -- one wave per SIMD with the whole 512-register file
+template <bool PK, int MI = 2>
 struct H3Waves {
-  static constexpr int value = PK ? 8 : 4;
+  static constexpr int value = PK ? (MI == 4 ? 4 : 8) : 4;
 };
 
-template <int DPAD, int NB, bool VEC4, int KIND, bool DH, bool PK>
-__global__ __launch_bounds__(64 * H3Waves<PK>::value, PK ? 1 : 2) void k_rbf_mfma_apply_h3(const float* __restrict__ xs, const float* __restrict__ sq,
+template <int DPAD, int NB, bool VEC4, int KIND, bool DH, bool PK, int MI = 2>
+__global__ __launch_bounds__((64 * H3Waves<PK, MI>::value), PK ? 1 : 2) void k_rbf_mfma_apply_h3(const float* __restrict__ xs, const float* __restrict__ sq,
                                                               int64_t n, const float* __restrict__ outputscale,
                                                               const float* __restrict__ noise,
                                                               const float* __restrict__ vscale,
@@ -449,7 +365,8 @@ __global__ __launch_bounds__(64 * H3Waves<PK>::value, PK ? 1 : 2) void k_rbf_mfm
   if (rangeflag && (*rangeflag != 0) == DH) return;
   // gridDim.z > 1: column split for small n (too few 256-row blocks to fill 256 CUs): workgroup z sweeps its share of the
   // 64-column tiles and writes a partial result to part[z][probe][row]; k_split_reduce adds them in a fixed order.
-  constexpr int kMI = 2, kTJ = 64;
+  constexpr int kMI = MI, kTJ = 64;
+  static_assert(MI == 2 || (MI == 4 && PK && KIND == MFX_KERNEL_RBF), "fat waves: pre-packed RBF variant only");
   using Tile = RbfTileH3<DPAD, NB, kTJ, !PK>;
   constexpr int KD = Tile::KD, KS = KD / 2, NKD = Tile::NKD;
   constexpr float cfac = KIND == MFX_KERNEL_RBF ? kNegHalfLog2e : (KIND == MFX_KERNEL_MATERN32 ? 3.f : 1.f) * kLog2e * kLog2e;
@@ -457,7 +374,7 @@ __global__ __launch_bounds__(64 * H3Waves<PK>::value, PK ? 1 : 2) void k_rbf_mfm
   Tile* const tile = reinterpret_cast<Tile*>(h3_smem);  // [2]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
-  constexpr int WV = H3Waves<PK>::value;
+  constexpr int WV = H3Waves<PK, MI>::value;
   // master accumulators of the chain folds (PK variant): blocks 0 .. kMI NB - 2 in LDS behind the tiles, the last one in registers
   constexpr int kBlocks = kMI * NB;
   float* const master = reinterpret_cast<float*>(h3_smem + 2 * sizeof(Tile)) + ((size_t)wid * (kBlocks - 1) * 16) * 64 + lane;
@@ -505,6 +422,13 @@ __global__ __launch_bounds__(64 * H3Waves<PK>::value, PK ? 1 : 2) void k_rbf_mfm
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][nb][r] = 0.f;
+  if constexpr (MI == 4) {
+    // an "a"-constrained operand keeps the function from being marked amdgpu-no-agpr: the MFMAs are then selected in their AGPR
+    // form (accumulators live in the accumulation registers) instead of the VGPR form with v_accvgpr spill traffic
+    float agpr_seed = 0.f;
+    asm volatile("; agpr form" : "+a"(agpr_seed));
+    acc[0][0][0] = agpr_seed;
+  }
   if constexpr (PK) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) mreg[r] = 0.f;
@@ -690,6 +614,31 @@ __global__ __launch_bounds__(64 * H3Waves<PK>::value, PK ? 1 : 2) void k_rbf_mfm
     al[s][q] = l[0]; al[s][q + 1] = l[1];
   };
 
+  // Fat waves (MI = 4): ONE wave per SIMD, so nothing but this wave's own instruction-level parallelism covers the latencies of
+  // the chain exp -> cvt (hi) -> fma_mix (lo) -> cvt.  The chain of a pair of entries is cut into four steps that work IN PLACE on
+  // the distance block (step 0: exp2; 1: hi = f16(k); 2: k - hi; 3: lo = f16(.)), and the block loop issues the steps of different
+  // pairs side by side (software pipeline over the pairs, kSplitGap below): no step follows its producer within one MFMA gap.
+  auto split_step = [&](floatx16& w, const int p, const int st, const bool neg, half8 (&ah)[2], half8 (&al)[2]) {
+    const int s = p >> 2, q = (p & 3) * 2, r0 = 8 * s + q;
+    if (st == 0) {
+      w[r0] = __builtin_amdgcn_exp2f(neg ? -w[r0] : w[r0]);
+      w[r0 + 1] = __builtin_amdgcn_exp2f(neg ? -w[r0 + 1] : w[r0 + 1]);
+    } else if (st == 1) {
+      const half2v h = {(_Float16)w[r0], (_Float16)w[r0 + 1]};
+      ah[s][q] = h[0]; ah[s][q + 1] = h[1];
+    } else if (st == 2) {
+      const half2v h = {ah[s][q], ah[s][q + 1]};
+      const unsigned hb = __builtin_bit_cast(unsigned, h);
+      float l0, l1;
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hb), "v"(w[r0]));
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hb), "v"(w[r0 + 1]));
+      w[r0] = l0; w[r0 + 1] = l1;
+    } else {
+      const half2v l = {(_Float16)w[r0], (_Float16)w[r0 + 1]};
+      al[s][q] = l[0]; al[s][q + 1] = l[1];
+    }
+  };
+
   const int64_t ntile_tot = (n + kTJ - 1) / kTJ;
   const int64_t t_first = ntile_tot * blockIdx.z / gridDim.z, ntile = ntile_tot * (blockIdx.z + 1) / gridDim.z;
   if constexpr (PK) {
@@ -724,11 +673,25 @@ __global__ __launch_bounds__(64 * H3Waves<PK>::value, PK ? 1 : 2) void k_rbf_mfm
 #pragma unroll
         for (int q = 0; q < NKD; ++q) ajs[q] = *reinterpret_cast<const half8*>(&tl.ajh[jbx * 32 + l31][q * 16 + lhi * 8]);
       };
+      // Fat waves (MI = 4): the contraction accumulators live in AGPRs (see the "a" operand above), but a distance block is consumed
+      // by v_exp and must come out in VGPRs with a literal-zero addend (the intrinsic would zero 16 AGPRs and copy 16 back per
+      // block): written as asm.  The compiler does not see an MFMA there, so the MFMA-write -> VALU-read wait states are ours to
+      // keep: the first v_exp that reads the block follows at least two more MFMAs of this wave (>= 64 cycles on its own SIMD).
+      auto dist_step = [&](floatx16& kd, const half8& a, const half8& b, const bool first) {
+        if constexpr (MI == 4) {
+          if (first) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(kd) : "v"(a), "v"(b));
+          else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(kd) : "v"(a), "v"(b));
+        } else {
+          kd = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, kd, 0, 0, 0);
+        }
+      };
       auto dist = [&](floatx16& kd, int mix) {
+        if constexpr (MI != 4) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) kd[r] = 0.f;
+          for (int r = 0; r < 16; ++r) kd[r] = 0.f;
+        }
 #pragma unroll
-        for (int q = 0; q < NKD; ++q) kd = __builtin_amdgcn_mfma_f32_32x32x16_f16(ajs[q], bih[mix][q], kd, 0, 0, 0);
+        for (int q = 0; q < NKD; ++q) dist_step(kd, ajs[q], bih[mix][q], q == 0);
       };
       // B fragments (probe tile) of a block are fetched from LDS one block ahead: the ds_read latency in front of the first MFMA
       // of every block was ~10 % of the tile
@@ -746,13 +709,23 @@ __global__ __launch_bounds__(64 * H3Waves<PK>::value, PK ? 1 : 2) void k_rbf_mfm
       constexpr bool kPrefB = PK && (NB == 1 || DPAD <= 8);  // elsewhere the second fragment set does not fit in 256 VGPRs
       if (kPrefB) load_b(0, 0);
       {
-        static_assert(kMI == 2, "block order (jb, mi) = (0,0), (0,1), (1,0), (1,1)");
+        static_assert(kMI >= 2, "the first two blocks of a tile are (jb 0, mi 0) and (jb 0, mi 1)");
         floatx16 kd;
         load_a(0);
         dist(kd, 0);
         dist(kdn, 1);
+        // (MI = 4: the asm MFMAs hide their result hazard from the compiler.  Tie the first reader of kd behind the LAST of them:
+        // two MFMAs of this wave, i.e. 64 cycles of its own matrix pipe, then lie between the write of kd and that read.)
+        if constexpr (MI == 4) asm volatile("" : "+v"(kd));
+        if constexpr (MI == 4) {  // step by step over all eight pairs: eight independent instructions between producer and consumer
 #pragma unroll
-        for (int pr = 0; pr < 8; ++pr) exp_split_pair(kd, pr, kDiag, false, ah, al);
+          for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int pr = 0; pr < 8; ++pr) split_step(kd, pr, st, false, ah, al);
+        } else {
+#pragma unroll
+          for (int pr = 0; pr < 8; ++pr) exp_split_pair(kd, pr, kDiag, false, ah, al);
+        }
       }
 #pragma unroll
       for (int blk = 0; blk < 2 * kMI; ++blk) {
@@ -768,8 +741,10 @@ __global__ __launch_bounds__(64 * H3Waves<PK>::value, PK ? 1 : 2) void k_rbf_mfm
         if (has_next2 && mi2 == 0) load_a(jb2);  // blocks (jb2, 0) and (jb2, 1) are issued from blocks blk and blk + 1
         const bool negn = ((jbn + min_) & 1) != 0;
         floatx16 kdn2;
+        if constexpr (MI != 4) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) kdn2[r] = 0.f;
+          for (int r = 0; r < 16; ++r) kdn2[r] = 0.f;
+        }
         half8 ahn[2], aln[2];
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
@@ -777,14 +752,24 @@ __global__ __launch_bounds__(64 * H3Waves<PK>::value, PK ? 1 : 2) void k_rbf_mfm
           __builtin_amdgcn_sched_barrier(0);
           acc[mi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w == 2 ? al[s] : ah[s], w == 1 ? blb[cur][s][nb] : bhb[cur][s][nb],
                                                                acc[mi][nb], 0, 0, 0);
-          if (has_next2 && m >= MD && m - MD < NKD)
-            kdn2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ajs[m - MD], bih[mi2][m - MD], kdn2, 0, 0, 0);
+          if (has_next2 && m >= MD && m - MD < NKD) dist_step(kdn2, ajs[m - MD], bih[mi2][m - MD], m == MD);
           if (kPrefB && m == 0 && blk == 0 && 2 * kMI > kMI) load_b(1, 1);  // the second column block's fragments, two blocks ahead
           __builtin_amdgcn_sched_barrier(0);
           if (has_next) {
+            if constexpr (MI == 4) {
+              // pair p enters the four-step pipeline behind MFMA kSplitGap[p]; its last step follows MFMA kSplitGap[p] + 3 <= 11
+              static_assert(NM == 12, "fat waves: 64-probe chunks");
+              constexpr int kSplitGap[8] = {0, 1, 2, 3, 5, 6, 7, 8};
 #pragma unroll
-            for (int pr = 0; pr < 8; ++pr)
-              if (pr >= 8 * m / NM && pr < 8 * (m + 1) / NM) exp_split_pair(kdn, pr, kDiag && jbn == min_, negn, ahn, aln);
+              for (int st = 0; st < 4; ++st)
+#pragma unroll
+                for (int pr = 0; pr < 8; ++pr)
+                  if (kSplitGap[pr] + st == m) split_step(kdn, pr, st, negn, ahn, aln);
+            } else {
+#pragma unroll
+              for (int pr = 0; pr < 8; ++pr)
+                if (pr >= 8 * m / NM && pr < 8 * (m + 1) / NM) exp_split_pair(kdn, pr, kDiag && jbn == min_, negn, ahn, aln);
+            }
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1030,12 +1015,35 @@ __global__ __launch_bounds__(256) void k_pack_tiles(const float* __restrict__ xs
 // ceil(wgs s / 256) rounds of 1/s of the columns each; pick the s (at most 16, at least 8 tiles per split) that minimises
 // rounds / s, plus a small charge per split for the prologue and the partial sums.  (n = 45 730: 90 row blocks -> s = 8, 720
 // workgroups in 3 rounds = 0.375 of an unsplit launch, where "fill one round" (s = 2) gives 0.5.)
-static int rbf_split_count(int64_t nrow, int64_t n, int64_t p) {
+// Which kernel runs a 33..64-vector chunk of an RBF operator with d <= 8 (BASELINE config 4's matvec):
+//   default        the fat-wave kernel (mfx_rbf_fat.hip): one wave per SIMD, 80 % matrix-pipe share, -16 % cycles against h3
+//   MFX_RBF_FAT=0  the same-program kernel k_rbf_mfma_apply_h3 (two waves per SIMD), which also takes every other shape
+//   MFX_RBF_PC=1   the producer / consumer kernel (mfx_rbf_pc.hip): measured SLOWER (51 % matrix-pipe share);
+//                  kept as the recorded experiment, parity-tested, never the default
+static bool rbf_pc() {
+  static const int v = [] {
+    const char* e = getenv("MFX_RBF_PC");
+    return e ? atoi(e) : 0;
+  }();
+  return v != 0;
+}
+static bool rbf_fat() {
+  static const int v = [] {
+    const char* e = getenv("MFX_RBF_FAT");
+    return e ? atoi(e) : 1;
+  }();
+  return v != 0;
+}
+// the producer / consumer kernel takes 33..64-probe chunks with d <= 12 (its LDS ring + images do not fit next to a d = 16 column operand)
+static bool rbf_pc_eligible(int64_t p, int dpad) { return p > 32 && dpad <= 12 && rbf_pc(); }
+
+static int rbf_split_count(int64_t nrow, int64_t n, int64_t p, int dpad) {
   static const int forced = [] {
     const char* e = getenv("MFX_RBF_SPLIT");  // A/B: force the split count
     return e ? atoi(e) : 0;
   }();
-  const int64_t wgs = ((nrow + 511) / 512) * ((p + (p <= 32 ? 32 : 64) - 1) / (p <= 32 ? 32 : 64));
+  const int64_t wg_rows = rbf_pc_eligible(p, dpad) ? 256 : 512;
+  const int64_t wgs = ((nrow + wg_rows - 1) / wg_rows) * ((p + (p <= 32 ? 32 : 64) - 1) / (p <= 32 ? 32 : 64));
   const int64_t ntile = (n + 63) / 64;
   int64_t smax = ntile / 8;
   if (forced > 0) return forced <= 16 && forced <= ntile ? forced : 1;
@@ -1064,7 +1072,7 @@ int64_t rbf_pack_ws_bytes(const mfx_operator* op, int64_t p) {
   const int dpad = op->d <= 4 ? 4 : op->d <= 8 ? 8 : op->d <= 12 ? 12 : 16;
   const int64_t arow = ((3 * (dpad + 2) + 15) / 16) * 16 + 8;
   return align_up(rbf_pack_bytes_v(op->n, p), 256) + align_up(ntile * 64 * arow * 2, 256) +
-         align_up((int64_t)rbf_split_count(op_nrows(op), op->n, p) * p * align_up(op_nrows(op), 4) * 4, 256);
+         align_up((int64_t)rbf_split_count(op_nrows(op), op->n, p, dpad) * p * align_up(op_nrows(op), 4) * 4, 256);
 }
 
 // distances of the pipelined kernel on the f16 matrix pipe (3-product split, alternating block sign: default) or on the
@@ -1106,7 +1114,7 @@ static int launch_apply_h3k(const mfx_operator* op, const float* xs, const float
   const int64_t arow = ((3 * (DPAD + 2) + 15) / 16) * 16 + 8;
   float* part = pk ? reinterpret_cast<float*>(static_cast<char*>(pk) + off_a + align_up(ntile * 64 * arow * 2, 256)) : nullptr;
   const int64_t ldpart = align_up(nrow, 4);  // the partials have their own stride (any n, any ldy)
-  const int nsplit = part ? rbf_split_count(nrow, n, p) : 1;
+  const int nsplit = part ? rbf_split_count(nrow, n, p, DPAD) : 1;
   const dim3 grid3(grid.x, grid.y, (unsigned)nsplit);
   const dim3 grid_pk((unsigned)((nrow + 511) / 512), grid.y, (unsigned)nsplit);
   int* rangeflag = reinterpret_cast<int*>(vscale + 3 * p);  // zeroed by row_scales
@@ -1117,22 +1125,42 @@ static int launch_apply_h3k(const mfx_operator* op, const float* xs, const float
     MFX_CHECK_LAUNCH();
   }
   // LDS: the two tile buffers + (pre-packed variant) the chain masters of 8 waves x (2 NB - 1) blocks x 16 registers x 64 lanes
-#define MFX_H3_LAUNCH(V4, DHV, PKV, FLAG)                                                                            \
+#define MFX_H3_LAUNCH_MI(V4, DHV, PKV, FLAG, MIV)                                                                   \
   {                                                                                                                  \
-    constexpr size_t kSm = 2 * sizeof(RbfTileH3<DPAD, NB, 64, !(PKV)>) + ((PKV) ? (size_t)8 * (2 * NB - 1) * 16 * 64 * 4 : 0); \
+    constexpr int kWv = H3Waves<PKV, MIV>::value;                                                                    \
+    constexpr size_t kSm = 2 * sizeof(RbfTileH3<DPAD, NB, 64, !(PKV)>) + ((PKV) ? (size_t)kWv * ((MIV) * NB - 1) * 16 * 64 * 4 : 0); \
+    static_assert(kSm <= 160 * 1024, "LDS budget of the pipelined matvec");                                          \
     if (kSm > 64 * 1024)                                                                                             \
-      MFX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rbf_mfma_apply_h3<DPAD, NB, V4, KIND, DHV, PKV>), \
+      MFX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rbf_mfma_apply_h3<DPAD, NB, V4, KIND, DHV, PKV, MIV>), \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSm));                       \
-    k_rbf_mfma_apply_h3<DPAD, NB, V4, KIND, DHV, PKV><<<(PKV) ? grid_pk : grid3, 64 * H3Waves<PKV>::value, kSm, stream>>>( \
+    k_rbf_mfma_apply_h3<DPAD, NB, V4, KIND, DHV, PKV, MIV><<<(PKV) ? grid_pk : grid3, 64 * kWv, kSm, stream>>>(        \
         xs, sq, n, (const float*)op->outputscale, (const float*)op->noise, vscale, x, ldx, y, ldy, p, pkv, pka, part, FLAG, ldpart, row0, rend); \
   }
+#define MFX_H3_LAUNCH(V4, DHV, PKV, FLAG) MFX_H3_LAUNCH_MI(V4, DHV, PKV, FLAG, 2)
   if (pack) {
-    if (vec4) MFX_H3_LAUNCH(true, true, true, rangeflag) else MFX_H3_LAUNCH(false, true, true, rangeflag)
+    bool pc_done = false;
+    if (NB == 2 && rbf_pc_eligible(p, DPAD)) {  // producer / consumer kernel (mfx_rbf_pc.hip): 256-row workgroups
+      const dim3 grid_pc((unsigned)((nrow + 255) / 256), grid.y, (unsigned)nsplit);
+      MFX_TRY(rbf_pc_launch(DPAD, KIND, vec4, grid_pc, stream, xs, sq, n, (const float*)op->outputscale, (const float*)op->noise,
+                            vscale, x, ldx, y, ldy, p, pkv, pka, part, rangeflag, ldpart, row0, rend));
+      pc_done = true;
+    }
+    if constexpr (KIND == MFX_KERNEL_RBF && NB == 2 && DPAD <= 8) {
+      if (!pc_done && rbf_fat()) {  // fat waves (mfx_rbf_fat.hip): four waves of 128 rows, one per SIMD
+        MFX_TRY(rbf_fat_launch(DPAD, vec4, grid_pk, stream, xs, sq, n, (const float*)op->outputscale, (const float*)op->noise, vscale,
+                               x, ldx, y, ldy, p, pkv, pka, part, rangeflag, ldpart, row0, rend));
+        pc_done = true;
+      }
+    }
+    if (!pc_done) {
+      if (vec4) MFX_H3_LAUNCH(true, true, true, rangeflag) else MFX_H3_LAUNCH(false, true, true, rangeflag)
+    }
     if (vec4) MFX_H3_LAUNCH(true, false, false, rangeflag) else MFX_H3_LAUNCH(false, false, false, rangeflag)  // runs only if flagged
   } else {  // MFX_RBF_DIST=0 / MFX_RBF_PACK=0 (or no pack workspace): fp32-MFMA distances, in-kernel split of the probe tiles
     if (vec4) MFX_H3_LAUNCH(true, false, false, nullptr) else MFX_H3_LAUNCH(false, false, false, nullptr)
   }
 #undef MFX_H3_LAUNCH
+#undef MFX_H3_LAUNCH_MI
   MFX_CHECK_LAUNCH();
   if (nsplit > 1) {
     k_split_reduce<<<dim3((unsigned)((nrow + 255) / 256), (unsigned)p), 256, 0, stream>>>(part, ldpart, nsplit, p, nrow, ldy,
