@@ -26,14 +26,18 @@
 namespace mfx {
 
 // MFMA slots of a block: 0-9 contraction c0-c9, 10 distance d0, 11 c10, 12 d1, 13 c11.  Entry = slot + 14 * lag: lag 1 = in the
-// NEXT block (only pairs of the second k-step, whose consumers c6.. come after slot 5).
+// NEXT block (only pairs of the second k-step, whose consumers c6.. come after slot 5).  Steps of the split chain of a pair of
+// entries (2p, 2p + 1):  e: v_exp_f32 of one entry;  h: hi pair = v_cvt_pk_f16_f32;  m: lo half = f16(k - hi) written straight into
+// its half of the packed lo register (v_fma_mixlo_f16 for the even entry, then v_fma_mixhi_f16 for the odd one: 40 VALU
+// instructions per block instead of 48 with v_fma_mix_f32 x 2 + v_cvt_pk; bit-identical).  Issue cycles per slot (exp 8, others
+// 4): 16 12 16 12 16 20 16 16 16 16 20 16 16 16 -- under the ~24 that hide behind an MFMA, and no step follows its producer
+// within one slot.
 struct FatSplit {
-  int e[16], h[8], f[16], l[8];
+  int e[16], h[8], m[16];
 };
 constexpr FatSplit kSplit = {{0, 1, 2, 3, 4, 5, 5, 6, 7, 8, 9, 10, 10, 11, 12, 13},
                              {2, 4, 6, 7, 9, 11, 12, 14},
-                             {3, 3, 5, 5, 7, 7, 8, 8, 10, 10, 12, 12, 13, 13, 15, 15},
-                             {4, 6, 8, 9, 11, 13, 14, 16}};
+                             {3, 4, 5, 6, 7, 8, 8, 9, 10, 11, 12, 13, 13, 14, 15, 16}};
 
 template <int DPAD>
 struct FatSmem {
@@ -158,41 +162,38 @@ __global__ __launch_bounds__(256, 1) void k_rbf_fat_apply(const float* __restric
   // ---- one micro-step of the split chain of a distance block, in place: t = 0 exp2 of entry i; 1 hi = f16 of pair i; 2 entry i
   //      minus its hi; 3 lo = f16 of pair i.  Register r of the block <-> column (r & 3) + 8 (r >> 2) + 4 lhi; the pair (2p, 2p + 1)
   //      is one packed register of the A fragment of k-step p >> 2. --------------------------------------------------------------
-  auto split_op = [&](floatx16& w, half8 (&ah)[2], half8 (&al)[2], const int t, const int i, const bool neg) {
+  auto split_op = [&](floatx16& w, half8 (&ah)[2], half8 (&al)[2], unsigned (&lopk)[8], const int t, const int i, const bool neg) {
     if (t == 0) {
       w[i] = __builtin_amdgcn_exp2f(neg ? -w[i] : w[i]);
     } else if (t == 1) {
       const half2v h = {(_Float16)w[2 * i], (_Float16)w[2 * i + 1]};  // one v_cvt_pk_f16_f32, round to nearest
       ah[i >> 2][(i & 3) * 2] = h[0];
       ah[i >> 2][(i & 3) * 2 + 1] = h[1];
-    } else if (t == 2) {
+    } else {
       const int pr = i >> 1;
       const half2v h = {ah[pr >> 2][(pr & 3) * 2], ah[pr >> 2][(pr & 3) * 2 + 1]};
       const unsigned hb = __builtin_bit_cast(unsigned, h);
-      float l;
-      if (i & 1) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hb), "v"(w[i]));
-      else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hb), "v"(w[i]));
-      w[i] = l;
-    } else {
-      const half2v l = {(_Float16)w[2 * i], (_Float16)w[2 * i + 1]};
-      al[i >> 2][(i & 3) * 2] = l[0];
-      al[i >> 2][(i & 3) * 2 + 1] = l[1];
+      if ((i & 1) == 0) {
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lopk[pr]) : "v"(hb), "v"(w[i]));
+      } else {
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lopk[pr]) : "v"(hb), "v"(w[i]));
+        const half2v l = __builtin_bit_cast(half2v, lopk[pr]);
+        al[pr >> 2][(pr & 3) * 2] = l[0];
+        al[pr >> 2][(pr & 3) * 2 + 1] = l[1];
+      }
     }
   };
   // all micro-steps of the table that fall behind MFMA slot `slot` (lag 0: on the next block's data, lag 1: on this block's)
-  auto split_slot = [&](const int slot, const int lag, floatx16& w, half8 (&ah)[2], half8 (&al)[2], const bool neg) {
+  auto split_slot = [&](const int slot, const int lag, floatx16& w, half8 (&ah)[2], half8 (&al)[2], unsigned (&lopk)[8], const bool neg) {
 #pragma unroll
     for (int i = 0; i < 16; ++i)
-      if (kSplit.e[i] == slot + 14 * lag) split_op(w, ah, al, 0, i, neg);
+      if (kSplit.e[i] == slot + 14 * lag) split_op(w, ah, al, lopk, 0, i, neg);
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-      if (kSplit.h[i] == slot + 14 * lag) split_op(w, ah, al, 1, i, neg);
+      if (kSplit.h[i] == slot + 14 * lag) split_op(w, ah, al, lopk, 1, i, neg);
 #pragma unroll
     for (int i = 0; i < 16; ++i)
-      if (kSplit.f[i] == slot + 14 * lag) split_op(w, ah, al, 2, i, neg);
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-      if (kSplit.l[i] == slot + 14 * lag) split_op(w, ah, al, 3, i, neg);
+      if (kSplit.m[i] == slot + 14 * lag) split_op(w, ah, al, lopk, 2, i, neg);
   };
 
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): my pieces of tiles 0 and 1
@@ -202,6 +203,7 @@ __global__ __launch_bounds__(256, 1) void k_rbf_fat_apply(const float* __restric
   // ---- pipeline state.  Blocks are numbered along the sweep: block = 8 tile + 4 jb + mi. --------------------------------------
   floatx16 wc, wn, wd;          // distance blocks: current (its last pairs still being split), next (being split), next but one
   half8 ahc[2], alc[2], ahn[2], aln[2];   // A fragments (hi, lo) x k-step of the current and of the next block
+  unsigned lpc[8], lpn[8];                 // packed lo pairs in the making (between the mixlo and the mixhi step)
   half8 vf[2][2][2];            // probe fragments of the current column block [k-step][probe block][hi / lo]
   half8 ajs[2][NKD];            // column operand of a column block, by parity
   // prologue (once per sweep, not per tile): blocks 0 and 1 by hand
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(256, 1) void k_rbf_fat_apply(const float* __restric
   asm volatile("" : "+v"(wc));  // ties the first reader of wc behind the last of these MFMAs (two MFMAs after the one that wrote wc)
   // block 0's split as far as the table places it before a block boundary (its lag-1 steps run in the loop, like every block's)
 #pragma unroll
-  for (int slot = 0; slot < 14; ++slot) split_slot(slot, 0, wc, ahc, alc, false);
+  for (int slot = 0; slot < 14; ++slot) split_slot(slot, 0, wc, ahc, alc, lpc, false);
 
   const float sc = outputscale[0];
   int tl = 0;
@@ -259,8 +261,8 @@ __global__ __launch_bounds__(256, 1) void k_rbf_fat_apply(const float* __restric
                                                                acc[mi][nb], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        split_slot(slot, 1, wc, ahc, alc, neg_c);  // this block's late pairs first (their consumers are a few slots away)
-        split_slot(slot, 0, wn, ahn, aln, neg_n);
+        split_slot(slot, 1, wc, ahc, alc, lpc, neg_c);  // this block's late pairs first (their consumers are a few slots away)
+        split_slot(slot, 0, wn, ahn, aln, lpn, neg_n);
         // fragment reads, one per gap: the probe fragments of the NEXT column block during this one (blocks mi = 1, 2: sixteen
         // reads... eight per block), the column operand of the column block after that in block mi = 1
         if (mi == 1 && slot < NKD) {
@@ -296,6 +298,8 @@ __global__ __launch_bounds__(256, 1) void k_rbf_fat_apply(const float* __restric
       alc[0] = aln[0]; alc[1] = aln[1];
       wc = wn;
       wn = wd;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) lpc[q] = lpn[q];
     }
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);  // no LDS-DMA of mine is left in flight
