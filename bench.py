@@ -54,7 +54,7 @@ def parse(argv=None):
     ap.add_argument("--row-group", type=int, default=0, help="strong scaling: ranks per row group (0 = all ranks: pure row sharding)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-modes", action="store_true", help="skip the timings of the other two arithmetic modes")
-    ap.add_argument("--cpu-sample-n", type=int, default=0, help="0 = calibrate so that one oracle run takes ~12 s")
+    ap.add_argument("--cpu-sample-n", type=int, default=0, help="0 = 8192 (smaller on a host where that would exceed ~30 s per run)")
     ap.add_argument("--kernel", default="rbf", choices=["rbf", "matern32", "matern12"],
                     help="kernel family (BASELINE config 4 is the RBF kernel; the reference's UCI runs use matern32)")
     ap.add_argument("--precision", default=DEFAULT_MODE, choices=list(MODES),
@@ -80,20 +80,52 @@ def inv_softplus(x):
 # launcher: `python bench.py --gpus N` without a launcher starts its own ranks (the parent never touches a GPU)
 # ------------------------------------------------------------------------------------------------------------------------
 def launch_children(args, argv):
-    import socket
+    """Start the ranks, watch ALL of them: the first rank that dies takes the others with it (a rank that fails at start-up --
+    --gpus beyond the device count, an RCCL init error -- must not leave its peers waiting in the rendezvous until the
+    time-out).  Rendezvous through a file store owned by the parent: no port to lose between choosing it and binding it."""
+    import tempfile
 
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    store = tempfile.NamedTemporaryFile(prefix="mfx_bench_store_", delete=False)
+    store.close()
+    os.unlink(store.name)  # torch's FileStore creates it
     procs = []
     for rank in range(args.gpus):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus), MFX_BENCH_INIT=f"file://{store.name}",
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         # rank 0 inherits stdout (its JSON line is the result); the others keep stderr only
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
                                       stdout=None if rank == 0 else subprocess.DEVNULL))
-    rcs = [p.wait() for p in procs]
-    return next((rc for rc in rcs if rc != 0), 0)
+    rc = 0
+    try:
+        live = list(procs)
+        while live:
+            time.sleep(0.2)
+            for pr in list(live):
+                code = pr.poll()
+                if code is None:
+                    continue
+                live.remove(pr)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for other in live:  # exact PIDs of our own children
+                        other.terminate()
+            if rc != 0 and live:
+                deadline = time.time() + 10
+                for other in live:
+                    try:
+                        other.wait(timeout=max(0.1, deadline - time.time()))
+                    except subprocess.TimeoutExpired:
+                        other.kill()
+                live = []
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+        try:
+            os.unlink(store.name)
+        except OSError:
+            pass
+    return rc
 
 
 # ------------------------------------------------------------------------------------------------------------------------
@@ -101,9 +133,12 @@ def launch_children(args, argv):
 # ------------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(args):
     """The oracle (NumPy port of the reference algorithm, kind "port") on a bounded sample of the same workload: identical
-    d, k and hyper-parameters, ONE probe, n reduced.  Protocol: one warm-up, then the MEDIAN of 5 timed
-    runs at the sample size; the Gram work scales as n^2, so the full-size figure is the measured one times (n_sample / n)^2
-    (both are in the line)."""
+    d, k and hyper-parameters, ONE probe, n reduced to 8192 (6 % of N; ~4 s per run on the 16 host cores of the 1-GPU box).
+    Protocol: one warm-up, then the MEDIAN of 5 timed runs at the sample size.  The full-size figure is an
+    extrapolation with the exponent FITTED from two measured sizes (the 2048-point calibration run and the sample), not assumed:
+    time ~ n^e, e in the line (the Gram work alone would give 2)."""
+    import math
+
     import numpy as np
     from threadpoolctl import threadpool_limits
 
@@ -121,23 +156,28 @@ def cpu_baseline(args):
         return time.perf_counter() - t0
 
     with threadpool_limits(limits=threads):
-        ns = args.cpu_sample_n
-        if ns <= 0:  # calibrate on a small run: aim at ~12 s per timed run (6 runs ~ 75 s)
-            t_cal = once(2048)
-            ns = int(min(16384, max(2048, 2048 * (12.0 / max(t_cal, 1e-3)) ** 0.5)) // 512 * 512)
+        n_cal = 2048
+        once(n_cal)
+        t_cal = sorted(once(n_cal) for _ in range(3))[1]
+        ns = args.cpu_sample_n if args.cpu_sample_n > 0 else 8192
+        if args.cpu_sample_n <= 0 and t_cal * (ns / n_cal) ** 2 > 30.0:  # a slow host: keep the whole leg near a minute
+            ns = int(n_cal * (30.0 / t_cal) ** 0.5) // 512 * 512
         once(ns)  # warm-up
         times = sorted(once(ns) for _ in range(5))
     med = times[2]
     measured = 1.0 / med
+    expo = math.log(med / t_cal) / math.log(ns / n_cal) if ns > n_cal else 2.0
     return {
-        "value": measured * (ns / args.n) ** 2,
+        "value": measured * (ns / args.n) ** expo,
         "unit": "probes/s",
         "cores": threads,
         "kind": "port",
         "measured_at_sample": {"n": ns, "probes_per_s": measured, "seconds_median_of_5": med, "seconds_all": times},
+        "scaling_fit": {"n_small": n_cal, "seconds_small_median_of_3": t_cal, "n_sample": ns, "seconds_sample": med, "exponent": expo,
+                        "value_with_exponent_2": measured * (ns / args.n) ** 2},
         "sample": f"NumPy oracle (matrix-free kernel, re-evaluated per matvec), 1 probe, k={args.k}, d={args.d}, n={ns} (of {args.n}): "
-                  f"1 warm-up + median of 5 runs = {med:.2f} s = {measured:.4f} probes/s at n={ns}; value = that x (n_sample/n)^2 "
-                  f"(Gram work ~ n^2), BLAS threads={threads}",
+                  f"1 warm-up + median of 5 runs = {med:.2f} s = {measured:.4f} probes/s at n={ns}; value = that x (n_sample/n)^e with "
+                  f"e = {expo:.2f} fitted from the runs at n={n_cal} ({t_cal:.2f} s) and n={ns}; BLAS threads={threads}",
     }
 
 
@@ -150,7 +190,10 @@ def run_stub(args, world, rank):
     import torch.distributed as dist
 
     if world > 1:
-        dist.init_process_group(args.stub)
+        how = {}
+        if os.environ.get("MFX_BENCH_INIT"):
+            how = dict(init_method=os.environ["MFX_BENCH_INIT"], rank=rank, world_size=world)
+        dist.init_process_group(args.stub, **how)
         dist.barrier()
     t = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
     if world > 1:
@@ -191,11 +234,14 @@ def main(argv=None):
     if world > 1:
         import datetime
 
-        limit = datetime.timedelta(seconds=600)  # a rank that dies must not leave the others waiting in a collective for long
+        limit = datetime.timedelta(seconds=180)  # a rank that dies must not leave the others waiting in a collective for long
+        how = {}
+        if os.environ.get("MFX_BENCH_INIT"):  # started by launch_children: the parent's file store (a launcher sets MASTER_*)
+            how = dict(init_method=os.environ["MFX_BENCH_INIT"], rank=rank, world_size=world)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev, timeout=limit)  # nccl == RCCL on ROCm; one rank per GPU
+            dist.init_process_group("nccl", device_id=dev, timeout=limit, **how)  # nccl == RCCL on ROCm; one rank per GPU
         else:
-            dist.init_process_group(args.backend, timeout=limit)
+            dist.init_process_group(args.backend, timeout=limit, **how)
 
     from matfree_extensions import _lib, hutchinson, lanczos
     from matfree_extensions.distributed import Layout, reduce_estimate, shard_probes
@@ -280,12 +326,12 @@ def main(argv=None):
         achieved = flops_launch / (avg_ms * 1e-3) / 1e12 if apply_cnt else 0.0
         split = args.precision.startswith("f16x3")
         peak = MFMA_F16_PEAK_TFLOPS if split else MFMA_F32_PEAK_TFLOPS
-        kernel = ("k_rbf_mfma_apply_h3 (Gram matvec, fp32 emulated by 3 f16 MFMA products, distances included; pre-pass and "
-                  "split reduction inside the timed span)" if split else "k_rbf_mfma_apply (Gram matvec, exact fp32 MFMA)")
+        kernel = ("k_rbf_fat_apply (Gram matvec, one wave per SIMD; fp32 emulated by 3 f16 MFMA products, distances included; "
+                  "pre-pass and split reduction inside the timed span)" if split else "k_rbf_mfma_apply (Gram matvec, exact fp32 MFMA)")
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile) and world == 1:
-            traffic = json.load(open(tfile)).get("k_rbf_mfma_apply_h3_hbm_bytes_per_launch" if split
+            traffic = json.load(open(tfile)).get("k_rbf_fat_apply_hbm_bytes_per_launch" if split
                                                  else "k_rbf_mfma_apply_hbm_bytes_per_launch")
         mean, std, grads = out
         batch = count * k
@@ -301,14 +347,15 @@ def main(argv=None):
             "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32" if not split else "f32 (Gram contraction emulated with 3 f16 MFMA products, fp32 accumulate; accuracy vs "
-                                             "fp64 at this size: profiles/r02a_accuracy)",
+                                             "fp64 at this size: profiles/r03a_accuracy)",
             "data": "synthetic",
             "config": {
                 "workload": f"matrix-free RBF GP kernel N={n} d={d}, SLQ log-det value+grad, {k} Lanczos steps (full reortho) x "
                             f"{p_total} probes, fp32 (BASELINE config 4)",
                 "N": n, "d": d, "krylov_depth": k, "probes_total": p_total, "probes_on_this_rank": count,
                 "rows_on_this_rank": rows_local,
-                "parallelism": f"{layout.describe()}; world size seen by rank 0 = {dist.get_world_size() if world > 1 else 1}",
+                "parallelism": f"{layout.describe()}; world size seen by rank 0 = {dist.get_world_size() if world > 1 else 1}; "
+                               f"row-group collectives: {'libmfx -> RCCL (native)' if layout.native else ('host callbacks' if layout.comm is not None else 'none')}",
                 "gram_precision": args.precision, "kernel": args.kernel,
             },
             "modes": {"ms_per_step": modes,

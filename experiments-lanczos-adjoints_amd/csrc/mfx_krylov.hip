@@ -571,6 +571,11 @@ static int apply_sharded(const mfx_operator* op, const mfx_comm* cm, int transpo
                                    hipMemcpyDeviceToDevice, stream));
     const int rc = cm->exchange(cm->ctx, x, ldx, full, ldfull, p, op->dtype, transpose, stream);
     MFX_REQUIRE(rc == 0, MFX_ERR_CALLBACK, "exchange callback failed with code %d", rc);
+  } else if (cm->allgather_rows && nrows == nloc && (int64_t)cm->world * nloc == n) {
+    // every rank owns exactly nloc rows: the shards go straight into the (p, n) operator input, no pack / unpack copies
+    ScopedTimer t(3, stream);
+    const int rc = cm->allgather_rows(cm->ctx, x, ldx, full, ldfull, p, nloc, op->dtype, stream);
+    MFX_REQUIRE(rc == 0, MFX_ERR_CALLBACK, "all-gather (rows) failed with code %d", rc);
   } else {
     ScopedTimer t(3, stream);
     k_pack_shard<T><<<dim3((unsigned)((nloc + 255) / 256), (unsigned)p), 256, 0, stream>>>(x, ldx, nrows, nloc, (T*)ws.send);

@@ -76,6 +76,10 @@ ALLGATHER_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64
 EXCHANGE_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p)
 
 
+# ctx, local, ldlocal, full, ldfull, p, count, dtype, stream
+ALLGATHER_ROWS_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p)
+
+
 class Comm(C.Structure):
     """mirror of ``struct mfx_comm`` (row-sharded drivers)."""
 
@@ -87,6 +91,7 @@ class Comm(C.Structure):
         ("allgather", ALLGATHER_T),
         ("ctx", C.c_void_p),
         ("exchange", EXCHANGE_T),
+        ("allgather_rows", ALLGATHER_ROWS_T),
     ]
 
 
@@ -116,6 +121,9 @@ SYMBOLS = {
         _I,
         [_OPP, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _GRP, _P, _I64, _P],
     ),
+    "mfx_rccl_unique_id": (_I, [_P, _I64]),
+    "mfx_comm_create_rccl": (_I, [_P, _I64, C.c_int32, C.c_int32, _I64, _CMP]),
+    "mfx_comm_destroy_rccl": (_I, [_CMP]),
     "mfx_sharded_workspace_bytes": (_I64, [_OPP, _CMP, _I64, _I64, _I64]),
     "mfx_arnoldi_forward_sharded": (_I, [_OPP, _CMP, _P, _I64, _I64, _I64, _I, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "mfx_arnoldi_adjoint_sharded": (

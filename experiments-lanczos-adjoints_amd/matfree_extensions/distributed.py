@@ -244,6 +244,45 @@ class RowComm:
         return cm, (cb_r, cb_g, failure, cb_x)
 
 
+class NativeRowComm(RowComm):
+    """RowComm whose ``mfx_comm`` is libmfx's own RCCL communicator (``mfx_comm_create_rccl``, csrc/mfx_comm.hip): the
+    all-gather of the iterate and the small all-reduces of a Krylov step are issued by the library itself on the stream of
+    the driver call -- no Python between two kernels.  Creation is collective over the row group: rank 0 makes the RCCL
+    unique id, torch.distributed (any backend) carries it to the others, every rank calls ``ncclCommInitRank`` on its
+    CURRENT device (``torch.cuda.set_device(local_rank)`` first).  The host-side helpers (``all_reduce_`` of the parameter
+    gradients, ``gather_rows``) and a sparse operator's neighbour exchange stay on torch.distributed."""
+
+    def __init__(self, n: int, group=None):
+        super().__init__(n, group)
+        lib = _lib.get()
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0:
+            _lib.check(lib.mfx_rccl_unique_id(uid.data_ptr(), uid.numel()))
+        if self.world > 1:
+            box = [bytes(uid.tolist())]
+            src = dist.get_process_group_ranks(group)[0] if group is not None else 0
+            dist.broadcast_object_list(box, src=src, group=group)
+            uid = torch.tensor(list(box[0]), dtype=torch.uint8)
+        self._cm = _lib.Comm()
+        _lib.check(lib.mfx_comm_create_rccl(uid.data_ptr(), uid.numel(), self.rank, self.world, self.nloc, C.byref(self._cm)))
+
+    def struct(self, ws, tensors=(), plans=None):
+        if plans is not None:  # neighbour exchange: callbacks (the exchange plan lives on the host side)
+            return super().struct(ws, tensors, plans)
+        return self._cm, (None, None, [], None)
+
+    def close(self):
+        if getattr(self, "_cm", None) is not None:
+            _lib.get().mfx_comm_destroy_rccl(C.byref(self._cm))
+            self._cm = None
+
+    def __del__(self):  # the communicator must go before the process group does: call close() explicitly in long-lived programs
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class _ShardedSumSq(torch.autograd.Function):
     """sum over ALL rows of v^2 from row shards (p, nrows) -> (p,), identical on every rank.  Backward: every rank holds
     the same downstream cotangent, and its rows enter the sum only through its own partial sum."""
@@ -311,7 +350,9 @@ class Layout:
     row_group_size = 1: pure probe sharding; = world size: pure row sharding (all probes on every rank).
     """
 
-    def __init__(self, n: int, row_group_size: int = 1, group=None):
+    def __init__(self, n: int, row_group_size: int = 1, group=None, native: bool | None = None):
+        """native: the row group's collectives as libmfx's own RCCL calls (NativeRowComm); default: whenever the process
+        group's backend is "nccl" (= RCCL), i.e. one GPU per rank -- gloo rehearsals keep the callback path."""
         on = dist.is_available() and dist.is_initialized()
         self.group = group
         self.world = dist.get_world_size(group) if on else 1
@@ -325,9 +366,13 @@ class Layout:
                 row_group, self.probe_index, self.probe_groups = group, 0, 1
             else:
                 raise ValueError(f"row group size {row_group_size} exceeds the world size {self.world}")
-            self.comm = RowComm(n, row_group)
+            if native is None:
+                native = on and dist.get_backend(row_group) == "nccl"
+            self.comm = NativeRowComm(n, row_group) if native else RowComm(n, row_group)
+            self.native = bool(native)
         else:
             self.comm, self.probe_index, self.probe_groups = None, rank, self.world
+            self.native = False
 
     def describe(self):
         return f"{self.replicas} row shard(s) x {self.probe_groups} probe group(s)"

@@ -226,14 +226,32 @@ typedef int (*mfx_allgather_fn)(void* ctx, const void* in, void* out, int64_t co
  * A^T (transpose = 1) read and that another rank owns; it may leave the rest untouched (it is never read).  NULL: all-gather. */
 typedef int (*mfx_exchange_fn)(void* ctx, const void* local, int64_t ldlocal, void* full, int64_t ldfull, int64_t p,
                                int dtype, int transpose, void* stream);
+/* Optional: all p vectors of the iterate at once, straight from the row shards (`local`, leading dimension ldlocal) into the
+ * operator input `full` (leading dimension ldfull): full[b][r count + i] = local_of_rank_r[b][i], count = nloc.  Used when every
+ * rank owns exactly nloc rows (n == world nloc); saves the pack / unpack copies around `allgather`.  NULL: `allgather`. */
+typedef int (*mfx_allgather_rows_fn)(void* ctx, const void* local, int64_t ldlocal, void* full, int64_t ldfull, int64_t p,
+                                     int64_t count, int dtype, void* stream);
 typedef struct mfx_comm {
   int32_t rank, world;
   int64_t nloc; /* rows per rank (last rank: n - rank * nloc >= 1) */
   mfx_allreduce_fn allreduce_sum;
   mfx_allgather_fn allgather;
   void* ctx;
-  mfx_exchange_fn exchange; /* optional, see above */
+  mfx_exchange_fn exchange;             /* optional, see above */
+  mfx_allgather_rows_fn allgather_rows; /* optional, see above */
 } mfx_comm;
+
+/* Native communicator: the function pointers of an mfx_comm filled with C functions of libmfx that issue ncclAllReduce /
+ * ncclAllGather (RCCL over xGMI) themselves, on the stream of the driver call -- no host-language callback on the path
+ * (round 2 went libmfx -> ctypes -> torch.distributed, ~280 callbacks per SLQ step).  RCCL is loaded at run time
+ * (dlopen "librccl.so.1"); MFX_ERR_UNSUPPORTED when it is not there.
+ *   mfx_rccl_unique_id   : one rank makes the id (ncclGetUniqueId; id: >= 128 bytes of host memory) and hands it to the others
+ *                          by any means (matfree_extensions/distributed.py broadcasts it with torch.distributed);
+ *   mfx_comm_create_rccl : COLLECTIVE over the `world` ranks (ncclCommInitRank on the calling thread's current device);
+ *   mfx_comm_destroy_rccl: releases the communicator (a no-op for an mfx_comm the caller filled in itself). */
+int mfx_rccl_unique_id(void* id, int64_t bytes);
+int mfx_comm_create_rccl(const void* id, int64_t bytes, int32_t rank, int32_t world, int64_t nloc, mfx_comm* out);
+int mfx_comm_destroy_rccl(mfx_comm* comm);
 
 int64_t mfx_sharded_workspace_bytes(const mfx_operator* op, const mfx_comm* comm, int64_t n, int64_t k, int64_t p);
 

@@ -47,6 +47,17 @@ def main():
     for a, b in zip(g0, g1):
         ok = ok and torch.allclose(a, b, rtol=5e-4, atol=5e-4 * a.abs().max().item())
     print("values", v0[:3].tolist(), v1[:3].tolist(), "ok", ok)
+    # the NATIVE path: libmfx's own one-rank RCCL communicator (ncclCommInitRank / ncclAllGather / ncclAllReduce issued from C, the
+    # grouped per-vector all-gather straight into the operator input); same arithmetic -> the same numbers as the callback path
+    from matfree_extensions.distributed import NativeRowComm
+
+    ncomm = NativeRowComm(n)
+    v2, g2 = run(RowShardedOp(op, ncomm))
+    torch.cuda.synchronize()
+    same = torch.equal(v1, v2) and all(torch.equal(a, b) for a, b in zip(g1, g2))
+    print("native communicator: values", v2[:3].tolist(), "bit-identical to the callback path:", same)
+    ok = ok and same
+    ncomm.close()
     dist.destroy_process_group()
     return 0 if ok else 1
 

@@ -120,10 +120,12 @@ def test_unsplit_sweep_with_chain_folds_three_kernels(tmp_path):
     h3 = _run_child(tmp_path, "h3", MFX_RBF_SPLIT="1", MFX_RBF_PC="0", MFX_RBF_FAT="0")
     for kernel in ("rbf", "matern32"):
         yb = np.load(h3 + "_" + kernel + ".npy")
-        for other in (fat, pc):
-            ya = np.load(other + "_" + kernel + ".npy")
-            rel = (np.abs(ya - yb).max(axis=1) / np.abs(yb).max(axis=1)).max()
-            assert rel < 2e-5, (kernel, other, rel)  # same arithmetic, different summation order inside a 64-column tile
+        ya = np.load(pc + "_" + kernel + ".npy")
+        rel = (np.abs(ya - yb).max(axis=1) / np.abs(yb).max(axis=1)).max()
+        assert rel < 2e-5, (kernel, rel)  # same arithmetic, different summation order inside a 64-column tile
+        # the fat-wave kernel keeps the order of every sum of the same-program kernel (blocks, k-steps, products, chain folds):
+        # bit-identical, so the accuracy tables of profiles/r02a_accuracy carry over (Matern: the child runs h3 both times)
+        assert np.array_equal(np.load(fat + "_" + kernel + ".npy"), yb), kernel
 
 
 def test_every_parity_case_on_the_non_default_kernels():

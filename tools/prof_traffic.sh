@@ -20,13 +20,13 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for row in csv.DictReader(open(f)):
         if row["Counter_Name"] != c:
             continue
-        for tag in ("k_rbf_mfma_apply_h3", "k_rbf_mfma_grad_h"):
+        for tag in ("k_rbf_fat_apply", "k_rbf_mfma_grad_h"):
             if tag in row["Kernel_Name"] and "false, false>" not in row["Kernel_Name"]:  # not the empty range-guard fallback launch
                 acc[tag][0] += float(row["Counter_Value"]); acc[tag][1] += 1
     for tag, (v, n) in acc.items():
         res[f"{tag}_{c}_KB"] = v / n
         res[f"{tag}_launches_{c}"] = n
-for tag in ("k_rbf_mfma_apply_h3", "k_rbf_mfma_grad_h"):
+for tag in ("k_rbf_fat_apply", "k_rbf_mfma_grad_h"):
     if f"{tag}_FETCH_SIZE_KB" in res:
         res[f"{tag}_hbm_bytes_per_launch"] = (2 * res[f"{tag}_FETCH_SIZE_KB"] + res[f"{tag}_WRITE_SIZE_KB"]) * 1024
 res["algorithmic_hbm_bytes_per_launch"] = 131072 * 8 * 4 + 2 * 64 * 131072 * 4 + 131072 * 4 * 9
