@@ -183,6 +183,18 @@ def uci_protein():
     save("uci_protein_2048.npz", **out)
 
 
+def uci_protein_full():
+    """BASELINE config 2's input at FULL size: all 45 730 rows of data/uci/protein/data.csv.gz, the 9 input columns z-scored as
+    uci_util.py:229-230 does, stored in fp32 (the dtype config 2 runs in): data only, 1.5 MB."""
+    import pandas as pd
+
+    raw = pd.read_csv("/root/reference/data/uci/protein/data.csv.gz", header=None).values.astype(np.float64)
+    assert raw.shape == (45730, 10)
+    X = raw[:, :9]
+    X = (X - X.mean(0)) / X.std(0)
+    save("uci_protein_X.npz", X=X.astype(np.float32), col_mean=raw[:, :9].mean(0), col_std=raw[:, :9].std(0))
+
+
 def gp_logml():
     """The "next" tier: short PCG runs (<= 8 steps: deterministic across implementations),
     pivoted partial Cholesky, Woodbury preconditioner and the composed log-marginal likelihood with its gradient."""
@@ -235,4 +247,5 @@ if __name__ == "__main__":
     csr_bloweybq()
     pde_wave()
     uci_protein()
+    uci_protein_full()
     gp_logml()

@@ -3,7 +3,8 @@
 * C4 (n = 131072, d = 8, k = 40): the north-star ACCURACY GATE -- every fp32 arithmetic mode of the Gram kernels against the
   fp64 HIP path (itself oracle-checked at small n, tests/test_gpu_parity.py), rtol 1e-4 on the SLQ value AND on the gradient.
 * C2 (UCI protein, d = 9, k = 30, 8 probes): the reference's own data (2048-row slice, tests/golden/uci_protein_2048.npz) against
-  the oracle, and the full size n = 45730 (synthetic inputs of the same shape: the data file does not travel) against fp64.
+  the oracle, and ALL 45 730 rows (tests/golden/uci_protein_X.npz, 1.4 MB of z-scored fp32 inputs) against fp64; C4's fp64 HIP
+  kernels against NumPy slabs of the oracle at n = 131072.
 * C3: SuiteSparse bloweybq next to 1138_bus (tests/test_gpu_parity.py).
 * C5 / (f)-2: the reference-produced pde_wave targets through expm_arnoldi + wave_operator.
 """
@@ -95,24 +96,97 @@ def test_c2_protein_slice_matches_the_oracle(tag, dtype, precision, vtol, gtol):
         assert np.allclose(got, ref, rtol=gtol, atol=gtol * np.abs(ref).max()), (name, got, ref)
 
 
+@pytest.mark.parametrize("tag", ["ard", "iso"])
 @pytest.mark.parametrize("precision", ["f16x3", "f16x3-matvec"])
-def test_c2_full_size_against_fp64(precision):
-    """n = 45730, d = 9, k = 30, 8 probes: the size at which the small-n column split of the matrix-core matvec is active (90 row
-    blocks of 512 < 256 CUs) and once silently ran unsplit.  Matvec and SLQ value-and-gradient against the fp64 kernels."""
-    n, d, k, p = 45730, 9, 30, 8
-    gen = torch.Generator().manual_seed(2)
-    X64 = torch.randn((n, d), generator=gen, dtype=torch.float32).double().to(DEV)
-    raw = (0.0, 0.0, 0.0)  # lengthscale = outputscale = softplus(0), noise = 1e-4 + softplus(0): SURVEY.md section 8(d) C2
+def test_c2_full_size_against_fp64(precision, tag):
+    """BASELINE config 2 as stated: ALL 45 730 rows of the UCI protein set (tests/golden/uci_protein_X.npz: the reference's
+    data/uci/protein/data.csv.gz, 9 input columns z-scored as util/uci_util.py:229-230 does), d = 9, k = 30, 8 probes, ARD and scalar
+    lengthscale.  It is also the size at which the small-n column split of the matrix-core matvec is active (90 row blocks of 512 <
+    256 CUs) and once silently ran unsplit.  Matvec and SLQ value-and-gradient against the fp64 kernels."""
+    X64 = torch.tensor(np.load(os.path.join(GOLD, "uci_protein_X.npz"))["X"], dtype=torch.float64, device=DEV)
+    n, d = X64.shape
+    assert (n, d) == (45730, 9)
+    k, p = 30, 8
+    # lengthscale = outputscale = softplus(0), noise = 1e-4 + softplus(0): SURVEY.md section 8(d) C2
+    raw_l = np.zeros(d) if tag == "ard" else 0.0
     probes = hutchinson.sampler_rademacher(X64[:, 0], num=p)(2)
+
+    def slq(X, precision):
+        dtype = X.dtype
+        params = [torch.tensor(raw_l, dtype=dtype, device=DEV, requires_grad=True)] + [torch.zeros((), dtype=dtype, device=DEV, requires_grad=True)
+                                                                                       for _ in range(2)]
+        op = gp_util.gram_operator(X, noise_minval=1e-4, precision=precision)
+        vals = lanczos.integrand_spd(torch.log, k, op)(probes.to(dtype), *params)
+        grads = torch.autograd.grad(vals.sum(), params)
+        return vals.double().mean().item(), np.concatenate([g.double().reshape(-1).cpu().numpy() / p for g in grads])
+
     with torch.no_grad():
-        raw64 = [torch.tensor(v, dtype=torch.float64, device=DEV) for v in raw]
+        raw64 = [torch.tensor(raw_l, dtype=torch.float64, device=DEV), torch.zeros((), dtype=torch.float64, device=DEV),
+                 torch.zeros((), dtype=torch.float64, device=DEV)]
         W64 = gp_util.gram_operator(X64, noise_minval=1e-4)(probes, *raw64)
         W32 = gp_util.gram_operator(X64.float(), noise_minval=1e-4, precision=precision)(probes.float(), *[r.float() for r in raw64])
         assert float((W32.double() - W64).norm() / W64.norm()) < 2e-6
-    v64, g64 = _slq(X64, raw, k, probes, "fp32")
-    v32, g32 = _slq(X64.float(), raw, k, probes, precision)
+    v64, g64 = slq(X64, "fp32")
+    v32, g32 = slq(X64.float(), precision)
     assert abs(v32 - v64) <= 1e-4 * abs(v64)
-    assert np.all(np.abs(g32 - g64) <= 1e-4 * np.abs(g64)), (g32, g64)
+    # per component relative to the largest gradient component (ARD: nine lengthscale derivatives of very different size)
+    assert np.all(np.abs(g32 - g64) <= 2e-4 * np.abs(g64).max()), (g32, g64)
+
+
+def test_c4_fp64_hip_rows_against_the_numpy_oracle_at_full_size():
+    """Closes the two-hop chain of the accuracy gate: the gate compares the fp32 modes with the fp64 HIP path, and that path was
+    oracle-checked only at n <= 2600.  Here, at n = 131072 (n^2 = 1.7e10 exceeds 32-bit index range), d = 8, C4's hyper-parameters:
+    256 rows -- the first block, the last block, a block across row 2^31 / n = 16384, a ragged block in the middle -- of
+      (a) the fp64 HIP matvec (mfx_op_apply, 4 vectors) against  kernel_matrix(X[rows], X) @ v + noise v[rows]  in NumPy fp64, 1e-12;
+      (b) the fp64 parameter sweep restricted to those row blocks (mfx_op_vjp_params with row0 / nrows) against the same sums
+          over the slab in NumPy, 1e-10.
+    Kernel: util/gp_util.py:160-176 (+ softplus parametrisation :187-201)."""
+    import ctypes as C
+
+    from matfree_extensions import _lib
+
+    n, d, p = 131072, 8, 4
+    gen = torch.Generator().manual_seed(4)
+    X64 = torch.randn((n, d), generator=gen, dtype=torch.float32).double()
+    Xn = X64.numpy()
+    raw = (INV(2.0), INV(1.0), INV(0.1))
+    ls, s, noise = orc.softplus(np.float64(raw[0])), orc.softplus(np.float64(raw[1])), orc.softplus(np.float64(raw[2]))
+    rng = np.random.default_rng(0)
+    V, Cc = rng.standard_normal((p, n)), rng.standard_normal((p, n))
+    Xd = X64.to(DEV)
+    op = gp_util.gram_operator(Xd)
+    cparams = op.constrain(*[torch.tensor(v, dtype=torch.float64, device=DEV) for v in raw])
+    Vd, Cd = torch.tensor(V, device=DEV), torch.tensor(Cc, device=DEV)
+    lib = _lib.get()
+    desc = op.descriptor(cparams, torch.float64, n)
+    ws = _lib.workspace(desc, n, 1, p, DEV)
+    y = torch.empty((p, n), dtype=torch.float64, device=DEV)
+    _lib.check(lib.mfx_op_apply(C.byref(desc), _lib.ptr(Vd), n, _lib.ptr(y), n, p, 0, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(DEV)))
+    y = y.cpu().numpy()
+    for row0, nrows in [(0, 64), (16320, 128), (70016, 37), (n - 64, 64)]:
+        rows = slice(row0, row0 + nrows)
+        K = orc.kernel_matrix("rbf", Xn[rows], Xn, ls, s)  # (nrows, n) slab
+        ref = V @ K.T + noise * V[:, rows]
+        assert np.allclose(y[:, rows], ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max()), (row0, np.abs(y[:, rows] - ref).max())
+        # parameter sweep over this row block: sum_b cot_b[rows]^T dA[rows, :] v_b
+        descb = op.descriptor(cparams, torch.float64, n)
+        descb.row0, descb.nrows = row0, nrows
+        wsb = _lib.workspace(descb, n, 1, p, DEV)
+        gs, gt = op.new_grads(*cparams)
+        Lb = Cd[:, rows].contiguous()
+        _lib.check(lib.mfx_op_vjp_params(C.byref(descb), _lib.ptr(Lb), nrows, _lib.ptr(Vd), n, p, C.byref(gs), _lib.ptr(wsb), wsb.numel(),
+                                         _lib.stream_ptr(DEV)))
+        S = Cc[:, rows].T @ V  # (nrows, n)
+        g_s = (S * K).sum() / s
+        W = S * (s * orc.kernel_lengthscale_weight("rbf", Xn[rows], Xn, ls))
+        sqn = (Xn * Xn).sum(-1)
+        diff2 = np.maximum(0.0, sqn[rows, None] + sqn[None, :] - 2.0 * Xn[rows] @ Xn.T)
+        diff2[np.arange(nrows), np.arange(row0, row0 + nrows)] = 0.0
+        g_l = (W * diff2).sum() / ls**3
+        g_n = float((Cc[:, rows] * V[:, rows]).sum())
+        got = [float(t.double().reshape(-1)[0]) for t in gt]  # derivatives w.r.t. the CONSTRAINED parameters (lengthscale, outputscale, noise)
+        for name, a, b in zip(("lengthscale", "outputscale", "noise"), got, (g_l, g_s, g_n)):
+            assert abs(a - b) <= 1e-10 * max(abs(b), abs(g_l), abs(g_s)), (row0, name, a, b)
 
 
 # ------------------------------------------------------------------------------------------------------------------------

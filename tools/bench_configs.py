@@ -47,15 +47,17 @@ def c1():
 
 
 def c2():
-    n, d, k, p = 45730, 9, 30, 8
-    g = torch.Generator().manual_seed(2)
-    X = torch.randn(n, d, generator=g, dtype=torch.float32).to(dev)
-    params = [torch.zeros((d,) if i == 0 else (), dtype=torch.float32, device=dev, requires_grad=True) for i in range(3)]
+    # BASELINE config 2 on its own data: all 45 730 rows of the UCI protein set, z-scored (tests/golden/uci_protein_X.npz)
+    k, p = 30, 8
+    X = torch.tensor(np.load(os.path.join(ROOT, "tests", "golden", "uci_protein_X.npz"))["X"], dtype=torch.float32, device=dev)
+    n, d = X.shape
     probes = torch.tensor(orc.rademacher(2, p, n), dtype=torch.float32, device=dev)
-    f = lanczos.integrand_spd(torch.log, k, gp_util.gram_operator(X, noise_minval=1e-4))
-    fwd = timeit(lambda: f(probes, *params), reps=3, warm=1)
-    both = timeit(lambda: torch.autograd.grad(f(probes, *params).sum(), params), reps=3, warm=1)
-    print(f"C2-like RBF N={n} d={d} ARD k={k} p={p} fp32 (synthetic X; UCI protein has this shape): value {fwd:.2f} ms, value+grad {both:.2f} ms")
+    for tag, shape in (("ARD", (d,)), ("scalar lengthscale", ())):
+        params = [torch.zeros(shape if i == 0 else (), dtype=torch.float32, device=dev, requires_grad=True) for i in range(3)]
+        f = lanczos.integrand_spd(torch.log, k, gp_util.gram_operator(X, noise_minval=1e-4))
+        fwd = timeit(lambda: f(probes, *params), reps=3, warm=1)
+        both = timeit(lambda: torch.autograd.grad(f(probes, *params).sum(), params), reps=3, warm=1)
+        print(f"C2 UCI protein RBF N={n} d={d} {tag} k={k} p={p} fp32: value {fwd:.2f} ms, value+grad {both:.2f} ms")
 
 
 def c3():
