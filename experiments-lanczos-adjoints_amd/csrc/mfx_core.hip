@@ -88,7 +88,17 @@ struct GraphEntry {
   hipGraphExec_t exec;  // null until the second call with this key
   bool failed;          // capture or instantiation failed once: always eager
   uint64_t last_use;
+  hipEvent_t done;      // recorded behind every replay: an exec is destroyed only after its last launch has finished
 };
+static void destroy_entry(GraphEntry& g) {
+  if (g.exec) {
+    if (g.done) (void)hipEventSynchronize(g.done);  // the host may be many replays ahead of the GPU
+    (void)hipGraphExecDestroy(g.exec);
+  }
+  if (g.done) (void)hipEventDestroy(g.done);
+  g.exec = nullptr;
+  g.done = nullptr;
+}
 static std::mutex g_gmutex;
 static std::vector<GraphEntry> g_graphs;
 static uint64_t g_gclock = 0;
@@ -104,9 +114,16 @@ static bool graphs_enabled() {
 
 int run_graphed(bool eligible, const GraphKey& key, hipStream_t stream, const std::function<int(hipStream_t)>& fn) {
   if (!eligible || g_timing || !graphs_enabled()) return fn(stream);
-  int device = -1;
+  // A graph belongs to the device its kernels were captured for, and the capture stream is created on the CURRENT device: replay only
+  // when the caller's stream lives on the current device (a caller that passes a stream of another device without making that
+  // device current gets eager launches, which HIP routes by the stream).  The Python wrappers enter torch.cuda.device(dev).
+  int device = -1, stream_device = -1;
   if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 16) return fn(stream);
-  std::string full = key.bytes;  // a graph belongs to the device its kernels were captured for
+  if (stream != nullptr && (hipStreamGetDevice(stream, &stream_device) != hipSuccess || stream_device != device)) {
+    (void)hipGetLastError();
+    return fn(stream);
+  }
+  std::string full = key.bytes;
   full.append(reinterpret_cast<const char*>(&device), sizeof(device));
   std::lock_guard<std::mutex> lock(g_gmutex);
   GraphEntry* e = nullptr;
@@ -117,10 +134,10 @@ int run_graphed(bool eligible, const GraphKey& key, hipStream_t stream, const st
       size_t old = 0;
       for (size_t i = 1; i < g_graphs.size(); ++i)
         if (g_graphs[i].last_use < g_graphs[old].last_use) old = i;
-      if (g_graphs[old].exec) (void)hipGraphExecDestroy(g_graphs[old].exec);
+      destroy_entry(g_graphs[old]);
       g_graphs.erase(g_graphs.begin() + (long)old);
     }
-    g_graphs.push_back(GraphEntry{full, nullptr, false, ++g_gclock});
+    g_graphs.push_back(GraphEntry{full, nullptr, false, ++g_gclock, nullptr});
     return fn(stream);
   }
   e->last_use = ++g_gclock;
@@ -155,9 +172,14 @@ int run_graphed(bool eligible, const GraphKey& key, hipStream_t stream, const st
     }
     (void)hipGraphDestroy(graph);
     e->exec = exec;
+    if (hipEventCreateWithFlags(&e->done, hipEventDisableTiming) != hipSuccess) {
+      e->done = nullptr;
+      (void)hipGetLastError();
+    }
     ++g_captured;
   }
   MFX_CHECK_HIP(hipGraphLaunch(e->exec, stream));
+  if (e->done) (void)hipEventRecord(e->done, stream);
   ++g_replayed;
   return MFX_OK;
 }

@@ -499,13 +499,14 @@ static int64_t carve_ws(const mfx_operator* op, int64_t n, int64_t k, int64_t p,
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 static bool csr_fusable(const mfx_operator* op, const Ctx<T>& c, int transpose) {
-  // MFX_CSR_FUSED: 0 = never, 1 = only few-slice problems (launch-bound regime), 2 (default) = every CSR problem
-  static const int mode = [] { const char* e = getenv("MFX_CSR_FUSED"); return e ? atoi(e) : 2; }();
-  if (mode == 0 || op->kind != MFX_OP_CSR || c.comm || op->nrows != 0) return false;
+  if (op->kind != MFX_OP_CSR || c.comm || op->nrows != 0) return false;
   if (!op->crow || !op->col || !op->val || op->nnz < 1) return false;
-  if (op->nnz > 24 * op->n) return false;  // one thread walks a whole row there: long rows belong to the 8-lanes-per-row kernel
+  // One thread walks a whole row in the fused step, and a workgroup waits for its longest: skewed matrices (one dense row, a
+  // power-law graph) belong to the 8-lanes-per-row kernel.  Decided on the LONGEST row when the caller states it
+  // (mfx_operator.max_row_nnz; CsrOp computes it once), on the mean row length otherwise.
+  if (op->max_row_nnz > 0 ? op->max_row_nnz > 64 : op->nnz > 24 * op->n) return false;
   if (transpose && !(op->t_crow && op->t_col && op->t_perm)) return false;
-  return mode >= 2 || (int64_t)c.nblk * c.p < 256;
+  return true;
 }
 
 template <typename T>

@@ -97,13 +97,6 @@ struct RbfTileH3 {
 };
 
 
-// launcher of the producer / consumer matvec kernel (mfx_rbf_pc.hip); arguments as k_rbf_mfma_apply_h3
-int64_t rbf_pc_smem_bytes(int dpad);
-int rbf_pc_launch(int dpad, int kind, bool vec4, dim3 grid, hipStream_t stream, const float* xs, const float* sq, int64_t n,
-                  const float* outputscale, const float* noise, const float* vscale, const float* x, int64_t ldx, float* y,
-                  int64_t ldy, int64_t p, const void* pkv, const void* pka, float* part, const int* rangeflag, int64_t ldpart,
-                  int64_t row0, int64_t rend);
-
 // launcher of the fat-wave matvec kernel (mfx_rbf_fat.hip): RBF, d <= 8, 33..64-probe chunks; grid = (ceil(rows / 512), chunks, splits)
 int rbf_fat_launch(int dpad, bool vec4, dim3 grid, hipStream_t stream, const float* xs, const float* sq, int64_t n,
                    const float* outputscale, const float* noise, const float* vscale, const float* x, int64_t ldx, float* y,

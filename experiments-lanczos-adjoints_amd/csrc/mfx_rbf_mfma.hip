@@ -318,11 +318,6 @@ struct RbfTileH {
   _Float16 vlo[(kTJ / 32) * 4][ROW];
 };
 
-// schedule of the pipelined kernel's block loop (see do_tile): 1 = exp/split spread over the whole block, 0 = two-phase
-#ifndef MFX_RBF_WIDE
-#define MFX_RBF_WIDE 1
-#endif
-constexpr bool kWideSched = MFX_RBF_WIDE != 0;
 
 // ================================================================================================
 // Pipelined 3 x f16 kernel ("h3"): the production fp32 RBF Gram matvec.
@@ -340,14 +335,13 @@ constexpr bool kWideSched = MFX_RBF_WIDE != 0;
 // ================================================================================================
 // waves per workgroup: the pre-packed variant runs 8 waves (512 rows) on ONE staged tile -- the same two waves per SIMD as two
 // 4-wave workgroups, but half the L2 -> LDS traffic and half the LDS tile copies
-// MI = 4 ("fat waves", pre-packed variant only): FOUR waves of 128 rows -- one wave per SIMD with the whole 512-register file
-template <bool PK, int MI = 2>
+template <bool PK>
 struct H3Waves {
-  static constexpr int value = PK ? (MI == 4 ? 4 : 8) : 4;
+  static constexpr int value = PK ? 8 : 4;
 };
 
-template <int DPAD, int NB, bool VEC4, int KIND, bool DH, bool PK, int MI = 2>
-__global__ __launch_bounds__((64 * H3Waves<PK, MI>::value), PK ? 1 : 2) void k_rbf_mfma_apply_h3(const float* __restrict__ xs, const float* __restrict__ sq,
+template <int DPAD, int NB, bool VEC4, int KIND, bool DH, bool PK>
+__global__ __launch_bounds__(64 * H3Waves<PK>::value, PK ? 1 : 2) void k_rbf_mfma_apply_h3(const float* __restrict__ xs, const float* __restrict__ sq,
                                                               int64_t n, const float* __restrict__ outputscale,
                                                               const float* __restrict__ noise,
                                                               const float* __restrict__ vscale,
@@ -365,8 +359,7 @@ __global__ __launch_bounds__((64 * H3Waves<PK, MI>::value), PK ? 1 : 2) void k_r
   if (rangeflag && (*rangeflag != 0) == DH) return;
   // gridDim.z > 1: column split for small n (too few 256-row blocks to fill 256 CUs): workgroup z sweeps its share of the
   // 64-column tiles and writes a partial result to part[z][probe][row]; k_split_reduce adds them in a fixed order.
-  constexpr int kMI = MI, kTJ = 64;
-  static_assert(MI == 2 || (MI == 4 && PK && KIND == MFX_KERNEL_RBF), "fat waves: pre-packed RBF variant only");
+  constexpr int kMI = 2, kTJ = 64;
   using Tile = RbfTileH3<DPAD, NB, kTJ, !PK>;
   constexpr int KD = Tile::KD, KS = KD / 2, NKD = Tile::NKD;
   constexpr float cfac = KIND == MFX_KERNEL_RBF ? kNegHalfLog2e : (KIND == MFX_KERNEL_MATERN32 ? 3.f : 1.f) * kLog2e * kLog2e;
@@ -374,7 +367,7 @@ __global__ __launch_bounds__((64 * H3Waves<PK, MI>::value), PK ? 1 : 2) void k_r
   Tile* const tile = reinterpret_cast<Tile*>(h3_smem);  // [2]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
-  constexpr int WV = H3Waves<PK, MI>::value;
+  constexpr int WV = H3Waves<PK>::value;
   // master accumulators of the chain folds (PK variant): blocks 0 .. kMI NB - 2 in LDS behind the tiles, the last one in registers
   constexpr int kBlocks = kMI * NB;
   float* const master = reinterpret_cast<float*>(h3_smem + 2 * sizeof(Tile)) + ((size_t)wid * (kBlocks - 1) * 16) * 64 + lane;
@@ -422,13 +415,6 @@ __global__ __launch_bounds__((64 * H3Waves<PK, MI>::value), PK ? 1 : 2) void k_r
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][nb][r] = 0.f;
-  if constexpr (MI == 4) {
-    // an "a"-constrained operand keeps the function from being marked amdgpu-no-agpr: the MFMAs are then selected in their AGPR
-    // form (accumulators live in the accumulation registers) instead of the VGPR form with v_accvgpr spill traffic
-    float agpr_seed = 0.f;
-    asm volatile("; agpr form" : "+a"(agpr_seed));
-    acc[0][0][0] = agpr_seed;
-  }
   if constexpr (PK) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) mreg[r] = 0.f;
@@ -614,31 +600,6 @@ __global__ __launch_bounds__((64 * H3Waves<PK, MI>::value), PK ? 1 : 2) void k_r
     al[s][q] = l[0]; al[s][q + 1] = l[1];
   };
 
-  // Fat waves (MI = 4): ONE wave per SIMD, so nothing but this wave's own instruction-level parallelism covers the latencies of
-  // the chain exp -> cvt (hi) -> fma_mix (lo) -> cvt.  The chain of a pair of entries is cut into four steps that work IN PLACE on
-  // the distance block (step 0: exp2; 1: hi = f16(k); 2: k - hi; 3: lo = f16(.)), and the block loop issues the steps of different
-  // pairs side by side (software pipeline over the pairs, kSplitGap below): no step follows its producer within one MFMA gap.
-  auto split_step = [&](floatx16& w, const int p, const int st, const bool neg, half8 (&ah)[2], half8 (&al)[2]) {
-    const int s = p >> 2, q = (p & 3) * 2, r0 = 8 * s + q;
-    if (st == 0) {
-      w[r0] = __builtin_amdgcn_exp2f(neg ? -w[r0] : w[r0]);
-      w[r0 + 1] = __builtin_amdgcn_exp2f(neg ? -w[r0 + 1] : w[r0 + 1]);
-    } else if (st == 1) {
-      const half2v h = {(_Float16)w[r0], (_Float16)w[r0 + 1]};
-      ah[s][q] = h[0]; ah[s][q + 1] = h[1];
-    } else if (st == 2) {
-      const half2v h = {ah[s][q], ah[s][q + 1]};
-      const unsigned hb = __builtin_bit_cast(unsigned, h);
-      float l0, l1;
-      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hb), "v"(w[r0]));
-      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hb), "v"(w[r0 + 1]));
-      w[r0] = l0; w[r0 + 1] = l1;
-    } else {
-      const half2v l = {(_Float16)w[r0], (_Float16)w[r0 + 1]};
-      al[s][q] = l[0]; al[s][q + 1] = l[1];
-    }
-  };
-
   const int64_t ntile_tot = (n + kTJ - 1) / kTJ;
   const int64_t t_first = ntile_tot * blockIdx.z / gridDim.z, ntile = ntile_tot * (blockIdx.z + 1) / gridDim.z;
   if constexpr (PK) {
@@ -661,7 +622,7 @@ __global__ __launch_bounds__((64 * H3Waves<PK, MI>::value), PK ? 1 : 2) void k_r
     // kernels) the per-entry self-distance fix is compiled in -- two copies of the tile body, chosen wave-uniformly
     auto do_tile = [&](auto diag_tag) {
     constexpr bool kDiag = decltype(diag_tag)::value;
-    if constexpr (DH && kWideSched) {
+    if constexpr (DH) {
       // ---- wide schedule: the exp / split of block b+1 is spread over ALL contraction MFMAs of block b (its distances were
       //      issued during block b-1), so the VALU stream runs beside the matrix pipe for the whole block instead of half of it
       //      (PMC: 29 % of the MFMA-busy cycles co-executed with VALU under the two-phase schedule) ----------------------
@@ -673,25 +634,11 @@ __global__ __launch_bounds__((64 * H3Waves<PK, MI>::value), PK ? 1 : 2) void k_r
 #pragma unroll
         for (int q = 0; q < NKD; ++q) ajs[q] = *reinterpret_cast<const half8*>(&tl.ajh[jbx * 32 + l31][q * 16 + lhi * 8]);
       };
-      // Fat waves (MI = 4): the contraction accumulators live in AGPRs (see the "a" operand above), but a distance block is consumed
-      // by v_exp and must come out in VGPRs with a literal-zero addend (the intrinsic would zero 16 AGPRs and copy 16 back per
-      // block): written as asm.  The compiler does not see an MFMA there, so the MFMA-write -> VALU-read wait states are ours to
-      // keep: the first v_exp that reads the block follows at least two more MFMAs of this wave (>= 64 cycles on its own SIMD).
-      auto dist_step = [&](floatx16& kd, const half8& a, const half8& b, const bool first) {
-        if constexpr (MI == 4) {
-          if (first) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(kd) : "v"(a), "v"(b));
-          else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(kd) : "v"(a), "v"(b));
-        } else {
-          kd = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, kd, 0, 0, 0);
-        }
-      };
       auto dist = [&](floatx16& kd, int mix) {
-        if constexpr (MI != 4) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) kd[r] = 0.f;
-        }
+        for (int r = 0; r < 16; ++r) kd[r] = 0.f;
 #pragma unroll
-        for (int q = 0; q < NKD; ++q) dist_step(kd, ajs[q], bih[mix][q], q == 0);
+        for (int q = 0; q < NKD; ++q) kd = __builtin_amdgcn_mfma_f32_32x32x16_f16(ajs[q], bih[mix][q], kd, 0, 0, 0);
       };
       // B fragments (probe tile) of a block are fetched from LDS one block ahead: the ds_read latency in front of the first MFMA
       // of every block was ~10 % of the tile
@@ -709,23 +656,13 @@ __global__ __launch_bounds__((64 * H3Waves<PK, MI>::value), PK ? 1 : 2) void k_r
       constexpr bool kPrefB = PK && (NB == 1 || DPAD <= 8);  // elsewhere the second fragment set does not fit in 256 VGPRs
       if (kPrefB) load_b(0, 0);
       {
-        static_assert(kMI >= 2, "the first two blocks of a tile are (jb 0, mi 0) and (jb 0, mi 1)");
+        static_assert(kMI == 2, "block order (jb, mi) = (0,0), (0,1), (1,0), (1,1)");
         floatx16 kd;
         load_a(0);
         dist(kd, 0);
         dist(kdn, 1);
-        // (MI = 4: the asm MFMAs hide their result hazard from the compiler.  Tie the first reader of kd behind the LAST of them:
-        // two MFMAs of this wave, i.e. 64 cycles of its own matrix pipe, then lie between the write of kd and that read.)
-        if constexpr (MI == 4) asm volatile("" : "+v"(kd));
-        if constexpr (MI == 4) {  // step by step over all eight pairs: eight independent instructions between producer and consumer
 #pragma unroll
-          for (int st = 0; st < 4; ++st)
-#pragma unroll
-            for (int pr = 0; pr < 8; ++pr) split_step(kd, pr, st, false, ah, al);
-        } else {
-#pragma unroll
-          for (int pr = 0; pr < 8; ++pr) exp_split_pair(kd, pr, kDiag, false, ah, al);
-        }
+        for (int pr = 0; pr < 8; ++pr) exp_split_pair(kd, pr, kDiag, false, ah, al);
       }
 #pragma unroll
       for (int blk = 0; blk < 2 * kMI; ++blk) {
@@ -741,10 +678,8 @@ __global__ __launch_bounds__((64 * H3Waves<PK, MI>::value), PK ? 1 : 2) void k_r
         if (has_next2 && mi2 == 0) load_a(jb2);  // blocks (jb2, 0) and (jb2, 1) are issued from blocks blk and blk + 1
         const bool negn = ((jbn + min_) & 1) != 0;
         floatx16 kdn2;
-        if constexpr (MI != 4) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) kdn2[r] = 0.f;
-        }
+        for (int r = 0; r < 16; ++r) kdn2[r] = 0.f;
         half8 ahn[2], aln[2];
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
@@ -752,24 +687,14 @@ __global__ __launch_bounds__((64 * H3Waves<PK, MI>::value), PK ? 1 : 2) void k_r
           __builtin_amdgcn_sched_barrier(0);
           acc[mi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w == 2 ? al[s] : ah[s], w == 1 ? blb[cur][s][nb] : bhb[cur][s][nb],
                                                                acc[mi][nb], 0, 0, 0);
-          if (has_next2 && m >= MD && m - MD < NKD) dist_step(kdn2, ajs[m - MD], bih[mi2][m - MD], m == MD);
+          if (has_next2 && m >= MD && m - MD < NKD)
+            kdn2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ajs[m - MD], bih[mi2][m - MD], kdn2, 0, 0, 0);
           if (kPrefB && m == 0 && blk == 0 && 2 * kMI > kMI) load_b(1, 1);  // the second column block's fragments, two blocks ahead
           __builtin_amdgcn_sched_barrier(0);
           if (has_next) {
-            if constexpr (MI == 4) {
-              // pair p enters the four-step pipeline behind MFMA kSplitGap[p]; its last step follows MFMA kSplitGap[p] + 3 <= 11
-              static_assert(NM == 12, "fat waves: 64-probe chunks");
-              constexpr int kSplitGap[8] = {0, 1, 2, 3, 5, 6, 7, 8};
 #pragma unroll
-              for (int st = 0; st < 4; ++st)
-#pragma unroll
-                for (int pr = 0; pr < 8; ++pr)
-                  if (kSplitGap[pr] + st == m) split_step(kdn, pr, st, negn, ahn, aln);
-            } else {
-#pragma unroll
-              for (int pr = 0; pr < 8; ++pr)
-                if (pr >= 8 * m / NM && pr < 8 * (m + 1) / NM) exp_split_pair(kdn, pr, kDiag && jbn == min_, negn, ahn, aln);
-            }
+            for (int pr = 0; pr < 8; ++pr)
+              if (pr >= 8 * m / NM && pr < 8 * (m + 1) / NM) exp_split_pair(kdn, pr, kDiag && jbn == min_, negn, ahn, aln);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1015,18 +940,10 @@ __global__ __launch_bounds__(256) void k_pack_tiles(const float* __restrict__ xs
 // ceil(wgs s / 256) rounds of 1/s of the columns each; pick the s (at most 16, at least 8 tiles per split) that minimises
 // rounds / s, plus a small charge per split for the prologue and the partial sums.  (n = 45 730: 90 row blocks -> s = 8, 720
 // workgroups in 3 rounds = 0.375 of an unsplit launch, where "fill one round" (s = 2) gives 0.5.)
-// Which kernel runs a 33..64-vector chunk of an RBF operator with d <= 8 (BASELINE config 4's matvec):
-//   default        the fat-wave kernel (mfx_rbf_fat.hip): one wave per SIMD, 80 % matrix-pipe share, -16 % cycles against h3
-//   MFX_RBF_FAT=0  the same-program kernel k_rbf_mfma_apply_h3 (two waves per SIMD), which also takes every other shape
-//   MFX_RBF_PC=1   the producer / consumer kernel (mfx_rbf_pc.hip): measured SLOWER (51 % matrix-pipe share);
-//                  kept as the recorded experiment, parity-tested, never the default
-static bool rbf_pc() {
-  static const int v = [] {
-    const char* e = getenv("MFX_RBF_PC");
-    return e ? atoi(e) : 0;
-  }();
-  return v != 0;
-}
+// Which kernel runs a 33..64-vector chunk of an RBF operator with d <= 8 (BASELINE config 4's matvec): the fat-wave kernel
+// (mfx_rbf_fat.hip: one wave per SIMD, 82 % matrix-pipe share, -16 % cycles against h3).  MFX_RBF_FAT=0 runs the same-program
+// kernel k_rbf_mfma_apply_h3 (two waves per SIMD) instead -- the one A/B switch kept, because it reproduces the comparison of
+// DESIGN.md §3.2 and the bit-identity test of the two kernels; h3 also takes every other shape.
 static bool rbf_fat() {
   static const int v = [] {
     const char* e = getenv("MFX_RBF_FAT");
@@ -1034,16 +951,14 @@ static bool rbf_fat() {
   }();
   return v != 0;
 }
-// the producer / consumer kernel takes 33..64-probe chunks with d <= 12 (its LDS ring + images do not fit next to a d = 16 column operand)
-static bool rbf_pc_eligible(int64_t p, int dpad) { return p > 32 && dpad <= 12 && rbf_pc(); }
 
 static int rbf_split_count(int64_t nrow, int64_t n, int64_t p, int dpad) {
   static const int forced = [] {
     const char* e = getenv("MFX_RBF_SPLIT");  // A/B: force the split count
     return e ? atoi(e) : 0;
   }();
-  const int64_t wg_rows = rbf_pc_eligible(p, dpad) ? 256 : 512;
-  const int64_t wgs = ((nrow + wg_rows - 1) / wg_rows) * ((p + (p <= 32 ? 32 : 64) - 1) / (p <= 32 ? 32 : 64));
+  (void)dpad;
+  const int64_t wgs = ((nrow + 511) / 512) * ((p + (p <= 32 ? 32 : 64) - 1) / (p <= 32 ? 32 : 64));
   const int64_t ntile = (n + 63) / 64;
   int64_t smax = ntile / 8;
   if (forced > 0) return forced <= 16 && forced <= ntile ? forced : 1;
@@ -1075,26 +990,6 @@ int64_t rbf_pack_ws_bytes(const mfx_operator* op, int64_t p) {
          align_up((int64_t)rbf_split_count(op_nrows(op), op->n, p, dpad) * p * align_up(op_nrows(op), 4) * 4, 256);
 }
 
-// distances of the pipelined kernel on the f16 matrix pipe (3-product split, alternating block sign: default) or on the
-// fp32 MFMA (MFX_RBF_DIST=0, kept for A/B runs).  Measured, C4 shape: 9.84 -> 8.08 ms per launch at 64 probes, 7.0 -> 4.8 ms
-// at <= 8 probes; SLQ value / gradient errors vs fp64 unchanged (tools/run_dist_ablation.sh, profiles/r01f_*).
-static bool rbf_dist_f16() {
-  static const int v = [] {
-    const char* e = getenv("MFX_RBF_DIST");
-    return e ? atoi(e) : 1;
-  }();
-  return v != 0;
-}
-
-// MFX_RBF_PACK=0 keeps the in-kernel split of the probe tiles (A/B runs)
-static bool rbf_prepack() {
-  static const int v = [] {
-    const char* e = getenv("MFX_RBF_PACK");
-    return e ? atoi(e) : 1;
-  }();
-  return v != 0;
-}
-
 template <int DPAD, int NB, int KIND>
 static int launch_apply_h3k(const mfx_operator* op, const float* xs, const float* sq, const float* x, int64_t ldx,
                             float* y, int64_t ldy, int64_t p, float* vscale, void* pk, hipStream_t stream) {
@@ -1106,7 +1001,7 @@ static int launch_apply_h3k(const mfx_operator* op, const float* xs, const float
   const dim3 grid((unsigned)((nrow + 255) / 256), chunks);  // 4-wave workgroups (256 rows); the pre-packed variant uses grid_pk
   const bool vec4 = (n % 4 == 0) && (nrow % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) &&
                     (reinterpret_cast<uintptr_t>(y) % 16 == 0);
-  const bool pack = rbf_dist_f16() && rbf_prepack() && pk != nullptr;
+  const bool pack = pk != nullptr;  // the pre-packed tile images need the caller's pack workspace (mfx_workspace_bytes sizes it)
   uintx4* pkv = nullptr;
   uintx4* pka = nullptr;
   const int64_t ntile = (n + 63) / 64;
@@ -1125,42 +1020,33 @@ static int launch_apply_h3k(const mfx_operator* op, const float* xs, const float
     MFX_CHECK_LAUNCH();
   }
   // LDS: the two tile buffers + (pre-packed variant) the chain masters of 8 waves x (2 NB - 1) blocks x 16 registers x 64 lanes
-#define MFX_H3_LAUNCH_MI(V4, DHV, PKV, FLAG, MIV)                                                                   \
+#define MFX_H3_LAUNCH(V4, DHV, PKV, FLAG)                                                                            \
   {                                                                                                                  \
-    constexpr int kWv = H3Waves<PKV, MIV>::value;                                                                    \
-    constexpr size_t kSm = 2 * sizeof(RbfTileH3<DPAD, NB, 64, !(PKV)>) + ((PKV) ? (size_t)kWv * ((MIV) * NB - 1) * 16 * 64 * 4 : 0); \
-    static_assert(kSm <= 160 * 1024, "LDS budget of the pipelined matvec");                                          \
+    constexpr size_t kSm = 2 * sizeof(RbfTileH3<DPAD, NB, 64, !(PKV)>) + ((PKV) ? (size_t)8 * (2 * NB - 1) * 16 * 64 * 4 : 0); \
     if (kSm > 64 * 1024)                                                                                             \
-      MFX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rbf_mfma_apply_h3<DPAD, NB, V4, KIND, DHV, PKV, MIV>), \
+      MFX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rbf_mfma_apply_h3<DPAD, NB, V4, KIND, DHV, PKV>), \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSm));                       \
-    k_rbf_mfma_apply_h3<DPAD, NB, V4, KIND, DHV, PKV, MIV><<<(PKV) ? grid_pk : grid3, 64 * kWv, kSm, stream>>>(        \
+    k_rbf_mfma_apply_h3<DPAD, NB, V4, KIND, DHV, PKV><<<(PKV) ? grid_pk : grid3, 64 * H3Waves<PKV>::value, kSm, stream>>>( \
         xs, sq, n, (const float*)op->outputscale, (const float*)op->noise, vscale, x, ldx, y, ldy, p, pkv, pka, part, FLAG, ldpart, row0, rend); \
   }
-#define MFX_H3_LAUNCH(V4, DHV, PKV, FLAG) MFX_H3_LAUNCH_MI(V4, DHV, PKV, FLAG, 2)
   if (pack) {
-    bool pc_done = false;
-    if (NB == 2 && rbf_pc_eligible(p, DPAD)) {  // producer / consumer kernel (mfx_rbf_pc.hip): 256-row workgroups
-      const dim3 grid_pc((unsigned)((nrow + 255) / 256), grid.y, (unsigned)nsplit);
-      MFX_TRY(rbf_pc_launch(DPAD, KIND, vec4, grid_pc, stream, xs, sq, n, (const float*)op->outputscale, (const float*)op->noise,
-                            vscale, x, ldx, y, ldy, p, pkv, pka, part, rangeflag, ldpart, row0, rend));
-      pc_done = true;
-    }
+    bool done = false;
     if constexpr (KIND == MFX_KERNEL_RBF && NB == 2 && DPAD <= 8) {
-      if (!pc_done && rbf_fat()) {  // fat waves (mfx_rbf_fat.hip): four waves of 128 rows, one per SIMD
+      if (rbf_fat()) {  // fat waves (mfx_rbf_fat.hip): four waves of 128 rows, one per SIMD
         MFX_TRY(rbf_fat_launch(DPAD, vec4, grid_pk, stream, xs, sq, n, (const float*)op->outputscale, (const float*)op->noise, vscale,
                                x, ldx, y, ldy, p, pkv, pka, part, rangeflag, ldpart, row0, rend));
-        pc_done = true;
+        done = true;
       }
     }
-    if (!pc_done) {
+    if (!done) {
       if (vec4) MFX_H3_LAUNCH(true, true, true, rangeflag) else MFX_H3_LAUNCH(false, true, true, rangeflag)
     }
-    if (vec4) MFX_H3_LAUNCH(true, false, false, rangeflag) else MFX_H3_LAUNCH(false, false, false, rangeflag)  // runs only if flagged
-  } else {  // MFX_RBF_DIST=0 / MFX_RBF_PACK=0 (or no pack workspace): fp32-MFMA distances, in-kernel split of the probe tiles
+    // f16 range guard: this launch returns at once unless k_pack_tiles raised the flag, in which case the launches above did
+    if (vec4) MFX_H3_LAUNCH(true, false, false, rangeflag) else MFX_H3_LAUNCH(false, false, false, rangeflag)
+  } else {  // no pack workspace: fp32-MFMA distances, in-kernel split of the probe tiles
     if (vec4) MFX_H3_LAUNCH(true, false, false, nullptr) else MFX_H3_LAUNCH(false, false, false, nullptr)
   }
 #undef MFX_H3_LAUNCH
-#undef MFX_H3_LAUNCH_MI
   MFX_CHECK_LAUNCH();
   if (nsplit > 1) {
     k_split_reduce<<<dim3((unsigned)((nrow + 255) / 256), (unsigned)p), 256, 0, stream>>>(part, ldpart, nsplit, p, nrow, ldy,
@@ -1248,7 +1134,6 @@ __global__ void k_global_scale(const float* __restrict__ amax, int64_t rows, flo
 // at random it enters S_ij as -sigma_i tau_j beta ulp -- sign-random over (i, j), uncorrelated with dK_ij/dtheta -- and
 // sums like noise (~ |dK|_F) instead of coherently (~ sum_ij dK_ij, n times larger).  Measured: profiles/r02a_*.
 __host__ __device__ __forceinline__ bool grad_col_sign(int64_t i, uint32_t salt) {
-  if (salt == 0u) return false;  // MFX_RBF_GRAD_SIGNS=0 (A/B runs): no column signs
   uint32_t h = (uint32_t)i * 0x9E3779B1u + salt;
   h ^= h >> 15;
   h *= 0x85EBCA77u;
@@ -1293,9 +1178,6 @@ __global__ __launch_bounds__(256) void k_pack_f16(const float* __restrict__ x, i
 // SIMD as two 128 x 128 workgroups, but (256 + 128) instead of 2 x (128 + 128) operand columns through L2 -> LDS per stage
 constexpr int kHM = 256;
 constexpr int kHLd = kHM + 4;
-#ifndef MFX_GRAD_PINGPONG
-#define MFX_GRAD_PINGPONG 1  // 0: one barrier per stage, all eight waves in lockstep (A/B builds)
-#endif
 
 // NBW = 32-column blocks per wave: the workgroup tile is 256 rows x (2 NBW 32) columns, 8 waves as 4 x 2 of 64 x (NBW 32).
 //   NBW = 2: 256 x 128 (round 1);  NBW = 4: 256 x 256 -- (256 + 256) instead of 2 x (256 + 128) operand columns through L2 -> LDS
@@ -1422,7 +1304,6 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
       ol += 3 * stage_bytes_l;
       orr += 3 * stage_bytes_r;
     }
-#if MFX_GRAD_PINGPONG
     // PING-PONG: waves w and w + 4 share a SIMD.  With one barrier per stage all eight waves read their fragments from LDS
     // together (96 KB per stage: ~770 cycles with the matrix pipe idle) and then queue their MFMAs together.  Here the two
     // halves of the workgroup run half a stage apart: two barriers per stage -- B1 before the fragment reads, B2 before the
@@ -1488,45 +1369,6 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
       __builtin_amdgcn_sched_barrier(0);
     }
     if (wid < 4) __builtin_amdgcn_s_barrier();  // the lower half catches up: both halves have taken 2 nstage + 1 barriers
-#else
-    for (int64_t st = 0; st < nstage; ++st) {
-      const int slot = (int)(st & 3);
-      // kGlds glds per stage and thread; stages st + 1, st + 2 may stay in flight
-      const int64_t later = nstage - 1 - st;
-      if (later >= 2) {
-        if constexpr (kGlds == 4) __builtin_amdgcn_s_waitcnt(0x0F78); else __builtin_amdgcn_s_waitcnt(0x0F76);  // vmcnt(8 | 6)
-      } else if (later == 1) {
-        if constexpr (kGlds == 4) __builtin_amdgcn_s_waitcnt(0x0F74); else __builtin_amdgcn_s_waitcnt(0x0F73);  // vmcnt(4 | 3)
-      } else {
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-      }
-      __builtin_amdgcn_s_barrier();
-      if (st + 3 < nstage) issue_stage(ol, orr, (int)((st + 3) & 3));
-      ol += stage_bytes_l;
-      orr += stage_bytes_r;
-      {
-        half8 ah[2], al[2], bh[NBW], bl[NBW];
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-          ah[a] = *reinterpret_cast<const half8*>(&sm.u.st.a_hi[slot][lhi][wm * 64 + a * 32 + l31][0]);
-          al[a] = *reinterpret_cast<const half8*>(&sm.u.st.a_lo[slot][lhi][wm * 64 + a * 32 + l31][0]);
-        }
-#pragma unroll
-        for (int b = 0; b < NBW; ++b) {
-          bh[b] = *reinterpret_cast<const half8*>(&sm.u.st.b_hi[slot][lhi][wn * (NBW * 32) + b * 32 + l31][0]);
-          bl[b] = *reinterpret_cast<const half8*>(&sm.u.st.b_lo[slot][lhi][wn * (NBW * 32) + b * 32 + l31][0]);
-        }
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int b = 0; b < NBW; ++b) {
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
-          }
-      }
-    }
-#endif
     if constexpr (REGEPI) {
       // Everything below that depends only on the workgroup's rows is invariant over the tile loop; hoisted out of it, it
       // would sit in registers through the K-loop, which has none to spare (measured: 380 B of spills, one reload per stage,
@@ -1728,15 +1570,6 @@ int64_t rbf_grad_h_ws_bytes(int64_t n, int64_t batch) {
   return 4 * bpad * npad * (int64_t)sizeof(_Float16) + 2 * bpad * (int64_t)sizeof(float) + 1024;
 }
 
-// column-tile width of the split gradient GEMM: 256 (NBW = 4) by default, MFX_GRAD_TILE=128 for the round-1 tile (A/B)
-static bool grad_wide_tile() {
-  static const int v = [] {
-    const char* e = getenv("MFX_GRAD_TILE");
-    return e ? atoi(e) : 256;
-  }();
-  return v != 128;
-}
-
 template <int DPAD, int NBW>
 static int launch_grad_h_t(const mfx_operator* op, const float* xs, const float* sq, int64_t n, int64_t npad_l, int64_t npad,
                            const _Float16* Lh, const _Float16* Ll, const _Float16* Rh, const _Float16* Rl, int64_t bpad,
@@ -1746,11 +1579,10 @@ static int launch_grad_h_t(const mfx_operator* op, const float* xs, const float*
   const int64_t nti = (nrow + kHM - 1) / kHM, ntj = (n + TN - 1) / TN;
   const int tiles_per_block = (int)((ntj + kGSplit * kGSub - 1) / (kGSplit * kGSub));
   const dim3 grid(kGSplit, (unsigned)(nti * kGSub));
-  // RBF kernel, one lengthscale, d <= 8: the register epilogue (MFX_GRAD_REGEPI=0: the LDS epilogue, A/B)
-  static const bool regepi_on = [] { const char* e = getenv("MFX_GRAD_REGEPI"); return e ? atoi(e) != 0 : true; }();
+  // RBF kernel, one lengthscale, d <= 8: the register epilogue; Matern / ARD / d > 8: the LDS epilogue
   bool launched = false;
   if constexpr (DPAD <= 8) {
-    if (!op->ard && op->kernel_fn == MFX_KERNEL_RBF && regepi_on) {
+    if (!op->ard && op->kernel_fn == MFX_KERNEL_RBF) {
       const size_t sh = sizeof(GradSmemH<DPAD, NBW, true>);
       MFX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rbf_mfma_grad_h<DPAD, NBW, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
@@ -1792,15 +1624,14 @@ static int launch_grad_h(const mfx_operator* op, const float* xs, const float* s
   k_global_scale<<<1, 256, 0, stream>>>(amaxR, batch, scl + 2);
   const dim3 pgrid((unsigned)((npad + 255) / 256), (unsigned)(bpad / 8));
   const dim3 pgrid_l((unsigned)((npad_l + 255) / 256), (unsigned)(bpad / 8));
-  static const bool signs = [] { const char* e = getenv("MFX_RBF_GRAD_SIGNS"); return e ? atoi(e) != 0 : true; }();
-  const uint32_t salt_l = signs ? kSaltL : 0u, salt_r = signs ? kSaltR : 0u;
+  const uint32_t salt_l = kSaltL, salt_r = kSaltR;
   k_pack_f16<<<pgrid_l, 256, 0, stream>>>(L, ldl, batch, nrow, npad_l, scl, salt_l, inner, Lh, Ll);
   k_pack_f16<<<pgrid, 256, 0, stream>>>(R, ldr, batch, n, npad, scl + 2, salt_r, inner, Rh, Rl);
   MFX_CHECK_LAUNCH();
-  if constexpr (DPAD <= 8) {  // (DPAD = 12, 16: the epilogue registers on top of 128 accumulators spill)
-    if (grad_wide_tile())
-      return launch_grad_h_t<DPAD, 4>(op, xs, sq, n, npad_l, npad, Lh, Ll, Rh, Rl, bpad, salt_l, salt_r, partial, nblocks_out, stream);
-  }
+  // 256 x 256 workgroup tile (NBW = 4) for d <= 8; d = 9..16 keeps the 256 x 128 tile (the epilogue registers on top of 128
+  // accumulators spill there)
+  if constexpr (DPAD <= 8)
+    return launch_grad_h_t<DPAD, 4>(op, xs, sq, n, npad_l, npad, Lh, Ll, Rh, Rl, bpad, salt_l, salt_r, partial, nblocks_out, stream);
   return launch_grad_h_t<DPAD, 2>(op, xs, sq, n, npad_l, npad, Lh, Ll, Rh, Rl, bpad, salt_l, salt_r, partial, nblocks_out, stream);
 }
 
@@ -1819,12 +1650,8 @@ int rbf_mfma_grad_h(const mfx_operator* op, const float* xs, const float* sq, in
   }
 }
 
-// 0: exact fp32 MFMA, 1: 3 x f16 matvec (pipelined kernel h3), 2: also the gradient GEMM split.
-// MFX_RBF_MODE in the environment overrides the descriptor (A/B experiments: -1 = un-pipelined split kernel).
-int rbf_mode(const mfx_operator* op) {
-  static const int env = [] { const char* e = getenv("MFX_RBF_MODE"); return e ? atoi(e) : -100; }();
-  return env != -100 ? env : op->rbf_mode;
-}
+// 0: exact fp32 MFMA, 1: 3 x f16 matvec (fat-wave / pipelined kernels), 2: also the gradient GEMM split
+int rbf_mode(const mfx_operator* op) { return op->rbf_mode; }
 
 bool rbf_mfma_supported(const mfx_operator* op, int64_t p) {
   // from 4 probes on, padding the probe dimension to 32 already beats the VALU kernel (C2-like: 12 ms -> ~1 ms)
@@ -1854,12 +1681,9 @@ static int launch_apply_mi(const mfx_operator* op, const float* xs, const float*
 template <int DPAD, int NB>
 static int launch_apply(const mfx_operator* op, const float* xs, const float* sq, const float* x, int64_t ldx,
                         float* y, int64_t ldy, int64_t p, hipStream_t stream) {
-  static const int mi_env = [] { const char* e = getenv("MFX_RBF_MI"); return e ? atoi(e) : 0; }();
   // 64 rows per wave (2 workgroups per CU at n = 131072) unless the problem is too small to fill the chip
   const bool small = (op_nrows(op) + 255) / 256 < 512;
-  static const int tj_env = [] { const char* e = getenv("MFX_RBF_TJ"); return e ? atoi(e) : 0; }();
-  if (mi_env == 1 || (mi_env == 0 && small)) return launch_apply_mi<DPAD, NB, 1, 64>(op, xs, sq, x, ldx, y, ldy, p, stream);
-  if (tj_env == 128) return launch_apply_mi<DPAD, NB, 2, 128>(op, xs, sq, x, ldx, y, ldy, p, stream);
+  if (small) return launch_apply_mi<DPAD, NB, 1, 64>(op, xs, sq, x, ldx, y, ldy, p, stream);
   return launch_apply_mi<DPAD, NB, 2, 64>(op, xs, sq, x, ldx, y, ldy, p, stream);
 }
 

@@ -89,17 +89,9 @@ constexpr int kRedG = 8;  // lanes per coefficient in the multi-coefficient prol
 // Accumulator type of the Gram-Schmidt dot products and norms inside a slice (products, per-thread sums, cross-lane tree): fp64
 // also for fp32 vectors.  The kernels are HBM-bound (C4: +1.3 ms of 48 ms per step), and at the C4 size the worst gradient
 // component against fp64 over four probe sets drops from 3.8e-5 ... 1.25e-4 to 1.2e-5 ... 6.0e-5 (profiles/r02a_accuracy/
-// table_other_probe_sets.log); what remains is the rounding of the fp32-stored vectors themselves.  -DMFX_DOTS_F64=0: fp32 (A/B).
-#ifndef MFX_DOTS_F64
-#define MFX_DOTS_F64 1
-#endif
-#if MFX_DOTS_F64
+// table_other_probe_sets.log); what remains is the rounding of the fp32-stored vectors themselves.
 template <typename T>
 using DotAcc = double;
-#else
-template <typename T>
-using DotAcc = T;
-#endif
 
 // Rows j0 <= j < j1 of a (rows, n) panel, this thread's elements of the slice, in order, JT rows at a time:
 // f(j, rows[JT][EPT], nvalid) --
@@ -472,10 +464,9 @@ struct Ctx {
   // Only drivers whose every kernel goes through MFX_VEC_EPT_SWITCH may call this (the partial layout changes with nblk).
   // First measured WITHOUT the other changes of DESIGN.md section 3.1 (profiles/r02g_*): no net gain -- every consumer re-reduced 4x more
   // partials in a serial prologue.  With the pipelined partial sums, the double-buffered sweeps and the DPP reductions it pays
-  // (config 3: forward + adjoint 8.2 -> 3.6 ms altogether, profiles/r02k_*).  MFX_FINE_SLICES=0 switches it off.
+  // (config 3: forward + adjoint 8.2 -> 3.6 ms altogether, profiles/r02k_*).
   void fine() {
-    static const bool on = [] { const char* e = getenv("MFX_FINE_SLICES"); return !e || atoi(e) != 0; }();
-    if (!on || vec <= 1 || wg != kBlock || (int64_t)nblk * p >= 128) return;
+    if (vec <= 1 || wg != kBlock || (int64_t)nblk * p >= 128) return;
     ept = VecWidth<T>::value;
     nblk = (int)((n + (int64_t)wg * ept - 1) / ((int64_t)wg * ept));
     if (!comm) nblk_in = nblk;

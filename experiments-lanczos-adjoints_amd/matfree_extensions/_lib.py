@@ -52,6 +52,7 @@ class Operator(C.Structure):
         ("row", C.c_void_p),
         ("val", C.c_void_p),
         ("nnz", C.c_int64),
+        ("max_row_nnz", C.c_int64),
         ("t_crow", C.c_void_p),
         ("t_col", C.c_void_p),
         ("t_perm", C.c_void_p),
@@ -244,15 +245,22 @@ def _take(need: int, device) -> torch.Tensor:
 
 class busy:
     """``with _lib.busy(ws): lib.mfx_...(ws)`` -- marks the buffer as in use for the duration of a call that may call back
-    into Python (callback operators, row-sharded collectives)."""
+    into Python (callback operators, row-sharded collectives), AND makes the buffer's device the current one for the call: libmfx
+    creates its graph-capture stream on the current device and replays a captured driver call only on a stream of that device
+    (a single process with tensors on cuda:1 while cuda:0 is current would otherwise never get its launch-bound calls replayed)."""
 
     def __init__(self, buf):
         self.key = id(buf)
+        self.guard = torch.cuda.device(buf.device) if buf.is_cuda else None
 
     def __enter__(self):
         _ws_busy.add(self.key)
+        if self.guard is not None:
+            self.guard.__enter__()
 
     def __exit__(self, *exc):
+        if self.guard is not None:
+            self.guard.__exit__(*exc)
         _ws_busy.discard(self.key)
         return False
 

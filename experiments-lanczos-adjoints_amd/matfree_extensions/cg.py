@@ -25,7 +25,7 @@ import torch
 
 from . import _lib
 from .low_rank import BoundPreconditioner
-from .operators import CallbackOp, _PtrRegistry, as_operator
+from .operators import CallbackOp, RowShardedOp, _PtrRegistry, as_operator
 
 
 def cg_fixed_step(*args, **kwargs):
@@ -89,6 +89,8 @@ def pcg_adaptive(*, atol: float, rtol, maxiter: int, miniter: int = 0):
 
 def _solve(A, b, P, cfg):
     op, bound = as_operator(A)
+    if isinstance(op, RowShardedOp):
+        raise NotImplementedError("PCG is not row-sharded in the MI355X build: pass the operator itself (all rows on one GPU)")
     params = tuple(bound) if bound is not None else ()
     if P is not None and not isinstance(P, BoundPreconditioner):
         raise TypeError("P must be None or low_rank.Preconditioner.bind(s): the PCG loop runs inside libmfx and "

@@ -18,6 +18,7 @@ different probes.
 
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 
 import torch
@@ -190,6 +191,13 @@ class RowComm:
         regs = [(ws.data_ptr(), ws.numel(), ws)] + [(t.data_ptr(), t.numel() * t.element_size(), t.view(-1).view(torch.uint8))
                                                    for t in tensors if t is not None]
 
+        def on(stream):
+            """the collectives are enqueued on the stream libmfx hands over (it is torch's current stream unless the caller passed
+            another one to the driver)"""
+            if ws.is_cuda and stream and stream != torch.cuda.current_stream(ws.device).cuda_stream:
+                return torch.cuda.stream(torch.cuda.ExternalStream(stream, device=ws.device))
+            return contextlib.nullcontext()
+
         def strided(ptr, ld, p, ncols, dtype_code):
             dt = torch.float32 if dtype_code == _lib.MFX_F32 else torch.float64
             es = 4 if dtype_code == _lib.MFX_F32 else 8
@@ -198,10 +206,11 @@ class RowComm:
                     return flat[ptr - b0 :].view(dt).as_strided((p, ncols), (ld, 1))
             raise RuntimeError("libmfx exchange callback received an unknown pointer")
 
-        def exchange(_ctx, local, ldlocal, full, ldfull, p, dtype_code, transpose, _stream):
+        def exchange(_ctx, local, ldlocal, full, ldfull, p, dtype_code, transpose, stream):
             try:
-                self._exchange(strided(local, ldlocal, p, self.nrows, dtype_code), strided(full, ldfull, p, self.n, dtype_code),
-                               plans[1 if transpose else 0])
+                with on(stream):
+                    self._exchange(strided(local, ldlocal, p, self.nrows, dtype_code), strided(full, ldfull, p, self.n, dtype_code),
+                                   plans[1 if transpose else 0])
                 return 0
             except Exception as exc:
                 failure.append(exc)
@@ -215,22 +224,24 @@ class RowComm:
                 raise RuntimeError("libmfx comm callback received a pointer outside the workspace")
             return ws[off : off + count * es].view(dt)
 
-        def allreduce(_ctx, buf, count, dtype_code, _stream):
+        def allreduce(_ctx, buf, count, dtype_code, stream):
             try:
                 if collective:
-                    dist.all_reduce(view(buf, count, dtype_code), op=dist.ReduceOp.SUM, group=group)
+                    with on(stream):
+                        dist.all_reduce(view(buf, count, dtype_code), op=dist.ReduceOp.SUM, group=group)
                 return 0
             except Exception as exc:  # never let an exception cross the C boundary
                 failure.append(exc)
                 return 1
 
-        def allgather(_ctx, inp, out, count, dtype_code, _stream):
+        def allgather(_ctx, inp, out, count, dtype_code, stream):
             try:
                 tin, tout = view(inp, count, dtype_code), view(out, count * world, dtype_code)
-                if collective:
-                    dist.all_gather_into_tensor(tout, tin, group=group)
-                else:
-                    tout.copy_(tin)
+                with on(stream):
+                    if collective:
+                        dist.all_gather_into_tensor(tout, tin, group=group)
+                    else:
+                        tout.copy_(tin)
                 return 0
             except Exception as exc:
                 failure.append(exc)

@@ -65,6 +65,9 @@ def _tridiag_reortho_full(matvec, krylov_depth, /, *, custom_vjp):
 
 def _tridiag_reortho_none(matvec, krylov_depth, /, *, custom_vjp):
     op, bound = as_operator(matvec)
+    if isinstance(op, RowShardedOp):  # raised at construction: before any rank has entered a collective
+        raise NotImplementedError("the three-term recurrence (reortho='none') is not row-sharded in the MI355X build; row-sharded "
+                                  "operators take tridiag(reortho='full') / arnoldi.hessenberg")
     k = int(krylov_depth)
 
     def estimate(vec, *params):
@@ -269,10 +272,11 @@ def integrand_spd(matfun, krylov_depth, matvec, /, *, reortho: str = "full",
         v0_flat, unflatten = _flatten(v0)
         batched = v0_flat.dim() == 2
         V = v0_flat if batched else v0_flat[None]
-        scale = _vec_norm(V, matvec)
-        V = V / scale[:, None]
+        # built first: it refuses an operator it cannot take before the norm below enters a collective on a row-sharded one
         algorithm = tridiag(_flat_matvec(matvec, unflatten), krylov_depth,
                             custom_vjp=use_adjoints_for_tridiag, reortho=reortho)
+        scale = _vec_norm(V, matvec)
+        V = V / scale[:, None]
         (_basis, (diag, off_diag)), _remainder = algorithm(V, *parameters)
         value, _evals, _evecs = _QuadformFn.apply(matfun, diag, off_diag)
         out = scale**2 * value

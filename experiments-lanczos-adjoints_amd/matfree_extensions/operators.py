@@ -206,6 +206,8 @@ class CsrOp(NativeOp):
         self.t_col = self.row[perm].contiguous()
         tcounts = torch.bincount(self.col.to(torch.int64), minlength=self.n)
         self.t_crow = torch.cat([torch.zeros(1, dtype=torch.int64, device=device), torch.cumsum(tcounts, 0)]).to(torch.int32)
+        # longest row of A and of A^T (one host read at construction): decides fused-step vs 8-lanes-per-row kernels in libmfx
+        self.max_row_nnz = int(max(int(counts.max()) if self.nnz else 0, int(tcounts.max()) if self.nnz else 0))
 
     @classmethod
     def from_coo(cls, row, col, vals, n, device):
@@ -229,7 +231,7 @@ class CsrOp(NativeOp):
         if vals.numel() != self.nnz:
             raise ValueError(f"CsrOp expects {self.nnz} values, got {vals.numel()}")
         desc.crow, desc.col, desc.row = self.crow.data_ptr(), self.col.data_ptr(), self.row.data_ptr()
-        desc.val, desc.nnz = vals.data_ptr(), self.nnz
+        desc.val, desc.nnz, desc.max_row_nnz = vals.data_ptr(), self.nnz, self.max_row_nnz
         desc.t_crow, desc.t_col, desc.t_perm = self.t_crow.data_ptr(), self.t_col.data_ptr(), self.t_perm.data_ptr()
 
     def new_grads(self, vals):

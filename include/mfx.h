@@ -92,6 +92,7 @@ typedef struct mfx_operator {
   const int32_t* row;
   const void* val;
   int64_t nnz;
+  int64_t max_row_nnz; /* longest row of A (of A and A^T when the transpose structure is present); 0 = unknown */
   const int32_t* t_crow;
   const int32_t* t_col;
   const int32_t* t_perm;

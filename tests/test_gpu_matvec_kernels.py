@@ -1,13 +1,12 @@
 """The matrix-core Gram matvec kernels for 33..64-vector chunks against the fp64 NumPy oracle: the fat-wave kernel
-(`k_rbf_fat_apply`, csrc/mfx_rbf_fat.hip: the default for RBF with d <= 8 -- BASELINE config 4's matvec), the producer / consumer
-kernel (`k_rbf_pc_apply`, csrc/mfx_rbf_pc.hip, MFX_RBF_PC=1: the recorded experiment) and the same-program kernel
-`k_rbf_mfma_apply_h3` (everything else, and MFX_RBF_FAT=0).
+(`k_rbf_fat_apply`, csrc/mfx_rbf_fat.hip: the default for RBF with d <= 8 -- BASELINE config 4's matvec) and the same-program
+kernel `k_rbf_mfma_apply_h3` (every other shape, and MFX_RBF_FAT=0).
 
 What is specific to these kernels and therefore tested here: two probe chunks with a ragged second one, ragged n (last tile and
 last row block), row blocks that start inside a workgroup, column splits (small n) and the unsplit sweep with chain folds (more
 than 128 tiles per sweep), every block position of a tile (the fat kernel's distance MFMAs are asm the compiler cannot check), the
-Matern diagonal fix, and agreement of the three kernels with each other.  The switches are read once per process, so the
-non-default kernels run in child processes.  Reference kernel: util/gp_util.py:69-184, Gram matvec :525-549.
+Matern diagonal fix, and BIT-IDENTITY of the two kernels (the fat kernel keeps the order of every sum).  The switch is read once
+per process, so the non-default kernel runs in child processes.  Reference kernel: util/gp_util.py:69-184, Gram matvec :525-549.
 """
 
 import ctypes as C
@@ -88,7 +87,7 @@ import sys, numpy as np, torch
 sys.path.insert(0, {tests!r})
 sys.path.insert(0, {root!r})
 sys.path.insert(0, {pkg!r})
-import test_gpu_pc_matvec as t
+import test_gpu_matvec_kernels as t
 n, d, p = 20000, 8, 64      # 313 tiles in ONE sweep: two chain folds
 for kernel in ("rbf", "matern32"):
     o, op, raw, params, V = t._setup(n, d, p, kernel, True, seed=11)
@@ -114,28 +113,21 @@ def _run_child(tmp_path, tag, **env_over):
     return out
 
 
-def test_unsplit_sweep_with_chain_folds_three_kernels(tmp_path):
-    fat = _run_child(tmp_path, "fat", MFX_RBF_SPLIT="1", MFX_RBF_PC="0", MFX_RBF_FAT="1")
-    pc = _run_child(tmp_path, "pc", MFX_RBF_SPLIT="1", MFX_RBF_PC="1")
-    h3 = _run_child(tmp_path, "h3", MFX_RBF_SPLIT="1", MFX_RBF_PC="0", MFX_RBF_FAT="0")
+def test_unsplit_sweep_with_chain_folds_and_bit_identity_of_the_two_kernels(tmp_path):
+    fat = _run_child(tmp_path, "fat", MFX_RBF_SPLIT="1", MFX_RBF_FAT="1")
+    h3 = _run_child(tmp_path, "h3", MFX_RBF_SPLIT="1", MFX_RBF_FAT="0")
     for kernel in ("rbf", "matern32"):
-        yb = np.load(h3 + "_" + kernel + ".npy")
-        ya = np.load(pc + "_" + kernel + ".npy")
-        rel = (np.abs(ya - yb).max(axis=1) / np.abs(yb).max(axis=1)).max()
-        assert rel < 2e-5, (kernel, rel)  # same arithmetic, different summation order inside a 64-column tile
         # the fat-wave kernel keeps the order of every sum of the same-program kernel (blocks, k-steps, products, chain folds):
         # bit-identical, so the accuracy tables of profiles/r02a_accuracy carry over (Matern: the child runs h3 both times)
-        assert np.array_equal(np.load(fat + "_" + kernel + ".npy"), yb), kernel
+        assert np.array_equal(np.load(fat + "_" + kernel + ".npy"), np.load(h3 + "_" + kernel + ".npy")), kernel
 
 
-def test_every_parity_case_on_the_non_default_kernels():
-    """The oracle and row-block cases above, re-run with the producer / consumer kernel and with the same-program kernel."""
-    for env_over in (dict(MFX_RBF_PC="1"), dict(MFX_RBF_PC="0", MFX_RBF_FAT="0")):
-        env = dict(os.environ)
-        env.update(env_over)
-        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", "oracle or row_blocks or positions",
-                            "-p", "no:cacheprovider"], cwd=os.path.dirname(HERE), env=env, capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0 and " passed" in r.stdout, (env_over, r.stdout[-2000:] + r.stderr[-1000:])
+def test_every_parity_case_on_the_same_program_kernel():
+    """The oracle, row-block and block-position cases of this file, re-run with MFX_RBF_FAT=0 (k_rbf_mfma_apply_h3 for every shape)."""
+    env = dict(os.environ, MFX_RBF_FAT="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", "oracle or row_blocks or position",
+                        "-p", "no:cacheprovider"], cwd=os.path.dirname(HERE), env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]
 
 
 def test_every_block_position_of_a_tile():

@@ -1,11 +1,20 @@
-// libmfx: producer / consumer form of the matrix-core Gram matvec (3 x f16 split), gfx950.
+// EXPERIMENT, not part of libmfx: producer / consumer form of the matrix-core Gram matvec (3 x f16 split), gfx950.
 //   W[i][b] = s * sum_j K(x_i, x_j) V[j][b] + noise V[i][b]   (util/gp_util.py:160-176,225-226,536-541 of the reference)
+// Built, parity-tested through libmfx (round 3, commits c85ebd9 .. ) and measured SLOWER than the kernel it was meant to replace
+// (7.05 vs 5.99 ms per launch at the C4 shape; 51 % vs 69 % matrix-pipe share): see README.md next to this file and DESIGN.md §3.2.
+// What replaced the idea is csrc/mfx_rbf_fat.hip.  The file is kept so that the measurement can be repeated (build.sh, pc_model.hip).
 #include <type_traits>
 
 #include "mfx_internal.h"
 #include "mfx_rbf_common.h"
 
 namespace mfx {
+
+int64_t rbf_pc_smem_bytes(int dpad);
+int rbf_pc_launch(int dpad, int kind, bool vec4, dim3 grid, hipStream_t stream, const float* xs, const float* sq, int64_t n,
+                  const float* outputscale, const float* noise, const float* vscale, const float* x, int64_t ldx, float* y,
+                  int64_t ldy, int64_t p, const void* pkv, const void* pka, float* part, const int* rangeflag, int64_t ldpart,
+                  int64_t row0, int64_t rend);
 
 // ================================================================================================
 // Producer / consumer form of the pipelined 3 x f16 matvec ("pc"): k_rbf_pc_apply.

@@ -1,6 +1,6 @@
 // The producer / consumer Gram matvec kernel ALONE, on synthetic operands, with per-wave cycle stamps: how many shader cycles
 // does a producer / a consumer wave spend per stage (32 columns)?  Build with the kernel's A/B macros, e.g.
-//   hipcc -O3 --offload-arch=gfx950 -I include -I experiments-lanczos-adjoints_amd/csrc -DMFX_PC_STAMP=1 [-DMFX_PC_DIAG=..] tools/pc_model.hip -o tools/pc_model.bin
+//   tools/experiments/pc_matvec/build.sh base ""      tools/experiments/pc_matvec/build.sh d1 "-DMFX_PC_DIAG=1"   ...
 // Results are NOT checked here (tests/test_gpu_pc_matvec.py does that through libmfx); this is a timing harness.
 #include <stdarg.h>
 #include <stdio.h>
