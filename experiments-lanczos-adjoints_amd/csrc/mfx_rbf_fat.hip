@@ -23,6 +23,10 @@
 #include "mfx_internal.h"
 #include "mfx_rbf_common.h"
 
+#ifndef MFX_FAT_DIAG
+#define MFX_FAT_DIAG 0  // timing diagnostics (WRONG results): 1 = no LDS-DMA in the tile loop, 2 = also no barrier, 3 = also no fragment reads
+#endif
+
 namespace mfx {
 
 // MFMA slots of a block: 0-9 contraction c0-c9, 10 distance d0, 11 c10, 12 d1, 13 c11.  Entry = slot + 14 * lag: lag 1 = in the
@@ -245,7 +249,7 @@ __global__ __launch_bounds__(256, 1) void k_rbf_fat_apply(const float* __restric
       const int blk1 = (blk + 1) & 7, blk2 = (blk + 2) & 7;
       const int jb2 = blk2 >> 2, mi2 = blk2 & 3;
       const bool neg_c = ((jb + mi) & 1) != 0, neg_n = (((blk1 >> 2) + (blk1 & 3)) & 1) != 0;
-      if (blk == 5 && tl + 2 < ntl) issue_tile_dma(tl + 2);  // (this tile's buffer has been dead since the barrier behind block 4)
+      if (MFX_FAT_DIAG == 0 && blk == 5 && tl + 2 < ntl) issue_tile_dma(tl + 2);  // (this tile's buffer has been dead since the barrier behind block 4)
       // Invariant at this point: (ahc, alc) hold K_blk except for the table's lag-1 steps (still to run on wc); wn holds the
       // distances of block blk + 1, untouched; ajs[jb2 & 1] holds the column operand that block blk + 2 needs from slot 10 on.
 #pragma unroll
@@ -265,12 +269,12 @@ __global__ __launch_bounds__(256, 1) void k_rbf_fat_apply(const float* __restric
         split_slot(slot, 0, wn, ahn, aln, lpn, neg_n);
         // fragment reads, one per gap: the probe fragments of the NEXT column block during this one (blocks mi = 1, 2: sixteen
         // reads... eight per block), the column operand of the column block after that in block mi = 1
-        if (mi == 1 && slot < NKD) {
+        if (MFX_FAT_DIAG < 3 && mi == 1 && slot < NKD) {
           // ajs of column block c + 1 is needed by the distances of block (c + 1, mi 0), issued in block (c, mi 2)
           ajs[(jb + 1) & 1][slot] = *reinterpret_cast<const half8*>(reinterpret_cast<const _Float16*>(fat_smem + (jb == 1 ? buf ^ 1 : buf) * S::kTile) +
                                                                    (((jb + 1) & 1) * 32 + l31) * AROW + slot * 16 + lhi * 8);
         }
-        if (mi == 3) {
+        if (MFX_FAT_DIAG < 3 && mi == 3) {
           // the probe fragments of the next column block roll in behind the last MFMA of this column block that reads the
           // register they replace: fragment (s, nb, hi) is read by MFMAs 6 s + 3 nb and + 2, (s, nb, lo) by + 1
 #pragma unroll
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(256, 1) void k_rbf_fat_apply(const float* __restric
         // tile tl + 1 (requested a tile ago) has landed for everybody, and everybody is done with this tile's buffer: its last reads
         // -- the probe fragments of column block 1, rolled in during block 3 -- were consumed by the MFMAs of this block
         __builtin_amdgcn_s_waitcnt(0x0F70);
-        __builtin_amdgcn_s_barrier();
+        if (MFX_FAT_DIAG < 2) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
       }
       // rotate: next -> current, next-but-one -> next

@@ -1,0 +1,211 @@
+// Which f16 MFMA shape is faster BY WALL TIME for the fat-wave Gram matvec's block loop on random data -- 32x32x16 (12 contraction +
+// 2 distance MFMAs of 32 cycles per 32 x 32 x 64-probe block) or 16x16x32 (24 + 4 MFMAs of 16 cycles)?  Same flops, same cycles on
+// paper; the chip is power-limited under this loop (1.5-1.7 GHz), and MI355X_MICROARCH.md ('DVFS give-back' item 7) reports that it
+// holds a higher clock on the 16x16x32 shape in bare loops.  Here: one wave per SIMD, the real VALU chain of a block (16 v_exp, 8
+// v_cvt_pk, 16 v_fma_mixlo/hi) spread over the MFMA gaps, probe fragments re-read from LDS (random data) every four blocks, the
+// distance operands from LDS, accumulators in AGPRs.  Not a correct matvec (no layout bookkeeping): an instruction-mix and data-
+// toggling model.  Prints wall time per block and the clock (s_memtime cycles / wall).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <type_traits>
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void chain_op(float (&w)[16], half8 (&ah)[2], half8 (&al)[2], unsigned (&lp)[8], int t, int i) {
+  if (t == 0) {
+    w[i] = __builtin_amdgcn_exp2f(w[i]);
+  } else if (t == 1) {
+    const half2v h = {(_Float16)w[2 * i], (_Float16)w[2 * i + 1]};
+    ah[i >> 2][(i & 3) * 2] = h[0];
+    ah[i >> 2][(i & 3) * 2 + 1] = h[1];
+  } else {
+    const int pr = i >> 1;
+    const half2v h = {ah[pr >> 2][(pr & 3) * 2], ah[pr >> 2][(pr & 3) * 2 + 1]};
+    const unsigned hb = __builtin_bit_cast(unsigned, h);
+    if ((i & 1) == 0) {
+      asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lp[pr]) : "v"(hb), "v"(w[i]));
+    } else {
+      asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lp[pr]) : "v"(hb), "v"(w[i]));
+      const half2v l = __builtin_bit_cast(half2v, lp[pr]);
+      al[pr >> 2][(pr & 3) * 2] = l[0];
+      al[pr >> 2][(pr & 3) * 2 + 1] = l[1];
+    }
+  }
+}
+
+// SHAPE 0: 32x32x16, 14 slots per block.  SHAPE 1: 16x16x32, 28 slots per block.
+template <int SHAPE, int CHAIN>
+__global__ __launch_bounds__(256, 1) void k(const _Float16* __restrict__ rnd, float* out, long long* cyc, int blocks) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int i = tid; i < 65536 / 2; i += 256) {
+    const _Float16 v = rnd[(blockIdx.x * 977 + i) % (1 << 20)];
+    // pieces 8-11 of every 12-piece group hold the distance operands: magnitudes <~ 0.7, so that a distance is O(+-3) and exp2 stays in range
+    const int piece = (i / 512) % 12;
+    reinterpret_cast<_Float16*>(smem)[i] = piece >= 8 ? (_Float16)((float)v * (1.f / 12000.f)) : v;
+  }
+  __syncthreads();
+  float agpr_seed = 0.f;
+  asm volatile("; agpr" : "+a"(agpr_seed));
+  constexpr int NACC = 8;  // 128 accumulator registers either way: 8 x floatx16 or 32 x floatx4
+  floatx16 acc16[SHAPE == 0 ? NACC : 1];
+  floatx4 acc4[SHAPE == 1 ? 4 * NACC : 1];
+  for (int q = 0; q < (SHAPE == 0 ? NACC : 1); ++q)
+    for (int r = 0; r < 16; ++r) acc16[q][r] = 0.f;
+  for (int q = 0; q < (SHAPE == 1 ? 4 * NACC : 1); ++q)
+    for (int r = 0; r < 4; ++r) acc4[q][r] = 0.f;
+  acc16[0][0] = agpr_seed;
+  acc4[0][0] = agpr_seed;
+  half8 vf[8], aj[2], bi[2];
+  half8 ahc[2], alc[2], ahn[2], aln[2];
+  unsigned lp[8];
+  float wn[16];
+  floatx16 wd16;
+  floatx4 wd4[4];
+  const char* base = smem + lane * 16;
+  for (int q = 0; q < 8; ++q) vf[q] = *reinterpret_cast<const half8*>(base + q * 1024);
+  for (int q = 0; q < 2; ++q) {
+    aj[q] = *reinterpret_cast<const half8*>(base + (8 + q) * 1024);
+    bi[q] = *reinterpret_cast<const half8*>(base + (10 + q) * 1024);
+    ahc[q] = vf[q];
+    alc[q] = vf[q + 2];
+    ahn[q] = vf[q];
+    aln[q] = vf[q + 2];
+  }
+  for (int q = 0; q < 16; ++q) wn[q] = -0.5f * (float)(q + 1) - 1e-3f * lane;
+  for (int q = 0; q < 8; ++q) lp[q] = 0;
+  constexpr int NSLOT = SHAPE == 0 ? 14 : 28;
+  // placement of the 40 chain steps: exp i behind slot e[i], hi-cvt of pair p behind h[p], mix step i behind m[i] (in units of slots of THIS shape)
+  const long long t0 = __builtin_readcyclecounter();
+  for (int b4 = 0; b4 < blocks / 4; ++b4) {
+    const char* vb = base + (b4 & 3) * 12288;  // other probe fragments every four blocks
+   auto body = [&](auto bc) {   // (compile-time block position: every register index below is static)
+    constexpr int b = decltype(bc)::value;
+#pragma unroll
+    for (int slot = 0; slot < NSLOT; ++slot) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (SHAPE == 0) {
+        if (slot == 10 || slot == 12) {
+          const int q = (slot - 10) / 2;
+          if (q == 0) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(wd16) : "a"(aj[q]), "a"(bi[q]));
+          else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(wd16) : "a"(aj[q]), "a"(bi[q]));
+        } else {
+          const int m = slot < 10 ? slot : (slot == 11 ? 10 : 11);
+          const int s = m / 6, nb = (m / 3) % 2, w = m % 3;
+          const int a = (b & 3) * 2 + nb;
+          acc16[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w == 2 ? alc[s] : ahc[s], w == 1 ? vf[s * 4 + nb * 2 + 1] : vf[s * 4 + nb * 2], acc16[a], 0, 0, 0);
+        }
+      } else {
+        if (slot >= 20 && (slot & 1) == 0 && slot < 28) {  // distance MFMAs behind slots 20, 22, 24, 26
+          const int q = (slot - 20) / 2;
+          asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(wd4[q]) : "a"(aj[q & 1]), "a"(bi[q >> 1]));
+        } else {
+          const int m = slot < 20 ? slot : 20 + (slot - 21) / 2;  // 24 contraction MFMAs: slots 0-19, 21, 23, 25, 27
+          const int ih = m / 12, pg = (m / 3) % 4, w = m % 3;
+          const int a = ((b & 3) * 2 + ih) * 4 + pg;
+          acc4[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w == 2 ? alc[ih] : ahc[ih], w == 1 ? vf[pg * 2 + 1] : vf[pg * 2], acc4[a], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // the chain of the next block, by table (slot + NSLOT * lag; lag-1 steps act on the block that has just become current:
+      // the model applies them to the same arrays, which only affects values, not the instruction stream)
+      if (CHAIN) {
+        constexpr int e0[16] = {0, 1, 2, 3, 4, 5, 5, 6, 7, 8, 9, 10, 10, 11, 12, 13};
+        constexpr int h0[8] = {2, 4, 6, 7, 9, 11, 12, 14};
+        constexpr int m0[16] = {3, 4, 5, 6, 7, 8, 8, 9, 10, 11, 12, 13, 13, 14, 15, 16};
+        constexpr int e1[16] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15};
+        constexpr int h1[8] = {16, 16, 17, 17, 22, 22, 23, 23};
+        constexpr int m1[16] = {18, 19, 18, 19, 20, 21, 20, 21, 24, 25, 24, 25, 26, 27, 26, 27};
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if ((SHAPE == 0 ? e0[i] : e1[i]) % NSLOT == slot) chain_op(wn, ahn, aln, lp, 0, i);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if ((SHAPE == 0 ? h0[i] : h1[i]) % NSLOT == slot) chain_op(wn, ahn, aln, lp, 1, i);
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if ((SHAPE == 0 ? m0[i] : m1[i]) % NSLOT == slot) chain_op(wn, ahn, aln, lp, 2, i);
+      }
+      // probe fragments of the next column block, one read per slot in the block before a column block starts
+      if ((b & 3) == 3 && slot < 8) vf[slot] = *reinterpret_cast<const half8*>(vb + slot * 1024 + 1024);
+      if ((b & 3) == 1 && slot < 2) aj[slot] = *reinterpret_cast<const half8*>(vb + (9 + slot) * 1024);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    ahc[0] = ahn[0]; ahc[1] = ahn[1];
+    alc[0] = aln[0]; alc[1] = aln[1];
+    if (SHAPE == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) wn[r] = wd16[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) wn[r] = wd4[r >> 2][r & 3];
+    }
+   };
+   body(std::integral_constant<int, 0>{});
+   body(std::integral_constant<int, 1>{});
+   body(std::integral_constant<int, 2>{});
+   body(std::integral_constant<int, 3>{});
+  }
+  const long long t1 = __builtin_readcyclecounter();
+  if (tid == 0) cyc[blockIdx.x] = t1 - t0;
+  float s = 0;
+  for (int q = 0; q < (SHAPE == 0 ? NACC : 1); ++q)
+    for (int r = 0; r < 16; ++r) s += acc16[q][r];
+  for (int q = 0; q < (SHAPE == 1 ? 4 * NACC : 1); ++q)
+    for (int r = 0; r < 4; ++r) s += acc4[q][r];
+  if (s == 12345.678f) out[0] = s;
+}
+
+template <int SHAPE, int CHAIN>
+void run(const char* name, const _Float16* rnd) {
+  float* d;
+  long long* cyc;
+  hipMalloc(&d, 64);
+  hipMalloc(&cyc, 256 * 8);
+  const int blocks = 400000;  // ~0.1 s: long enough for the clock to settle
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k<SHAPE, CHAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+  k<SHAPE, CHAIN><<<256, 256, 65536>>>(rnd, d, cyc, 20000);
+  float best = 1e30f;
+  double cycles = 0;
+  for (int it = 0; it < 3; ++it) {
+    hipEventRecord(e0);
+    k<SHAPE, CHAIN><<<256, 256, 65536>>>(rnd, d, cyc, blocks);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    long long h[256];
+    hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
+    double mean = 0;
+    for (int i = 0; i < 256; ++i) mean += (double)h[i];
+    mean /= 256;
+    if (ms < best) { best = ms; cycles = mean; }
+  }
+  printf("%-28s %8.1f ns per block, %7.1f cycles per block, %.2f GHz\n", name, best * 1e6 / blocks, cycles / blocks, cycles / (best * 1e-3) * 1e-9);
+  hipFree(d);
+  hipFree(cyc);
+}
+
+int main() {
+  const size_t n = 1 << 20;
+  _Float16* h = (_Float16*)malloc(n * 2);
+  srand(3);
+  for (size_t i = 0; i < n; ++i) h[i] = (_Float16)((rand() % 4001 - 2000) * 4.0f);
+  _Float16* rnd;
+  hipMalloc(&rnd, n * 2);
+  hipMemcpy(rnd, h, n * 2, hipMemcpyHostToDevice);
+  for (int rep = 0; rep < 2; ++rep) {
+    run<0, 1>("32x32x16 + chain", rnd);
+    run<1, 1>("16x16x32 + chain", rnd);
+    run<0, 0>("32x32x16, MFMAs only", rnd);
+    run<1, 0>("16x16x32, MFMAs only", rnd);
+  }
+  return 0;
+}
