@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
+import os
 
 import torch
 import torch.distributed as dist
@@ -378,7 +379,8 @@ class Layout:
             else:
                 raise ValueError(f"row group size {row_group_size} exceeds the world size {self.world}")
             if native is None:
-                native = on and dist.get_backend(row_group) == "nccl"
+                # MFX_NATIVE_COMM=0: operational escape hatch back to the torch.distributed callbacks (same results)
+                native = on and dist.get_backend(row_group) == "nccl" and os.environ.get("MFX_NATIVE_COMM", "1") != "0"
             self.comm = NativeRowComm(n, row_group) if native else RowComm(n, row_group)
             self.native = bool(native)
         else:
