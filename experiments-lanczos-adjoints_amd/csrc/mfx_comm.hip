@@ -111,6 +111,8 @@ int native_allgather_rows(void* ctx, const void* local, int64_t ldlocal, void* f
 
 extern "C" {
 
+int mfx_rccl_available(void) { return mfx::rccl() != nullptr ? 1 : 0; }
+
 int mfx_rccl_unique_id(void* id, int64_t bytes) {
   using namespace mfx;
   MFX_REQUIRE(id && bytes >= (int64_t)sizeof(ncclUniqueId), MFX_ERR_INVALID, "unique-id buffer of %lld bytes, need %zu", (long long)bytes,

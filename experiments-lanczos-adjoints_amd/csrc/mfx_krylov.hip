@@ -596,32 +596,58 @@ static int apply_sharded(const mfx_operator* op, const mfx_comm* cm, int transpo
 // ------------------------------------------------------------------------------------------------
 // drivers
 // ------------------------------------------------------------------------------------------------
+// i * (re, im) = (-im, re) on interleaved complex vectors held as 2 n reals: the second basis slot of a complex Arnoldi step
+template <typename T>
+__global__ __launch_bounds__(256) void k_times_i(const T* __restrict__ q, T* __restrict__ jq, int64_t ld, int64_t ncomplex) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= ncomplex) return;
+  const T* src = q + (int64_t)blockIdx.y * ld + 2 * i;
+  T* dst = jq + (int64_t)blockIdx.y * ld + 2 * i;
+  const T re = src[0], im = src[1];
+  dst[0] = -im;
+  dst[1] = re;
+}
+
 // comm != NULL: row-sharded (n = rows of this rank, op->n = operator size, Qfull (p, k, op->n) receives the gathered basis)
+//
+// S = 2: COMPLEX vectors of n / 2 entries, held interleaved as n reals, and an operator that is complex-linear on them.  A
+// complex Krylov vector q takes TWO real basis slots, q and i q: the complex projection h = q^H w is (<q, w>, <i q, w>) in
+// real inner products, and w -= h q is w -= Re(h) q + Im(h) (i q) -- so the complex recurrence (arnoldi.py:66,87,92,95 with
+// .conj()) is the real one on 2 (i + 1) slots, run by the same dots / update kernels.  Q is then (p, 2 k, n) and H is
+// (p, 2 k, k): rows 2 a and 2 a + 1 of column i hold Re and Im of H[a][i].
 template <typename T>
 static int arnoldi_forward_t(const mfx_operator* op, const T* v0, int64_t n, int64_t k, int64_t p,
                              int second_pass, T* Q, T* H, T* r, T* cinv, const KrylovWs& ws,
-                             hipStream_t stream, const mfx_comm* comm = nullptr, T* Qfull = nullptr) {
-  Ctx<T> c(n, k, p, pick_vec<T>(n, {v0, Q, r, ws.w}), stream);
+                             hipStream_t stream, const mfx_comm* comm = nullptr, T* Qfull = nullptr, int S = 1) {
+  Ctx<T> c(n, S * k, p, pick_vec<T>(n, {v0, Q, r, ws.w}), stream);
   if (comm) c.shard(comm, static_cast<T*>(ws.stage));
   c.fine();
   T* P1 = static_cast<T*>(ws.p1);
   T* P2 = static_cast<T*>(ws.p2);
   T* PN = static_cast<T*>(ws.pn);
-  const int64_t ldq = k * n;
-  MFX_TRY(zero_async(H, sizeof(T) * p * k * k, stream));
+  const int64_t ldq = S * k * n;
+  const int64_t ldh = S * k * k;
+  auto second_slot = [&](int64_t i) -> int {  // slot S i + 1 = i * slot S i
+    if (S == 1) return MFX_OK;
+    k_times_i<T><<<dim3((unsigned)((n / 2 + 255) / 256), (unsigned)p), 256, 0, stream>>>(Q + S * i * n, Q + (S * i + 1) * n, ldq, n / 2);
+    MFX_CHECK_LAUNCH();
+    return MFX_OK;
+  };
+  MFX_TRY(zero_async(H, sizeof(T) * p * ldh, stream));
   {
     ScopedTimer t(2, stream);
     MFX_TRY(launch_sumsq<T>(c, v0, n, PN));
     MFX_TRY(launch_scale<T>(c, v0, n, Q, ldq, PN, nullptr, 0, nullptr, 0, cinv));  // q_0, c = 1/|v|
+    MFX_TRY(second_slot(0));
   }
   T* w = r;  // the running vector lives in the remainder output (arnoldi.py:75 returns it as r)
   // CSR operator, few slices: normalisation of the previous step, operator application and h = Q^T w in one launch
   // (k_csr_step).  The un-normalised w of step i - 1 is the input of step i, so w alternates between r and a scratch
   // vector, arranged so that the last step ends in r.
-  const bool fused = csr_fusable<T>(op, c, 0);
+  const bool fused = S == 1 && csr_fusable<T>(op, c, 0);
   T* const scratch_w = static_cast<T*>(ws.w);
   for (int64_t i = 0; i < k; ++i) {
-    const int m = (int)(i + 1);
+    const int m = (int)(S * (i + 1));
     if (fused) {
       T* const w_prev = w;
       w = (((i ^ (k - 1)) & 1) != 0) ? scratch_w : r;
@@ -639,14 +665,14 @@ static int arnoldi_forward_t(const mfx_operator* op, const T* v0, int64_t n, int
     } else if (comm) {
       MFX_TRY(apply_sharded<T>(op, comm, 0, Q + i * n, ldq, w, n, p, Qfull + i * op->n, k * op->n, ws, stream));
     } else {
-      MFX_TRY(apply_any(op, 0, Q + i * n, ldq, nullptr, 0, w, n, p, ws.opws, ws.opws_bytes, stream));
+      MFX_TRY(apply_any(op, 0, Q + S * i * n, ldq, nullptr, 0, w, n, p, ws.opws, ws.opws_bytes, stream));
     }
     ScopedTimer t(2, stream);
     if (!fused) MFX_TRY(launch_dots<T>(c, Q, ldq, n, m, w, n, P1));
     UpdateArgs<T> a{};
     a.rows = Q; a.rows_ldb = ldq; a.row_stride = n; a.m = m;
     a.partial_in = P1; a.s1 = T(1);
-    a.hout = H + i; a.hout_ldb = k * k; a.hout_stride = k;  // H[:, i] (arnoldi.py:99)
+    a.hout = H + i; a.hout_ldb = ldh; a.hout_stride = k;  // H[:, i] (arnoldi.py:99)
     a.x = w; a.ldx = n; a.y = w; a.ldy = n;
     a.partial_out = P2; a.partial_norm = PN;
     if (second_pass) {
@@ -660,9 +686,59 @@ static int arnoldi_forward_t(const mfx_operator* op, const T* v0, int64_t n, int
       MFX_TRY(launch_update<T>(c, a, false, true));
     }
     if (i + 1 < k && !fused) {  // Q2: H[k][k-1] does not exist; the last vector stays un-normalised in r
-      MFX_TRY(launch_scale<T>(c, w, n, Q + (i + 1) * n, ldq, PN, nullptr, 0, H + (i + 1) * k + i, k * k, nullptr));
+      MFX_TRY(launch_scale<T>(c, w, n, Q + S * (i + 1) * n, ldq, PN, nullptr, 0, H + S * (i + 1) * k + i, ldh, nullptr));
+      MFX_TRY(second_slot(i + 1));
     }
   }
+  return MFX_OK;
+}
+
+// (p, 2 k, k) real rows (Re, Im interleaved by ROW) -> (p, k, k) complex entries; c -> (c, 0)
+template <typename T>
+__global__ __launch_bounds__(256) void k_complex_small(const T* __restrict__ Hext, const T* __restrict__ cinv, T* __restrict__ H,
+                                                       T* __restrict__ c, int k) {
+  const int b = blockIdx.x;
+  for (int e = threadIdx.x; e < k * k; e += 256) {
+    const int a = e / k, i = e % k;
+    H[((int64_t)b * k * k + e) * 2] = Hext[(int64_t)b * 2 * k * k + (2 * a) * k + i];
+    H[((int64_t)b * k * k + e) * 2 + 1] = Hext[(int64_t)b * 2 * k * k + (2 * a + 1) * k + i];
+  }
+  if (threadIdx.x == 0) {
+    c[2 * b] = cinv[b];
+    c[2 * b + 1] = T(0);
+  }
+}
+
+struct ComplexWs {
+  void* Qext;  // (p, 2 k, 2 n)
+  void* Hext;  // (p, 2 k, k)
+  void* cinv;  // (p)
+  KrylovWs kws;
+};
+static int64_t carve_complex_ws(const mfx_operator* op, int64_t n, int64_t k, int64_t p, void* ws, int64_t ws_bytes, ComplexWs* out) {
+  const size_t es = dtype_size(op->dtype);
+  Carver cv(ws, ws_bytes);
+  ComplexWs r{};
+  r.Qext = cv.take(p * 2 * k * 2 * n * es);
+  r.Hext = cv.take(p * 2 * k * k * es);
+  r.cinv = cv.take(p * es);
+  const int64_t inner = carve_ws(op, 2 * n, 2 * k, p, ws ? static_cast<char*>(ws) + cv.off : nullptr, ws ? ws_bytes - cv.off : 0, &r.kws);
+  if (out) *out = r;
+  return cv.off + inner;
+}
+
+template <typename T>
+static int arnoldi_forward_complex_t(const mfx_operator* op, const T* v0, int64_t n, int64_t k, int64_t p, int second_pass, T* Q,
+                                     T* H, T* r, T* c, const ComplexWs& w, hipStream_t stream) {
+  T* Qext = static_cast<T*>(w.Qext);
+  T* Hext = static_cast<T*>(w.Hext);
+  MFX_TRY(arnoldi_forward_t<T>(op, v0, 2 * n, k, p, second_pass, Qext, Hext, r, static_cast<T*>(w.cinv), w.kws, stream, nullptr,
+                               nullptr, 2));
+  // the complex basis = the even slots; (b, i) -> one row of 2 n reals
+  for (int64_t b = 0; b < p; ++b)
+    MFX_TRY(copy_rows_async(Q + b * k * 2 * n, sizeof(T) * 2 * n, Qext + b * 2 * k * 2 * n, sizeof(T) * 4 * n, sizeof(T) * 2 * n, (size_t)k, stream));
+  k_complex_small<T><<<(unsigned)p, 256, 0, stream>>>(Hext, static_cast<const T*>(w.cinv), H, c, (int)k);
+  MFX_CHECK_LAUNCH();
   return MFX_OK;
 }
 
@@ -954,6 +1030,26 @@ int mfx_arnoldi_forward(const mfx_operator* op, const void* v0, int64_t n, int64
       return arnoldi_forward_t<float>(op, (const float*)v0, n, k, p, second_pass, (float*)Q, (float*)H, (float*)r, (float*)c, kws, st);
     return arnoldi_forward_t<double>(op, (const double*)v0, n, k, p, second_pass, (double*)Q, (double*)H, (double*)r, (double*)c, kws, st);
   });
+}
+
+int64_t mfx_complex_workspace_bytes(const mfx_operator* op, int64_t n, int64_t k, int64_t p) {
+  if (!op) return -1;
+  return carve_complex_ws(op, n, k, p, nullptr, 0, nullptr);
+}
+
+int mfx_arnoldi_forward_complex(const mfx_operator* op, const void* v0, int64_t n, int64_t k, int64_t p, int second_pass, void* Q,
+                                void* H, void* r, void* c, void* ws, int64_t ws_bytes, void* stream) {
+  MFX_REQUIRE(op && v0 && Q && H && r && c, MFX_ERR_INVALID, "null argument");
+  MFX_REQUIRE(k >= 1 && k <= n, MFX_ERR_INVALID, "Parameter depth %lld is outside the expected range", (long long)k);
+  MFX_TRY(check_common(op, 2 * n, 2 * k, p));  // the operator is the real form (size 2 n) of the complex-linear map
+  MFX_REQUIRE(k <= 65535, MFX_ERR_UNSUPPORTED, "k=%lld exceeds the grid limit 65535", (long long)k);
+  ComplexWs cw;
+  const int64_t need = carve_complex_ws(op, n, k, p, ws, ws_bytes, &cw);
+  MFX_REQUIRE(ws && need <= ws_bytes, MFX_ERR_WORKSPACE, "workspace too small: need %lld bytes", (long long)need);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (op->dtype == MFX_F32)
+    return arnoldi_forward_complex_t<float>(op, (const float*)v0, n, k, p, second_pass, (float*)Q, (float*)H, (float*)r, (float*)c, cw, s);
+  return arnoldi_forward_complex_t<double>(op, (const double*)v0, n, k, p, second_pass, (double*)Q, (double*)H, (double*)r, (double*)c, cw, s);
 }
 
 int mfx_arnoldi_adjoint(const mfx_operator* op, int64_t n, int64_t k, int64_t p, const void* Q, const void* H,

@@ -97,8 +97,9 @@ struct RbfTileH3 {
 };
 
 
-// launcher of the fat-wave matvec kernel (mfx_rbf_fat.hip): RBF, d <= 8, 33..64-probe chunks; grid = (ceil(rows / 512), chunks, splits)
-int rbf_fat_launch(int dpad, bool vec4, dim3 grid, hipStream_t stream, const float* xs, const float* sq, int64_t n,
+// launcher of the fat-wave matvec kernel (mfx_rbf_fat.hip): RBF, d <= 8, chunks of nb * 32 vectors (nb = 1, 2);
+// grid = (ceil(rows / 512), chunks, splits)
+int rbf_fat_launch(int dpad, int nb, bool vec4, dim3 grid, hipStream_t stream, const float* xs, const float* sq, int64_t n,
                    const float* outputscale, const float* noise, const float* vscale, const float* x, int64_t ldx, float* y,
                    int64_t ldy, int64_t p, const void* pkv, const void* pka, float* part, const int* rangeflag, int64_t ldpart,
                    int64_t row0, int64_t rend);

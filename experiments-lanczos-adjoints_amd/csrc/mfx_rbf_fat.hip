@@ -29,33 +29,59 @@
 
 namespace mfx {
 
-// MFMA slots of a block: 0-9 contraction c0-c9, 10 distance d0, 11 c10, 12 d1, 13 c11.  Entry = slot + 14 * lag: lag 1 = in the
-// NEXT block (only pairs of the second k-step, whose consumers c6.. come after slot 5).  Steps of the split chain of a pair of
-// entries (2p, 2p + 1):  e: v_exp_f32 of one entry;  h: hi pair = v_cvt_pk_f16_f32;  m: lo half = f16(k - hi) written straight into
-// its half of the packed lo register (v_fma_mixlo_f16 for the even entry, then v_fma_mixhi_f16 for the odd one: 40 VALU
-// instructions per block instead of 48 with v_fma_mix_f32 x 2 + v_cvt_pk; bit-identical).  Issue cycles per slot (exp 8, others
-// 4): 16 12 16 12 16 20 16 16 16 16 20 16 16 16 -- under the ~24 that hide behind an MFMA, and no step follows its producer
-// within one slot.
+// MFMA slots of a block and the placement of the split chain behind them, by the number NB of 32-probe blocks of a chunk.
+//   NB = 2 (33..64 vectors): 14 slots -- 0-9 contraction c0-c9, 10 distance d0, 11 c10, 12 d1, 13 c11;
+//   NB = 1 (<= 32 vectors):   8 slots -- c0 c1 c2 d0 c3 d1 c4 c5 (the distances two contraction MFMAs before the block ends: their
+//                             first reader, a v_exp behind slot 0 of the next block, then follows three more MFMAs).
+// Table entry = slot + kSlots * lag: lag 1 = in the NEXT block (only pairs of the second k-step, whose consumers come later in
+// that block).  Steps of the chain of a pair of entries (2p, 2p + 1):  e: v_exp_f32 of one entry;  h: hi pair = v_cvt_pk_f16_f32;
+// m: lo half = f16(k - hi) written straight into its half of the packed lo register (v_fma_mixlo_f16 for the even entry, then
+// v_fma_mixhi_f16 for the odd one: 40 VALU instructions per block instead of 48 with v_fma_mix_f32 x 2 + v_cvt_pk; bit-identical).
+//   NB = 2: issue cycles per slot (exp 8, others 4) 16 12 16 12 16 20 16 16 16 16 20 16 16 16 -- under the ~24 that hide behind an
+//           MFMA, and no step follows its producer within one slot;
+//   NB = 1: the same 40 instructions behind 8 MFMAs: 28 issue cycles in EVERY slot (pair p: both exps behind slot p, hi p + 1,
+//           mixlo p + 2, mixhi p + 3) -- the block is VALU-bound (~290 cycles against 256 of matrix pipe), evenly.
 struct FatSplit {
   int e[16], h[8], m[16];
 };
-constexpr FatSplit kSplit = {{0, 1, 2, 3, 4, 5, 5, 6, 7, 8, 9, 10, 10, 11, 12, 13},
-                             {2, 4, 6, 7, 9, 11, 12, 14},
-                             {3, 4, 5, 6, 7, 8, 8, 9, 10, 11, 12, 13, 13, 14, 15, 16}};
+template <int NB>
+struct FatPlan;
+template <>
+struct FatPlan<2> {
+  static constexpr int kSlots = 14;
+  static constexpr FatSplit kSplit = {{0, 1, 2, 3, 4, 5, 5, 6, 7, 8, 9, 10, 10, 11, 12, 13},
+                                      {2, 4, 6, 7, 9, 11, 12, 14},
+                                      {3, 4, 5, 6, 7, 8, 8, 9, 10, 11, 12, 13, 13, 14, 15, 16}};
+  // slot -> distance step q (or -1), slot -> contraction MFMA m (or -1), contraction MFMA -> slot
+  static constexpr int dist_q(int slot) { return slot == 10 ? 0 : (slot == 12 ? 1 : -1); }
+  static constexpr int contr_m(int slot) { return slot < 10 ? slot : (slot == 11 ? 10 : (slot == 13 ? 11 : -1)); }
+  static constexpr int slot_of(int m) { return m < 10 ? m : (m == 10 ? 11 : 13); }
+};
+template <>
+struct FatPlan<1> {
+  static constexpr int kSlots = 8;
+  static constexpr FatSplit kSplit = {{0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7},
+                                      {1, 2, 3, 4, 5, 6, 7, 8},
+                                      {2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10}};
+  static constexpr int dist_q(int slot) { return slot == 3 ? 0 : (slot == 5 ? 1 : -1); }
+  static constexpr int contr_m(int slot) { return slot < 3 ? slot : (slot == 4 ? 3 : (slot >= 6 ? slot - 2 : -1)); }
+  static constexpr int slot_of(int m) { return m < 3 ? m : (m == 3 ? 4 : m + 2); }
+};
 
-template <int DPAD>
+template <int DPAD, int NB>
 struct FatSmem {
   static constexpr int KD = DPAD + 2;
   static constexpr int NKD = (3 * KD + 15) / 16;
   static constexpr int AROW = NKD * 16 + 8;
   static constexpr int kABytes = 64 * AROW * 2;  // column operand of a tile (k_pack_tiles' pka)
-  static constexpr int kVBytes = 2 * 8 * 64 * 16;  // probe image of a tile: 8 hi rows, 8 lo rows of 64 packs
+  static constexpr int kVRow = NB * 32 * 16;      // one image row: the 16-B packs of the chunk's NB * 32 probes
+  static constexpr int kVBytes = 2 * 8 * kVRow;   // probe image of a tile: 8 hi rows, then 8 lo rows
   static constexpr int kTile = kABytes + kVBytes;
   static constexpr int kTotal = 2 * kTile;
   static_assert(kABytes % 1024 == 0, "tile images are whole 1-KiB DMA pieces");
 };
 
-template <int DPAD, bool VEC4>
+template <int DPAD, bool VEC4, int NB>
 __global__ __launch_bounds__(256, 1) void k_rbf_fat_apply(const float* __restrict__ xs, const float* __restrict__ sq, int64_t n,
                                                           const float* __restrict__ outputscale, const float* __restrict__ noise,
                                                           const float* __restrict__ vscale, const float* __restrict__ x,
@@ -64,14 +90,16 @@ __global__ __launch_bounds__(256, 1) void k_rbf_fat_apply(const float* __restric
                                                           float* __restrict__ part, const int* __restrict__ rangeflag,
                                                           int64_t ldpart, int64_t row0, int64_t rend) {
   if (rangeflag && *rangeflag != 0) return;  // f16 range guard: the fp32-distance launch queued behind this one does the work
-  using S = FatSmem<DPAD>;
-  constexpr int KD = S::KD, NKD = S::NKD, AROW = S::AROW;
+  using S = FatSmem<DPAD, NB>;
+  using Plan = FatPlan<NB>;
+  constexpr int KD = S::KD, NKD = S::NKD, AROW = S::AROW, kSlots = Plan::kSlots;
+  static_assert(NKD == 2, "two distance MFMAs per block (d <= 8)");
   extern __shared__ __attribute__((aligned(16))) char fat_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5;
   const int64_t i_wave = row0 + (int64_t)blockIdx.x * 512 + wid * 128;
-  const int64_t b0 = (int64_t)blockIdx.y * 64;
+  const int64_t b0 = (int64_t)blockIdx.y * (NB * 32);
   const int64_t ntile_all = (n + 63) / 64;
   // gridDim.z > 1: column split (rbf_split_count): this workgroup sweeps tiles [t_first, t_first + ntl)
   const int64_t t_first = ntile_all * blockIdx.z / gridDim.z;
@@ -94,6 +122,7 @@ __global__ __launch_bounds__(256, 1) void k_rbf_fat_apply(const float* __restric
     }
 #pragma unroll
     for (int c = 0; c < S::kVBytes / 4096; ++c) glds16(vsrc + (wid + 4 * c) * 1024 + lane * 16, dst + S::kABytes + (wid + 4 * c) * 1024);
+    static_assert(S::kVBytes % 4096 == 0, "a whole number of probe-image pieces per wave");
   };
   if (0 < ntl) issue_tile_dma(0);
   if (1 < ntl) issue_tile_dma(1);
@@ -127,11 +156,11 @@ __global__ __launch_bounds__(256, 1) void k_rbf_fat_apply(const float* __restric
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
     for (int q = 0; q < NKD; ++q) asm volatile("" : "+a"(bih[mi][q]));
-  floatx16 acc[4][2], mst[4][2];
+  floatx16 acc[4][NB], mst[4][NB];
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         acc[mi][nb][r] = 0.f;
@@ -147,7 +176,7 @@ __global__ __launch_bounds__(256, 1) void k_rbf_fat_apply(const float* __restric
   };
   auto read_v1 = [&](half8& v, int buf, int jb, int s, int nb, int hl) {  // one probe fragment (k-step s, probe block nb, hi / lo)
     const int row = (jb * 2 + s) * 2 + lhi;
-    v = *reinterpret_cast<const half8*>(fat_smem + buf * S::kTile + S::kABytes + hl * 8192 + row * 1024 + (nb * 32 + l31) * 16);
+    v = *reinterpret_cast<const half8*>(fat_smem + buf * S::kTile + S::kABytes + hl * (8 * S::kVRow) + row * S::kVRow + (nb * 32 + l31) * 16);
   };
   // ---- the distance MFMAs: asm, because their 16 results must land in VGPRs with a literal-zero addend while the function's
   //      intrinsic MFMAs are in AGPR form.  The compiler does not see an MFMA there, so the wait states between the MFMA's
@@ -191,13 +220,13 @@ __global__ __launch_bounds__(256, 1) void k_rbf_fat_apply(const float* __restric
   auto split_slot = [&](const int slot, const int lag, floatx16& w, half8 (&ah)[2], half8 (&al)[2], unsigned (&lopk)[8], const bool neg) {
 #pragma unroll
     for (int i = 0; i < 16; ++i)
-      if (kSplit.e[i] == slot + 14 * lag) split_op(w, ah, al, lopk, 0, i, neg);
+      if (Plan::kSplit.e[i] == slot + kSlots * lag) split_op(w, ah, al, lopk, 0, i, neg);
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-      if (kSplit.h[i] == slot + 14 * lag) split_op(w, ah, al, lopk, 1, i, neg);
+      if (Plan::kSplit.h[i] == slot + kSlots * lag) split_op(w, ah, al, lopk, 1, i, neg);
 #pragma unroll
     for (int i = 0; i < 16; ++i)
-      if (kSplit.m[i] == slot + 14 * lag) split_op(w, ah, al, lopk, 2, i, neg);
+      if (Plan::kSplit.m[i] == slot + kSlots * lag) split_op(w, ah, al, lopk, 2, i, neg);
   };
 
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): my pieces of tiles 0 and 1
@@ -208,14 +237,14 @@ __global__ __launch_bounds__(256, 1) void k_rbf_fat_apply(const float* __restric
   floatx16 wc, wn, wd;          // distance blocks: current (its last pairs still being split), next (being split), next but one
   half8 ahc[2], alc[2], ahn[2], aln[2];   // A fragments (hi, lo) x k-step of the current and of the next block
   unsigned lpc[8], lpn[8];                 // packed lo pairs in the making (between the mixlo and the mixhi step)
-  half8 vf[2][2][2];            // probe fragments of the current column block [k-step][probe block][hi / lo]
+  half8 vf[2][NB][2];           // probe fragments of the current column block [k-step][probe block][hi / lo]
   half8 ajs[2][NKD];            // column operand of a column block, by parity
   // prologue (once per sweep, not per tile): blocks 0 and 1 by hand
   read_a(ajs[0], 0, 0);
 #pragma unroll
   for (int s = 0; s < 2; ++s)
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int hl = 0; hl < 2; ++hl) read_v1(vf[s][nb][hl], 0, 0, s, nb, hl);
 #pragma unroll
@@ -225,7 +254,7 @@ __global__ __launch_bounds__(256, 1) void k_rbf_fat_apply(const float* __restric
   asm volatile("" : "+v"(wc));  // ties the first reader of wc behind the last of these MFMAs (two MFMAs after the one that wrote wc)
   // block 0's split as far as the table places it before a block boundary (its lag-1 steps run in the loop, like every block's)
 #pragma unroll
-  for (int slot = 0; slot < 14; ++slot) split_slot(slot, 0, wc, ahc, alc, lpc, false);
+  for (int slot = 0; slot < kSlots; ++slot) split_slot(slot, 0, wc, ahc, alc, lpc, false);
 
   const float sc = outputscale[0];
   int tl = 0;
@@ -235,7 +264,7 @@ __global__ __launch_bounds__(256, 1) void k_rbf_fat_apply(const float* __restric
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             mst[mi][nb][r] += acc[mi][nb][r];
@@ -251,16 +280,17 @@ __global__ __launch_bounds__(256, 1) void k_rbf_fat_apply(const float* __restric
       const bool neg_c = ((jb + mi) & 1) != 0, neg_n = (((blk1 >> 2) + (blk1 & 3)) & 1) != 0;
       if (MFX_FAT_DIAG == 0 && blk == 5 && tl + 2 < ntl) issue_tile_dma(tl + 2);  // (this tile's buffer has been dead since the barrier behind block 4)
       // Invariant at this point: (ahc, alc) hold K_blk except for the table's lag-1 steps (still to run on wc); wn holds the
-      // distances of block blk + 1, untouched; ajs[jb2 & 1] holds the column operand that block blk + 2 needs from slot 10 on.
+      // distances of block blk + 1, untouched; ajs[jb2 & 1] holds the column operand that block blk + 2 needs from its first
+      // distance slot on.
 #pragma unroll
-      for (int slot = 0; slot < 14; ++slot) {
+      for (int slot = 0; slot < kSlots; ++slot) {
         __builtin_amdgcn_sched_barrier(0);
-        if (slot == 10 || slot == 12) {
-          const int q = (slot - 10) / 2;
-          if (q < NKD) dist_step(wd, ajs[jb2 & 1][q], bih[mi2][q], q == 0);
+        if (Plan::dist_q(slot) >= 0) {
+          const int q = Plan::dist_q(slot);
+          dist_step(wd, ajs[jb2 & 1][q], bih[mi2][q], q == 0);
         } else {
-          const int m = slot < 10 ? slot : (slot == 11 ? 10 : 11);
-          const int s = m / 6, nb = (m / 3) % 2, w = m % 3;
+          const int m = Plan::contr_m(slot);
+          const int s = m / (3 * NB), nb = (m / 3) % NB, w = m % 3;
           acc[mi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w == 2 ? alc[s] : ahc[s], w == 1 ? vf[s][nb][1] : vf[s][nb][0],
                                                                acc[mi][nb], 0, 0, 0);
         }
@@ -276,16 +306,15 @@ __global__ __launch_bounds__(256, 1) void k_rbf_fat_apply(const float* __restric
         }
         if (MFX_FAT_DIAG < 3 && mi == 3) {
           // the probe fragments of the next column block roll in behind the last MFMA of this column block that reads the
-          // register they replace: fragment (s, nb, hi) is read by MFMAs 6 s + 3 nb and + 2, (s, nb, lo) by + 1
+          // register they replace: fragment (s, nb, hi) is read by MFMAs 3 NB s + 3 nb and + 2, (s, nb, lo) by + 1
 #pragma unroll
           for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
+            for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
               for (int hl = 0; hl < 2; ++hl) {
-                const int mlast = 6 * s + 3 * nb + (hl ? 1 : 2);
-                const int slast = mlast < 10 ? mlast : (mlast == 10 ? 11 : 13);
-                if (slast == slot) read_v1(vf[s][nb][hl], jb == 1 ? buf ^ 1 : buf, (jb + 1) & 1, s, nb, hl);
+                const int mlast = 3 * NB * s + 3 * nb + (hl ? 1 : 2);
+                if (Plan::slot_of(mlast) == slot) read_v1(vf[s][nb][hl], jb == 1 ? buf ^ 1 : buf, (jb + 1) & 1, s, nb, hl);
               }
         }
       }
@@ -310,7 +339,7 @@ __global__ __launch_bounds__(256, 1) void k_rbf_fat_apply(const float* __restric
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][nb][r] += mst[mi][nb][r];
   const float nz = gridDim.z > 1 ? 0.f : noise[0];
@@ -319,7 +348,7 @@ __global__ __launch_bounds__(256, 1) void k_rbf_fat_apply(const float* __restric
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
+    for (int nb = 0; nb < NB; ++nb) {
       const int64_t b = b0 + nb * 32 + l31;
       if (b >= p) continue;
       const float sb = sc * vscale[2 * b + 1] * (1.f / 32768.f);
@@ -343,35 +372,34 @@ __global__ __launch_bounds__(256, 1) void k_rbf_fat_apply(const float* __restric
     }
 }
 
-int64_t rbf_fat_smem_bytes(int dpad) { return dpad <= 8 ? FatSmem<8>::kTotal : -1; }
-
-template <int DPAD>
-static int fat_launch_d(bool vec4, dim3 grid, hipStream_t stream, const float* xs, const float* sq, int64_t n,
-                        const float* outputscale, const float* noise, const float* vscale, const float* x, int64_t ldx, float* y,
-                        int64_t ldy, int64_t p, const void* pkv, const void* pka, float* part, const int* rangeflag,
-                        int64_t ldpart, int64_t row0, int64_t rend) {
-  constexpr int kSm = FatSmem<DPAD>::kTotal;
-#define MFX_FAT_LAUNCH(V4)                                                                                               \
-  k_rbf_fat_apply<DPAD, V4><<<grid, 256, kSm, stream>>>(xs, sq, n, outputscale, noise, vscale, x, ldx, y, ldy, p,         \
-                                                        static_cast<const uintx4*>(pkv), static_cast<const uintx4*>(pka), \
-                                                        part, rangeflag, ldpart, row0, rend)
+template <int DPAD, int NB>
+static int fat_launch_dn(bool vec4, dim3 grid, hipStream_t stream, const float* xs, const float* sq, int64_t n,
+                         const float* outputscale, const float* noise, const float* vscale, const float* x, int64_t ldx, float* y,
+                         int64_t ldy, int64_t p, const void* pkv, const void* pka, float* part, const int* rangeflag,
+                         int64_t ldpart, int64_t row0, int64_t rend) {
+  constexpr int kSm = FatSmem<DPAD, NB>::kTotal;
+#define MFX_FAT_LAUNCH(V4)                                                                                                   \
+  k_rbf_fat_apply<DPAD, V4, NB><<<grid, 256, kSm, stream>>>(xs, sq, n, outputscale, noise, vscale, x, ldx, y, ldy, p,         \
+                                                            static_cast<const uintx4*>(pkv), static_cast<const uintx4*>(pka), \
+                                                            part, rangeflag, ldpart, row0, rend)
   if (vec4) MFX_FAT_LAUNCH(true); else MFX_FAT_LAUNCH(false);
 #undef MFX_FAT_LAUNCH
   MFX_CHECK_LAUNCH();
   return MFX_OK;
 }
 
-int rbf_fat_launch(int dpad, bool vec4, dim3 grid, hipStream_t stream, const float* xs, const float* sq, int64_t n,
+int rbf_fat_launch(int dpad, int nb, bool vec4, dim3 grid, hipStream_t stream, const float* xs, const float* sq, int64_t n,
                    const float* outputscale, const float* noise, const float* vscale, const float* x, int64_t ldx, float* y,
                    int64_t ldy, int64_t p, const void* pkv, const void* pka, float* part, const int* rangeflag, int64_t ldpart,
                    int64_t row0, int64_t rend) {
 #define MFX_FAT_ARGS vec4, grid, stream, xs, sq, n, outputscale, noise, vscale, x, ldx, y, ldy, p, pkv, pka, part, rangeflag, ldpart, row0, rend
-  switch (dpad) {
-    case 4: return fat_launch_d<4>(MFX_FAT_ARGS);
-    case 8: return fat_launch_d<8>(MFX_FAT_ARGS);
-    default: set_error("fat-wave Gram matvec supports d <= 8"); return MFX_ERR_UNSUPPORTED;
-  }
+  if (dpad == 4 && nb == 1) return fat_launch_dn<4, 1>(MFX_FAT_ARGS);
+  if (dpad == 4 && nb == 2) return fat_launch_dn<4, 2>(MFX_FAT_ARGS);
+  if (dpad == 8 && nb == 1) return fat_launch_dn<8, 1>(MFX_FAT_ARGS);
+  if (dpad == 8 && nb == 2) return fat_launch_dn<8, 2>(MFX_FAT_ARGS);
 #undef MFX_FAT_ARGS
+  set_error("fat-wave Gram matvec supports d <= 8 and chunks of 32 or 64 vectors");
+  return MFX_ERR_UNSUPPORTED;
 }
 
 }  // namespace mfx

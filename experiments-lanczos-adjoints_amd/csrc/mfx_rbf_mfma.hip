@@ -940,8 +940,9 @@ __global__ __launch_bounds__(256) void k_pack_tiles(const float* __restrict__ xs
 // ceil(wgs s / 256) rounds of 1/s of the columns each; pick the s (at most 16, at least 8 tiles per split) that minimises
 // rounds / s, plus a small charge per split for the prologue and the partial sums.  (n = 45 730: 90 row blocks -> s = 8, 720
 // workgroups in 3 rounds = 0.375 of an unsplit launch, where "fill one round" (s = 2) gives 0.5.)
-// Which kernel runs a 33..64-vector chunk of an RBF operator with d <= 8 (BASELINE config 4's matvec): the fat-wave kernel
-// (mfx_rbf_fat.hip: one wave per SIMD, 82 % matrix-pipe share, -16 % cycles against h3).  MFX_RBF_FAT=0 runs the same-program
+// Which kernel runs the chunks (of 64 vectors, or one of at most 32) of an RBF operator with d <= 8 (BASELINE config 4's matvec,
+// config 2's): the fat-wave kernel (mfx_rbf_fat.hip: one wave per SIMD; at 64 vectors 82 % matrix-pipe share, -16 % cycles
+// against h3).  MFX_RBF_FAT=0 runs the same-program
 // kernel k_rbf_mfma_apply_h3 (two waves per SIMD) instead -- the one A/B switch kept, because it reproduces the comparison of
 // DESIGN.md §3.2 and the bit-identity test of the two kernels; h3 also takes every other shape.
 static bool rbf_fat() {
@@ -1031,9 +1032,9 @@ static int launch_apply_h3k(const mfx_operator* op, const float* xs, const float
   }
   if (pack) {
     bool done = false;
-    if constexpr (KIND == MFX_KERNEL_RBF && NB == 2 && DPAD <= 8) {
+    if constexpr (KIND == MFX_KERNEL_RBF && DPAD <= 8) {
       if (rbf_fat()) {  // fat waves (mfx_rbf_fat.hip): four waves of 128 rows, one per SIMD
-        MFX_TRY(rbf_fat_launch(DPAD, vec4, grid_pk, stream, xs, sq, n, (const float*)op->outputscale, (const float*)op->noise, vscale,
+        MFX_TRY(rbf_fat_launch(DPAD, NB, vec4, grid_pk, stream, xs, sq, n, (const float*)op->outputscale, (const float*)op->noise, vscale,
                                x, ldx, y, ldy, p, pkv, pka, part, rangeflag, ldpart, row0, rend));
         done = true;
       }

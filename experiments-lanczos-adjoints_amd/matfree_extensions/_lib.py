@@ -118,10 +118,13 @@ SYMBOLS = {
     "mfx_op_apply": (_I, [_OPP, _P, _I64, _P, _I64, _I64, _I, _P, _I64, _P]),
     "mfx_op_vjp_params": (_I, [_OPP, _P, _I64, _P, _I64, _I64, _GRP, _P, _I64, _P]),
     "mfx_arnoldi_forward": (_I, [_OPP, _P, _I64, _I64, _I64, _I, _P, _P, _P, _P, _P, _I64, _P]),
+    "mfx_complex_workspace_bytes": (_I64, [_OPP, _I64, _I64, _I64]),
+    "mfx_arnoldi_forward_complex": (_I, [_OPP, _P, _I64, _I64, _I64, _I, _P, _P, _P, _P, _P, _I64, _P]),
     "mfx_arnoldi_adjoint": (
         _I,
         [_OPP, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _GRP, _P, _I64, _P],
     ),
+    "mfx_rccl_available": (_I, []),
     "mfx_rccl_unique_id": (_I, [_P, _I64]),
     "mfx_comm_create_rccl": (_I, [_P, _I64, C.c_int32, C.c_int32, _I64, _CMP]),
     "mfx_comm_destroy_rccl": (_I, [_CMP]),

@@ -13,7 +13,11 @@ replaces ``jax.vmap`` over probes, hutchinson.py:14).
 Differences from the reference, all deliberate:
   * parameters must be explicit tensors (no closure conversion, arnoldi.py:22): pass a native
     operator (``operators.DenseOp`` ...) or any callable ``matvec(v, *params)``;
-  * real float32/float64 only (complex Arnoldi forward, test_hessenberg_forward.py, is out of scope);
+  * complex start vectors (tests/test_arnoldi/test_hessenberg_forward.py:10-37) run the FORWARD only
+    (``mfx_arnoldi_forward_complex``): a complex Krylov vector takes two real basis slots (q, i q), the operator acts on
+    interleaved (re, im) reals -- a complex ``DenseOp`` as its (2n, 2n) real form on the native dense kernel, any other
+    callable through the callback operator.  The adjoint is real float32/float64 only (the reference's is not exercised
+    on complex input either);
   * ``custom_vjp=False`` is the reference's baseline, back-propagation THROUGH the loop: the recurrence then runs as
     differentiable torch ops around the HIP operator (``_autodiff.py``) -- slow and memory-hungry by construction.
 Reference quirk Q1 is reproduced: the forward pass re-orthogonalises unless ``reortho_vjp="none"``
@@ -27,7 +31,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .operators import CallbackOp, RowShardedOp, _PtrRegistry, as_operator
+from .operators import CallbackOp, DenseOp, RowShardedOp, _PtrRegistry, as_operator
 
 
 def hessenberg(
@@ -51,6 +55,15 @@ def hessenberg(
         batched = v.dim() == 2
         V = v if batched else v[None]
         sharded = isinstance(op, RowShardedOp)
+        if V.is_complex():
+            if sharded:
+                raise NotImplementedError("complex Arnoldi on a row-sharded operator")
+            if torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in (V, *params)):
+                raise NotImplementedError("complex Arnoldi is forward only: detach the inputs (the adjoint system is real)")
+            second_pass = (reortho_vjp if reortho_vjp != "match" else reortho_vjp) != "none"  # Q1, as below
+            Qkn, H, r, c = _complex_forward(op, int(krylov_depth), second_pass, V, params)
+            Q = Qkn.transpose(-1, -2)
+            return (Q, H, r, c) if batched else (Q[0], H[0], r[0], c[0])
         n = op.comm.n if sharded else V.shape[-1]
         if sharded and V.shape[-1] != op.comm.nrows:
             raise ValueError(f"row-sharded operator: expected this rank's {op.comm.nrows} rows of the start vector, got {V.shape[-1]}")
@@ -77,6 +90,52 @@ def hessenberg(
         return Q, H, r, c
 
     return estimate
+
+
+def _complex_forward(op, k, second_pass, V, params):
+    """Complex forward (arnoldi.py:57-101 with its conjugations): the operator in its real form on interleaved vectors."""
+    lib = _lib.get()
+    V = V.contiguous()
+    p, n = V.shape
+    if k < 1 or k > n:
+        raise ValueError(f"Parameter depth {k} is outside the expected range")
+    cdt, dev = V.dtype, V.device
+    rdt = torch.float32 if cdt == torch.complex64 else torch.float64
+    _lib.require_device(V)
+    keep = None
+    if isinstance(op, DenseOp):  # native dense kernel on the (2n, 2n) real form [[Re, -Im], [Im, Re]] per entry
+        (A,) = op.constrain(*params)
+        A = A.to(cdt)
+        M = torch.stack([torch.stack([A.real, -A.imag], -1), torch.stack([A.imag, A.real], -1)], 1).reshape(2 * n, 2 * n)
+        desc = op.descriptor((M.contiguous(),), rdt, 2 * n)
+        hold = M
+    else:
+        fn = op.fn if isinstance(op, CallbackOp) else op
+
+        def real_form(x, *ps):  # x: (2n,) reals = n interleaved complex entries
+            y = fn(torch.view_as_complex(x.view(n, 2)), *ps)
+            return torch.view_as_real(y.to(cdt).contiguous()).reshape(2 * n)
+
+        reg = _PtrRegistry()
+        desc, keep, _ = CallbackOp(real_form).make(tuple(params), rdt, 2 * n, reg, want_grads=False)
+        hold = None
+    Q = torch.empty((p, k, n), dtype=cdt, device=dev)
+    H = torch.empty((p, k, k), dtype=cdt, device=dev)
+    r = torch.empty((p, n), dtype=cdt, device=dev)
+    c = torch.empty((p,), dtype=cdt, device=dev)
+    ws = _lib.scratch(int(lib.mfx_complex_workspace_bytes(C.byref(desc), n, k, p)), dev)
+    if keep is not None:
+        for t in (V, Q, r):
+            reg.add(torch.view_as_real(t))
+        reg.add_bytes(ws, rdt)
+    with _lib.busy(ws):
+        rc = lib.mfx_arnoldi_forward_complex(C.byref(desc), _lib.ptr(V), n, k, p, int(second_pass), _lib.ptr(Q), _lib.ptr(H),
+                                             _lib.ptr(r), _lib.ptr(c), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+    if keep is not None and keep[1]:
+        raise keep[1][0]
+    _lib.check(rc)
+    del hold
+    return Q, H, r, c
 
 
 class _ArnoldiFn(torch.autograd.Function):

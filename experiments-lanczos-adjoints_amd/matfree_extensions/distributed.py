@@ -283,6 +283,18 @@ class NativeRowComm(RowComm):
             return super().struct(ws, tensors, plans)
         return self._cm, (None, None, [], None)
 
+    def self_test(self) -> bool:
+        """One all-reduce and one grouped row all-gather through the native function pointers, checked on this rank."""
+        dev = torch.device("cuda", torch.cuda.current_device())
+        stream = _lib.stream_ptr(dev)
+        ones = torch.ones(8, dtype=torch.float64, device=dev)
+        rc = self._cm.allreduce_sum(self._cm.ctx, ones.data_ptr(), ones.numel(), _lib.MFX_F64, stream)
+        local = torch.full((2, 4), float(self.rank + 1), dtype=torch.float32, device=dev)
+        full = torch.zeros((2, 4 * self.world), dtype=torch.float32, device=dev)
+        rc |= self._cm.allgather_rows(self._cm.ctx, local.data_ptr(), 4, full.data_ptr(), 4 * self.world, 2, 4, _lib.MFX_F32, stream)
+        want = torch.arange(1, self.world + 1, dtype=torch.float32, device=dev).repeat_interleave(4).expand(2, -1)
+        return rc == 0 and bool((ones == self.world).all()) and bool((full == want).all())
+
     def close(self):
         if getattr(self, "_cm", None) is not None:
             _lib.get().mfx_comm_destroy_rccl(C.byref(self._cm))
@@ -293,6 +305,47 @@ class NativeRowComm(RowComm):
             self.close()
         except Exception:
             pass
+
+
+def _all_ranks(ok: bool, group) -> bool:
+    """True when ``ok`` holds on every rank of ``group`` (the ranks must take the same branch afterwards)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(flag.item())
+
+
+def _native_or_callbacks(n: int, group):
+    """The default on an RCCL process group: libmfx's native communicator, and if ANY rank of the group cannot bind librccl,
+    fails to create the communicator or gets a wrong answer from its self-test, every rank falls back to the
+    torch.distributed callbacks (the same RCCL underneath, the same results) and says so on stderr.  Each decision is taken
+    by all ranks together, so the group never splits between the two paths."""
+    import warnings
+
+    why = None
+    if not _all_ranks(bool(_lib.get().mfx_rccl_available()), group):
+        why = "librccl could not be bound on every rank"
+    else:
+        comm, err = None, None
+        try:
+            comm = NativeRowComm(n, group)
+        except Exception as e:  # noqa: BLE001 -- any failure of the collective creation takes the fallback
+            err = e
+        if not _all_ranks(comm is not None, group):
+            why = f"communicator creation failed ({err})"
+        else:
+            try:
+                ok = comm.self_test()
+            except Exception as e:  # noqa: BLE001
+                ok, err = False, e
+            if _all_ranks(ok, group):
+                return comm
+            why = f"self-test of the native collectives failed ({err})"
+        if comm is not None:
+            comm.close()
+    warnings.warn(f"matfree_extensions.distributed: native RCCL row-group collectives unavailable -- {why}; "
+                  "using the torch.distributed callbacks", RuntimeWarning, stacklevel=3)
+    return RowComm(n, group)
 
 
 class _ShardedSumSq(torch.autograd.Function):
@@ -381,8 +434,10 @@ class Layout:
             if native is None:
                 # MFX_NATIVE_COMM=0: operational escape hatch back to the torch.distributed callbacks (same results)
                 native = on and dist.get_backend(row_group) == "nccl" and os.environ.get("MFX_NATIVE_COMM", "1") != "0"
-            self.comm = NativeRowComm(n, row_group) if native else RowComm(n, row_group)
-            self.native = bool(native)
+                self.comm = _native_or_callbacks(n, row_group) if native else RowComm(n, row_group)
+            else:  # asked for explicitly: no way back
+                self.comm = NativeRowComm(n, row_group) if native else RowComm(n, row_group)
+            self.native = isinstance(self.comm, NativeRowComm)
         else:
             self.comm, self.probe_index, self.probe_groups = None, rank, self.world
             self.native = False

@@ -159,6 +159,20 @@ int mfx_arnoldi_forward(const mfx_operator* op, const void* v0, int64_t n, int64
                         int second_pass, void* Q, void* H, void* r, void* c, void* ws,
                         int64_t ws_bytes, void* stream);
 
+/* arnoldi._forward for COMPLEX vectors (arnoldi.py:57-101 with its .conj() at :66,87,92,95; the case
+ * tests/test_arnoldi/test_hessenberg_forward.py:10-37 runs with dtype=complex).  Forward only -- the reference's adjoint is not
+ * exercised on complex input either.  All buffers are interleaved (re, im) pairs of the operator's REAL dtype:
+ *   v0 (p, n) complex -> Q (p, k, n) complex [= reference Q^T, un-conjugated], H (p, k, k) complex row-major,
+ *   r (p, n) complex, c (p) complex (= 1/|v0| + 0 i).
+ * `op` is the complex-linear map in its real form: op->n = 2 n, acting on the interleaved vector (a dense complex A becomes the
+ * (2 n, 2 n) matrix of 2 x 2 blocks [[Re, -Im], [Im, Re]]; a CALLBACK sees 2 n reals per vector).  The recurrence runs on the
+ * real kernels of mfx_arnoldi_forward with two basis slots (q, i q) per complex Krylov vector.
+ * Workspace: mfx_complex_workspace_bytes(op, n, k, p). */
+int64_t mfx_complex_workspace_bytes(const mfx_operator* op, int64_t n, int64_t k, int64_t p);
+int mfx_arnoldi_forward_complex(const mfx_operator* op, const void* v0, int64_t n, int64_t k, int64_t p,
+                                int second_pass, void* Q, void* H, void* r, void* c, void* ws,
+                                int64_t ws_bytes, void* stream);
+
 /* arnoldi._adjoint (arnoldi.py:104-220).  Cotangents: dQ (p, k, n) or NULL (= 0), dH (p, k, k),
  * dr (p, n) or NULL, dc (p) or NULL.  Outputs dv (p, n); parameter gradients accumulated into
  * `grads` (native operators: one deferred sweep; CALLBACK: inside the callback, per step).
@@ -246,10 +260,13 @@ typedef struct mfx_comm {
  * ncclAllGather (RCCL over xGMI) themselves, on the stream of the driver call -- no host-language callback on the path
  * (round 2 went libmfx -> ctypes -> torch.distributed, ~280 callbacks per SLQ step).  RCCL is loaded at run time
  * (dlopen "librccl.so.1"); MFX_ERR_UNSUPPORTED when it is not there.
+ *   mfx_rccl_available   : 1 when librccl and the entry points used here could be bound in this process, else 0 (no GPU call;
+ *                          lets every rank of a group agree on native vs. callback collectives BEFORE the collective creation);
  *   mfx_rccl_unique_id   : one rank makes the id (ncclGetUniqueId; id: >= 128 bytes of host memory) and hands it to the others
  *                          by any means (matfree_extensions/distributed.py broadcasts it with torch.distributed);
  *   mfx_comm_create_rccl : COLLECTIVE over the `world` ranks (ncclCommInitRank on the calling thread's current device);
  *   mfx_comm_destroy_rccl: releases the communicator (a no-op for an mfx_comm the caller filled in itself). */
+int mfx_rccl_available(void);
 int mfx_rccl_unique_id(void* id, int64_t bytes);
 int mfx_comm_create_rccl(const void* id, int64_t bytes, int32_t rank, int32_t world, int64_t nloc, mfx_comm* out);
 int mfx_comm_destroy_rccl(mfx_comm* comm);

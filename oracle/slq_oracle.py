@@ -236,7 +236,8 @@ def arnoldi_forward(op, k, v, *params, reortho="full", reortho_vjp="match"):
     """Returns Q (n,k), H (k,k), r (n,) un-normalised, c = 1/|v|.
 
     Classical Gram-Schmidt against all (zero-padded) columns, optional second pass whose
-    coefficients are NOT added to h (arnoldi.py:87-92).
+    coefficients are NOT added to h (arnoldi.py:87-92).  Complex v: the conjugations of arnoldi.py:66,87,92,95
+    (identity on real input; the lengths then carry a zero imaginary part, as in the reference).
     """
     if reortho not in ("none", "full"):
         raise TypeError(f"Unexpected input for {reortho}: either of ['none', 'full'] expected.")
@@ -248,18 +249,18 @@ def arnoldi_forward(op, k, v, *params, reortho="full", reortho_vjp="match"):
     second_pass = reortho_vjp != "none"
     Q = np.zeros((n, k), dtype=v.dtype)
     H = np.zeros((k, k), dtype=v.dtype)
-    length0 = np.sqrt(v @ v)
+    length0 = np.sqrt(np.vdot(v, v))
     length = length0
     w = v
     for i in range(k):
         q = w / length
         Q[:, i] = q
         w = op.apply(q, *params)
-        h = Q.T @ w
+        h = Q.conj().T @ w
         w = w - Q @ h
         if second_pass:
-            w = w - Q @ (Q.T @ w)
-        length = np.sqrt(w @ w)
+            w = w - Q @ (Q.conj().T @ w)
+        length = np.sqrt(np.vdot(w, w))
         if i + 1 < k:  # Q2 (arnoldi.py:98): the out-of-range write at i = k-1 is dropped
             h[i + 1] = length
         H[:, i] = h

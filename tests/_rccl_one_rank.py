@@ -58,6 +58,24 @@ def main():
     print("native communicator: values", v2[:3].tolist(), "bit-identical to the callback path:", same)
     ok = ok and same
     ncomm.close()
+    # what Layout does by default on an RCCL group: native communicator after an agreed availability check and self-test; when the
+    # self-test (here: made to) fails on a rank, ALL ranks take the torch.distributed callbacks, with a warning
+    import warnings
+
+    from matfree_extensions import distributed as D
+
+    c1 = D._native_or_callbacks(n, None)
+    agreed = isinstance(c1, NativeRowComm) and c1.self_test()
+    c1.close()
+    real = NativeRowComm.self_test
+    NativeRowComm.self_test = lambda self: False
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        c2 = D._native_or_callbacks(n, None)
+    NativeRowComm.self_test = real
+    fell_back = type(c2) is RowComm and any("native RCCL" in str(x.message) for x in w)
+    print("default path: native after self-test:", agreed, "; fallback when a self-test fails:", fell_back)
+    ok = ok and agreed and fell_back
     dist.destroy_process_group()
     return 0 if ok else 1
 

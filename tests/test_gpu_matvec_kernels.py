@@ -1,6 +1,7 @@
-"""The matrix-core Gram matvec kernels for 33..64-vector chunks against the fp64 NumPy oracle: the fat-wave kernel
-(`k_rbf_fat_apply`, csrc/mfx_rbf_fat.hip: the default for RBF with d <= 8 -- BASELINE config 4's matvec) and the same-program
-kernel `k_rbf_mfma_apply_h3` (every other shape, and MFX_RBF_FAT=0).
+"""The matrix-core Gram matvec kernels against the fp64 NumPy oracle: the fat-wave kernel (`k_rbf_fat_apply`,
+csrc/mfx_rbf_fat.hip: the default for RBF with d <= 8 -- BASELINE config 4's matvec -- in its two forms, chunks of 64 vectors and,
+for at most 32 vectors, one 32-probe block) and the same-program kernel `k_rbf_mfma_apply_h3` (every other shape, and
+MFX_RBF_FAT=0).
 
 What is specific to these kernels and therefore tested here: two probe chunks with a ragged second one, ragged n (last tile and
 last row block), row blocks that start inside a workgroup, column splits (small n) and the unsplit sweep with chain folds (more
@@ -48,7 +49,8 @@ def _rel_err_rows(y, ref):
 
 @pytest.mark.parametrize("kernel", ["rbf", "matern32", "matern12"])
 @pytest.mark.parametrize("n,d,p,ard", [(1000, 8, 64, False), (2341, 3, 33, True), (5000, 11, 100, True), (4096, 8, 64, True),
-                                       (777, 12, 40, False)])
+                                       (777, 12, 40, False), (1000, 8, 32, False), (2341, 3, 7, True), (4096, 5, 20, True),
+                                       (3000, 8, 1, False), (5000, 4, 3, True)])
 def test_pc_matvec_against_the_oracle(kernel, n, d, p, ard):
     o, op, raw, params, V = _setup(n, d, p, kernel, ard, seed=n + p)
     y = op(torch.tensor(V, dtype=torch.float32, device=DEV), *params)
@@ -66,11 +68,12 @@ def _apply_block(op, cparams, V, row0, nrows):
     return y
 
 
+@pytest.mark.parametrize("p", [64, 20])
 @pytest.mark.parametrize("kernel", ["rbf", "matern32"])
-def test_pc_matvec_row_blocks(kernel):
+def test_pc_matvec_row_blocks(kernel, p):
     """Row blocks (the row-sharded layout, util/gp_util.py:496-509): starts on multiples of 64 inside a 256-row workgroup,
     ragged ends, a block shorter than one wave's 64 rows."""
-    n, d, p = 3000, 8, 64
+    n, d = 3000, 8
     o, op, raw, params, V = _setup(n, d, p, kernel, True, seed=5)
     ref = o.apply(V, *raw)
     Vt = torch.tensor(V, dtype=torch.float32, device=DEV)
@@ -88,8 +91,8 @@ sys.path.insert(0, {tests!r})
 sys.path.insert(0, {root!r})
 sys.path.insert(0, {pkg!r})
 import test_gpu_matvec_kernels as t
-n, d, p = 20000, 8, 64      # 313 tiles in ONE sweep: two chain folds
-for kernel in ("rbf", "matern32"):
+n, d = 20000, 8             # 313 tiles in ONE sweep: two chain folds
+for kernel, p in (("rbf", 64), ("matern32", 64), ("rbf", 24)):
     o, op, raw, params, V = t._setup(n, d, p, kernel, True, seed=11)
     # smooth positive vectors: the accumulators grow monotonically, which is what the chain folds are for
     V[:8] = np.abs(V[:8])
@@ -97,7 +100,7 @@ for kernel in ("rbf", "matern32"):
     err = t._rel_err_rows(y, o.apply(V, *raw))
     print(kernel, "err", err)
     assert err < 3e-5, err
-    np.save({out!r} + "_" + kernel + ".npy", y.cpu().numpy())
+    np.save({out!r} + "_" + kernel + str(p) + ".npy", y.cpu().numpy())
 print("child ok")
 """
 
@@ -116,7 +119,7 @@ def _run_child(tmp_path, tag, **env_over):
 def test_unsplit_sweep_with_chain_folds_and_bit_identity_of_the_two_kernels(tmp_path):
     fat = _run_child(tmp_path, "fat", MFX_RBF_SPLIT="1", MFX_RBF_FAT="1")
     h3 = _run_child(tmp_path, "h3", MFX_RBF_SPLIT="1", MFX_RBF_FAT="0")
-    for kernel in ("rbf", "matern32"):
+    for kernel in ("rbf64", "matern3264", "rbf24"):
         # the fat-wave kernel keeps the order of every sum of the same-program kernel (blocks, k-steps, products, chain folds):
         # bit-identical, so the accuracy tables of profiles/r02a_accuracy carry over (Matern: the child runs h3 both times)
         assert np.array_equal(np.load(fat + "_" + kernel + ".npy"), np.load(h3 + "_" + kernel + ".npy")), kernel
@@ -130,14 +133,16 @@ def test_every_parity_case_on_the_same_program_kernel():
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]
 
 
-def test_every_block_position_of_a_tile():
-    """Unit vectors: K[i][j] itself, for the 64 columns of one tile at a time -- every (column block, row block) position of the
-    fat kernel's block pipeline (the blocks whose distances are computed across the mid-tile barrier included), first, middle and last tile."""
-    n, d, p = 1536, 8, 64
+@pytest.mark.parametrize("p", [64, 32])
+def test_every_block_position_of_a_tile(p):
+    """Unit vectors: K[i][j] itself, for the columns of one tile at a time -- every (column block, row block) position of the fat
+    kernel's block pipeline (the blocks whose distances are computed across the mid-tile barrier included), first, middle and last
+    tile; with 32 vectors (the one-probe-block form) one column block of the tile at a time."""
+    n, d = 1536, 8
     o, op, raw, params, _ = _setup(n, d, p, "rbf", False, seed=3)
-    for tile in (0, 1, 11, n // 64 - 1):
+    for tile, half in [(t, h) for t in (0, 1, 11, n // 64 - 1) for h in range(64 // p)]:
         E = np.zeros((p, n))
-        E[np.arange(64), tile * 64 + np.arange(64)] = 1.0
+        E[np.arange(p), tile * 64 + half * p + np.arange(p)] = 1.0
         y = op(torch.tensor(E, dtype=torch.float32, device=DEV), *params).cpu().numpy().astype(np.float64)
         ref = o.apply(E, *raw)
-        assert np.abs(y - ref).max() < 3e-6 * np.abs(ref).max(), (tile, np.abs(y - ref).max())
+        assert np.abs(y - ref).max() < 3e-6 * np.abs(ref).max(), (tile, half, np.abs(y - ref).max())

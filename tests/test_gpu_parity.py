@@ -186,6 +186,51 @@ def test_hessenberg_forward_identities_and_oracle(dtype, tol, k, reortho):
     assert close(c, co, tol)
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.complex128, 1e-10), (torch.complex64, 1e-4)])
+@pytest.mark.parametrize("k", [1, 5, 10])
+@pytest.mark.parametrize("reortho", ["none", "full"])
+@pytest.mark.parametrize("kind", ["native", "callable"])
+def test_hessenberg_forward_complex(dtype, tol, k, reortho, kind):
+    """tests/test_arnoldi/test_hessenberg_forward.py:10-37 with dtype=complex: the decomposition identities and the oracle; the
+    dense operator on the native kernel (real form of the complex matrix) and the reference's own `lambda s, p: p @ s`."""
+    n = 10
+    rng = np.random.default_rng(1)
+    A = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    v = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    matvec = DenseOp() if kind == "native" else (lambda s, p: p @ s)
+    At, vt = torch.tensor(A, dtype=dtype, device=DEV), torch.tensor(v, dtype=dtype, device=DEV)
+    Q, H, r, c = arnoldi.hessenberg(matvec, k, reortho=reortho)(vt, At)
+    assert Q.shape == (n, k) and H.shape == (k, k) and r.shape == (n,) and c.shape == ()
+    assert Q.dtype == H.dtype == r.dtype == c.dtype == dtype
+    Qn, Hn, rn, cn = (t.cpu().numpy().astype(np.complex128) for t in (Q, H, r, c))
+    eK = np.eye(k)[-1]
+    assert np.allclose(A @ Qn - Qn @ Hn - np.outer(rn, eK), 0.0, atol=tol * 10)
+    assert np.allclose(Qn.T.conj() @ Qn, np.eye(k), atol=tol * 10)
+    assert np.allclose(Qn[:, 0], cn * v, atol=tol)
+    Qo, Ho, ro, co = orc.arnoldi_forward(orc.DenseOp(), k, v, A, reortho=reortho)
+    assert np.allclose(Qn, Qo, atol=tol * 10) and np.allclose(Hn, Ho, atol=tol * 10 * np.abs(Ho).max())
+    assert np.allclose(rn, ro, atol=tol * 100) and np.allclose(cn, co, atol=tol)
+
+
+def test_hessenberg_complex_batched_larger_and_limits():
+    """A batch of complex start vectors at a size where the vector kernels run several slices; forward only."""
+    n, k, p = 3000, 12, 3
+    rng = np.random.default_rng(2)
+    A = (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))) / np.sqrt(n)
+    V = rng.standard_normal((p, n)) + 1j * rng.standard_normal((p, n))
+    At, Vt = torch.tensor(A, dtype=torch.complex128, device=DEV), torch.tensor(V, dtype=torch.complex128, device=DEV)
+    Q, H, r, c = arnoldi.hessenberg(DenseOp(), k, reortho="full")(Vt, At)
+    assert Q.shape == (p, n, k) and H.shape == (p, k, k) and r.shape == (p, n) and c.shape == (p,)
+    for b in range(p):
+        Qo, Ho, ro, co = orc.arnoldi_forward(orc.DenseOp(), k, V[b], A, reortho="full")
+        assert np.allclose(Q[b].cpu().numpy(), Qo, atol=1e-10) and np.allclose(H[b].cpu().numpy(), Ho, atol=1e-10)
+        assert np.allclose(r[b].cpu().numpy(), ro, atol=1e-10) and np.allclose(c[b].cpu().numpy(), co, atol=1e-12)
+    with pytest.raises(NotImplementedError, match="forward only"):
+        arnoldi.hessenberg(DenseOp(), k, reortho="full")(Vt, At.clone().requires_grad_(True))
+    with pytest.raises(ValueError, match="depth"):
+        arnoldi.hessenberg(DenseOp(), n + 1, reortho="full")(Vt[0], At)
+
+
 def test_hessenberg_batched_callable_and_errors():
     n, k = 12, 4
     rng = np.random.default_rng(5)

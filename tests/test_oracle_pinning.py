@@ -71,6 +71,24 @@ def test_hessenberg_decomposition(k, reortho, which):
     assert np.allclose(Q[:, 0], c * v, atol=tol)
 
 
+# test_arnoldi/test_hessenberg_forward.py:10-37 with dtype=complex
+@pytest.mark.parametrize("k", [1, 5, 10])
+@pytest.mark.parametrize("reortho", ["none", "full"])
+def test_hessenberg_decomposition_complex(k, reortho):
+    n = 10
+    rng = np.random.default_rng(1)
+    A = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    v = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    Q, H, r, c = orc.arnoldi_forward(orc.DenseOp(), k, v, A, reortho=reortho)
+    assert Q.shape == (n, k) and H.shape == (k, k) and r.shape == (n,) and np.shape(c) == ()
+    assert Q.dtype == H.dtype == r.dtype == np.complex128
+    tol = np.sqrt(np.finfo(np.float64).eps)
+    eK = np.eye(k)[-1]
+    assert np.allclose(A @ Q - Q @ H - np.outer(r, eK), 0.0, atol=tol)
+    assert np.allclose(Q.T.conj() @ Q, np.eye(k), atol=tol)
+    assert np.allclose(Q[:, 0], c * v, atol=tol)
+
+
 # test_arnoldi/test_hessenberg_forward.py:69-84, test_hessenberg_adjoint.py:107-113
 def test_error_conventions():
     v = np.ones(4)

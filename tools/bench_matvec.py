@@ -11,7 +11,7 @@ for d in (3, 8):
     for kernel in ("rbf", "matern32"):
         op = RbfGramOp(X, noise_minval=1e-4, kernel=kernel)
         params = [torch.zeros((), device=dev) for _ in range(3)]
-        for p in (1, 2, 3, 4, 8, 16, 64):
+        for p in (1, 2, 4, 8, 16, 32, 64):
             v = torch.randn(p, n, device=dev)
             with torch.no_grad():
                 op(v, *params)
