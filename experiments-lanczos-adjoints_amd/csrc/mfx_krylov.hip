@@ -485,7 +485,7 @@ static int64_t carve_ws(const mfx_operator* op, int64_t n, int64_t k, int64_t p,
   const int64_t cb = dq_batch_cols(n, k, p, comm);
   r.pb = cb > 1 ? cv.take(cb * p * kmax * nblk * es) : nullptr;
   if (comm) {
-    r.stage = cv.take(p * kmax * nblk * es);                 // producers' per-slice partials before the all-reduce
+    r.stage = cv.take(p * (kmax > 3 ? kmax : 3) * nblk * es);  // producers' per-slice partials before the all-reduce (3: the three-term adjoint's dots)
     r.send = cv.take(p * comm->nloc * es);                   // this rank's (p, nloc) iterate, zero padded
     r.gathered = cv.take(comm->world * p * comm->nloc * es); // (world, p, nloc)
     r.xfull = cv.take(p * op->n * es);                       // the full iterate (p, n) (adjoint; the forward writes Qfull)
@@ -845,11 +845,15 @@ static int arnoldi_adjoint_t(const mfx_operator* op, int64_t n, int64_t k, int64
   return MFX_OK;
 }
 
+// comm != NULL: row-sharded (n = rows of this rank; every x_i is gathered into the scratch ws.xfull for the operator)
 template <typename T>
 static int lanczos_forward_t(const mfx_operator* op, const T* v0, int64_t n, int64_t k, int64_t p, T* xs,
-                             T* alpha, T* beta, T* vnorm, const KrylovWs& ws, hipStream_t stream) {
+                             T* alpha, T* beta, T* vnorm, const KrylovWs& ws, hipStream_t stream,
+                             const mfx_comm* comm = nullptr) {
   Ctx<T> c(n, k, p, pick_vec<T>(n, {v0, xs, ws.w}), stream);
+  if (comm) c.shard(comm, static_cast<T*>(ws.stage));
   c.fine();
+  const int64_t prow = comm ? 1 : c.nblk;  // stride of a coefficient row in the partials (sharded: already summed)
   T* P1 = static_cast<T*>(ws.p1);
   T* P2 = static_cast<T*>(ws.p2);
   T* PN = static_cast<T*>(ws.pn);
@@ -877,7 +881,7 @@ static int lanczos_forward_t(const mfx_operator* op, const T* v0, int64_t n, int
       w = (i & 1) ? w0 + p * n : w0;
       CsrStepArgs<T> cs{};
       cs.y = w; cs.ldy = n;
-      cs.rows = xs + i * n; cs.rows_ldb = ldx; cs.row_stride = n; cs.m = 1; cs.partial = P + (m - 1) * c.nblk;
+      cs.rows = xs + i * n; cs.rows_ldb = ldx; cs.row_stride = n; cs.m = 1; cs.partial = P + (m - 1) * prow;
       if (i == 0) {
         cs.x = xs; cs.ldx = ldx;
         MFX_TRY(launch_csr_step<T>(c, op, 0, cs, false, true));
@@ -886,11 +890,13 @@ static int lanczos_forward_t(const mfx_operator* op, const T* v0, int64_t n, int
         cs.partial_norm = PN; cs.qout = xs + i * n; cs.ldq = ldx; cs.len_out = beta + (i - 1); cs.len_ld = k;
         MFX_TRY(launch_csr_step<T>(c, op, 0, cs, true, true));
       }
+    } else if (comm) {
+      MFX_TRY(apply_sharded<T>(op, comm, 0, xs + i * n, ldx, w, n, p, static_cast<T*>(ws.xfull), op->n, ws, stream));
     } else {
       MFX_TRY(apply_any(op, 0, xs + i * n, ldx, nullptr, 0, w, n, p, ws.opws, ws.opws_bytes, stream));
     }
     ScopedTimer t(2, stream);
-    if (!fused) MFX_TRY(launch_dots<T>(c, xs + i * n, ldx, n, 1, w, n, P + (m - 1) * c.nblk));  // a = x_i . A x_i
+    if (!fused) MFX_TRY(launch_dots<T>(c, xs + i * n, ldx, n, 1, w, n, P + (m - 1) * prow));  // a = x_i . A x_i
     UpdateArgs<T> a{};
     a.rows = xs + (i == 0 ? 0 : (i - 1) * n); a.rows_ldb = ldx; a.row_stride = n; a.m = m;
     a.partial_in = P; a.s1 = T(1);
@@ -903,11 +909,15 @@ static int lanczos_forward_t(const mfx_operator* op, const T* v0, int64_t n, int
   return MFX_OK;
 }
 
+// comm != NULL: row-sharded; Lamfull (p, k, op->n) receives the gathered adjoint states (the operator input of every step and
+// the right factor of the parameter-gradient sweep)
 template <typename T>
 static int lanczos_adjoint_t(const mfx_operator* op, int64_t n, int64_t k, int64_t p, const T* xs, const T* alpha,
                              const T* beta, const T* vnorm, const T* dxs, const T* dalpha, const T* dbeta, T* dv,
-                             T* Lam, const mfx_op_grads* grads, const KrylovWs& ws, hipStream_t stream) {
+                             T* Lam, const mfx_op_grads* grads, const KrylovWs& ws, hipStream_t stream,
+                             const mfx_comm* comm = nullptr, T* Lamfull = nullptr) {
   Ctx<T> c(n, k, p, pick_vec<T>(n, {xs, dxs, dv, Lam, ws.w}), stream);
+  if (comm) c.shard(comm, static_cast<T*>(ws.stage));
   T* P1 = static_cast<T*>(ws.p1);
   T* PN = static_cast<T*>(ws.pn);
   T* xi = static_cast<T*>(ws.w);
@@ -927,14 +937,19 @@ static int lanczos_adjoint_t(const mfx_operator* op, int64_t n, int64_t k, int64
     T* lam_j = Lam + j * n;
     {
       ScopedTimer t(2, stream);
-      MFX_VEC_SWITCH(c.vec, (k_lz_adj_dots<T, VEC><<<c.grid(), c.wg, 0, stream>>>(xj, xj1, ldx, xi, lam_plus, ldl, n, PN, c.nblk)));
+      MFX_VEC_SWITCH(c.vec, (k_lz_adj_dots<T, VEC><<<c.grid(), c.wg, 0, stream>>>(xj, xj1, ldx, xi, lam_plus, ldl, n, c.producer(PN), c.nblk)));
       MFX_CHECK_LAUNCH();
+      MFX_TRY(c.finish(PN, 3, 3));
       MFX_VEC_SWITCH(c.vec, (k_lz_adj_lambda<T, VEC><<<c.grid(), c.wg, 0, stream>>>(
-                                xj, xj1, ldx, xi, n, PN, c.nblk, beta, dalpha, dbeta, (int)k, (int)j, lam_j, ldl, munu)));
+                                xj, xj1, ldx, xi, n, PN, c.nblk_in, beta, dalpha, dbeta, (int)k, (int)j, lam_j, ldl, munu)));
       MFX_CHECK_LAUNCH();
     }
     // A lambda (Q4: not A^T), parameter gradient of x_j^T A(theta) lambda (lanczos.py:328-329)
-    MFX_TRY(apply_any(op, 2, lam_j, ldl, xj, ldx, y, n, p, ws.opws, ws.opws_bytes, stream));
+    if (comm) {
+      MFX_TRY(apply_sharded<T>(op, comm, 0, lam_j, ldl, y, n, p, Lamfull + j * op->n, k * op->n, ws, stream));
+    } else {
+      MFX_TRY(apply_any(op, 2, lam_j, ldl, xj, ldx, y, n, p, ws.opws, ws.opws_bytes, stream));
+    }
     ScopedTimer t(2, stream);
     MFX_VEC_SWITCH(c.vec, (k_lz_adj_xi<T, VEC><<<c.grid(), c.wg, 0, stream>>>(
                               dxs ? dxs + j * n : nullptr, ldx, y, lam_j, ldl, lam_plus, ldl, xj1, ldx, n, alpha, beta,
@@ -944,14 +959,22 @@ static int lanczos_adjoint_t(const mfx_operator* op, int64_t n, int64_t k, int64
   {
     ScopedTimer t(2, stream);
     MFX_TRY(launch_dots<T>(c, xs, ldx, n, 1, xi, n, P1));  // xi . x_0 (Q3: "lambda_1" is the final xi)
-    MFX_VEC_SWITCH(c.vec, (k_lz_adj_dvec<T, VEC><<<c.grid(), c.wg, 0, stream>>>(xs, ldx, xi, n, P1, c.kmax, c.nblk, vnorm, dv)));
+    MFX_VEC_SWITCH(c.vec, (k_lz_adj_dvec<T, VEC><<<c.grid(), c.wg, 0, stream>>>(xs, ldx, xi, n, P1, c.kmax, c.nblk_in, vnorm, dv)));
     MFX_CHECK_LAUNCH();
   }
   if (op->kind != MFX_OP_CALLBACK && grads) {
     // d/dtheta sum_j x_j^T A(theta) lambda_j : L = xs (ld (k+1) n per probe), R = Lambda
     ScopedTimer t(1, stream);
-    for (int64_t b = 0; b < p; ++b)
-      MFX_TRY(op_vjp_params(op, xs + b * ldx, n, Lam + b * ldl, n, k, grads, ws.opws, ws.opws_bytes, stream));
+    if (comm) {  // this rank's rows of the x_j against ALL entries of the lambda_j
+      mfx_operator rows = *op;
+      rows.row0 = shard_row0(comm);
+      rows.nrows = n;
+      for (int64_t b = 0; b < p; ++b)
+        MFX_TRY(op_vjp_params(&rows, xs + b * ldx, n, Lamfull + b * k * op->n, op->n, k, grads, ws.opws, ws.opws_bytes, stream));
+    } else {
+      for (int64_t b = 0; b < p; ++b)
+        MFX_TRY(op_vjp_params(op, xs + b * ldx, n, Lam + b * ldl, n, k, grads, ws.opws, ws.opws_bytes, stream));
+    }
   }
   return MFX_OK;
 }
@@ -1123,6 +1146,30 @@ int mfx_arnoldi_adjoint_sharded(const mfx_operator* op, const mfx_comm* comm, in
   return arnoldi_adjoint_t<double>(op, nrows, k, p, (const double*)Q, (const double*)H, (const double*)r, (const double*)c,
                                    (const double*)dQ, (const double*)dH, (const double*)dr, (const double*)dc, reortho,
                                    (double*)dv, (double*)Lambda, grads, kws, s, comm, (const double*)Qfull);
+}
+
+int mfx_lanczos_forward_sharded(const mfx_operator* op, const mfx_comm* comm, const void* v0, int64_t n, int64_t k, int64_t p,
+                                void* xs, void* alpha, void* beta, void* vnorm, void* ws, int64_t ws_bytes, void* stream) {
+  MFX_REQUIRE(v0 && xs && alpha && beta && vnorm, MFX_ERR_INVALID, "null argument");
+  MFX_SHARDED_PROLOGUE();
+  if (op->dtype == MFX_F32)
+    return lanczos_forward_t<float>(op, (const float*)v0, nrows, k, p, (float*)xs, (float*)alpha, (float*)beta, (float*)vnorm, kws, s, comm);
+  return lanczos_forward_t<double>(op, (const double*)v0, nrows, k, p, (double*)xs, (double*)alpha, (double*)beta, (double*)vnorm, kws, s, comm);
+}
+
+int mfx_lanczos_adjoint_sharded(const mfx_operator* op, const mfx_comm* comm, int64_t n, int64_t k, int64_t p, const void* xs,
+                                const void* alpha, const void* beta, const void* vnorm, const void* dxs, const void* dalpha,
+                                const void* dbeta, void* dv, void* Lambda, void* Lambdafull, const mfx_op_grads* grads, void* ws,
+                                int64_t ws_bytes, void* stream) {
+  MFX_REQUIRE(xs && alpha && beta && vnorm && dalpha && dbeta && dv && Lambda && Lambdafull, MFX_ERR_INVALID, "null argument");
+  MFX_SHARDED_PROLOGUE();
+  if (op->dtype == MFX_F32)
+    return lanczos_adjoint_t<float>(op, nrows, k, p, (const float*)xs, (const float*)alpha, (const float*)beta, (const float*)vnorm,
+                                    (const float*)dxs, (const float*)dalpha, (const float*)dbeta, (float*)dv, (float*)Lambda, grads,
+                                    kws, s, comm, (float*)Lambdafull);
+  return lanczos_adjoint_t<double>(op, nrows, k, p, (const double*)xs, (const double*)alpha, (const double*)beta, (const double*)vnorm,
+                                   (const double*)dxs, (const double*)dalpha, (const double*)dbeta, (double*)dv, (double*)Lambda, grads,
+                                   kws, s, comm, (double*)Lambdafull);
 }
 
 int mfx_lanczos_forward(const mfx_operator* op, const void* v0, int64_t n, int64_t k, int64_t p, void* xs,

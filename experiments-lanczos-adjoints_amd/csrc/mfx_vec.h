@@ -484,7 +484,8 @@ struct Ctx {
     if (!comm) return MFX_OK;
     k_compact_partials<T><<<(unsigned)p, 256, 0, stream>>>(stage, kmax_, nblk, m, dst);
     MFX_CHECK_LAUNCH();
-    const int rc = comm->allreduce_sum(comm->ctx, dst, p * (int64_t)kmax_, sizeof(T) == 4 ? MFX_F32 : MFX_F64, stream);
+    // the span just written: rows b < p of stride kmax_, m entries each (dst may point INTO a coefficient row)
+    const int rc = comm->allreduce_sum(comm->ctx, dst, (p - 1) * (int64_t)kmax_ + m, sizeof(T) == 4 ? MFX_F32 : MFX_F64, stream);
     MFX_REQUIRE(rc == 0, MFX_ERR_CALLBACK, "all-reduce callback failed with code %d", rc);
     return MFX_OK;
   }

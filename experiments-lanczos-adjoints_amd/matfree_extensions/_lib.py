@@ -124,6 +124,8 @@ SYMBOLS = {
         _I,
         [_OPP, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _GRP, _P, _I64, _P],
     ),
+    "mfx_lanczos_forward_sharded": (_I, [_OPP, _CMP, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _I64, _P]),
+    "mfx_lanczos_adjoint_sharded": (_I, [_OPP, _CMP, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _GRP, _P, _I64, _P]),
     "mfx_rccl_available": (_I, []),
     "mfx_rccl_unique_id": (_I, [_P, _I64]),
     "mfx_comm_create_rccl": (_I, [_P, _I64, C.c_int32, C.c_int32, _I64, _CMP]),

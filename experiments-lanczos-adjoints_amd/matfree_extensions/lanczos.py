@@ -65,9 +65,7 @@ def _tridiag_reortho_full(matvec, krylov_depth, /, *, custom_vjp):
 
 def _tridiag_reortho_none(matvec, krylov_depth, /, *, custom_vjp):
     op, bound = as_operator(matvec)
-    if isinstance(op, RowShardedOp):  # raised at construction: before any rank has entered a collective
-        raise NotImplementedError("the three-term recurrence (reortho='none') is not row-sharded in the MI355X build; row-sharded "
-                                  "operators take tridiag(reortho='full') / arnoldi.hessenberg")
+    sharded = isinstance(op, RowShardedOp)
     k = int(krylov_depth)
 
     def estimate(vec, *params):
@@ -75,11 +73,16 @@ def _tridiag_reortho_none(matvec, krylov_depth, /, *, custom_vjp):
             params = tuple(bound) + tuple(params)
         batched = vec.dim() == 2
         V = vec if batched else vec[None]
-        n = V.shape[-1]
+        n = op.comm.n if sharded else V.shape[-1]
+        if sharded and V.shape[-1] != op.comm.nrows:
+            raise ValueError(f"row-sharded operator: expected this rank's {op.comm.nrows} rows of the start vector, got {V.shape[-1]}")
         if k < 1 or k > n:
             raise ValueError(f"Parameter depth {k} is outside the expected range")
         wants_grad = torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in (V, *params))
-        if not custom_vjp and wants_grad:  # autodiff through the loop (the reference's baseline), see _autodiff.py
+        if sharded:  # vectors are row shards, alpha / beta replicated (mfx_lanczos_*_sharded)
+            cparams = op.constrain(*params)
+            xs, alpha, beta = _LanczosShardedFn.apply(op, k, custom_vjp, V, *cparams)
+        elif not custom_vjp and wants_grad:  # autodiff through the loop (the reference's baseline), see _autodiff.py
             from . import _autodiff
 
             xs, alpha, beta = _autodiff.batched(_autodiff.lanczos_forward, V, op, k, params)
@@ -169,6 +172,83 @@ class _LanczosFn(torch.autograd.Function):
         if keep is not None and keep[1]:
             raise keep[1][0]
         _lib.check(rc)
+        return (None, None, None, dv, *grads)
+
+
+class _LanczosShardedFn(torch.autograd.Function):
+    """_LanczosFn on row shards (``mfx_lanczos_forward_sharded`` / ``mfx_lanczos_adjoint_sharded``): V, xs, dv hold this rank's
+    rows; alpha, beta are replicated; the parameter gradients are summed over the row group before they are returned."""
+
+    @staticmethod
+    def forward(ctx, sop, k, differentiable, V, *cparams):
+        op, comm = sop.op, sop.comm
+        tensors = [q for q in cparams if torch.is_tensor(q)]
+        _lib.require_device(V, *tensors)
+        lib = _lib.get()
+        V = V.contiguous()
+        p, nrows = V.shape
+        n = comm.n
+        dt, dev = V.dtype, V.device
+        xs = torch.empty((p, k + 1, nrows), dtype=dt, device=dev)
+        alpha = torch.empty((p, k), dtype=dt, device=dev)
+        beta = torch.empty((p, k), dtype=dt, device=dev)
+        vnorm = torch.empty((p,), dtype=dt, device=dev)
+        desc = op.descriptor(cparams, dt, n)
+        cm0 = _lib.Comm()
+        cm0.rank, cm0.world, cm0.nloc = comm.rank, comm.world, comm.nloc
+        ws = _lib.scratch(int(lib.mfx_sharded_workspace_bytes(C.byref(desc), C.byref(cm0), n, k, p)), dev)
+        cm, keep = comm.struct(ws, tensors=(xs,), plans=sop.plans)
+        with _lib.busy(ws):
+            rc = lib.mfx_lanczos_forward_sharded(C.byref(desc), C.byref(cm), _lib.ptr(V), n, k, p, _lib.ptr(xs), _lib.ptr(alpha),
+                                                 _lib.ptr(beta), _lib.ptr(vnorm), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+        if keep[2]:
+            raise keep[2][0]
+        _lib.check(rc)
+        ctx.sop, ctx.k, ctx.differentiable = sop, k, differentiable
+        ctx.nontensor = [None if torch.is_tensor(q) else q for q in cparams]
+        ctx.save_for_backward(xs, alpha, beta, vnorm, *tensors)
+        ctx.set_materialize_grads(False)
+        return xs, alpha, beta
+
+    @staticmethod
+    def backward(ctx, dxs, dalpha, dbeta):
+        if not ctx.differentiable:
+            raise RuntimeError("tridiag(custom_vjp=False) is not differentiable in the MI355X build; "
+                               "use custom_vjp=True (the adjoint system).")
+        xs, alpha, beta, vnorm, *tensors = ctx.saved_tensors
+        it = iter(tensors)
+        cparams = tuple(next(it) if q is None else q for q in ctx.nontensor)
+        op, comm, k, lib = ctx.sop.op, ctx.sop.comm, ctx.k, _lib.get()
+        p, _, nrows = xs.shape
+        n = comm.n
+        dt, dev = xs.dtype, xs.device
+        dxs = None if dxs is None else dxs.contiguous()
+        dalpha = torch.zeros_like(alpha) if dalpha is None else dalpha.contiguous()
+        dbeta = torch.zeros_like(beta) if dbeta is None else dbeta.contiguous()
+        dv = torch.empty((p, nrows), dtype=dt, device=dev)
+        Lam = torch.empty((p, k, nrows), dtype=dt, device=dev)
+        Lamfull = torch.empty((p, k, n), dtype=dt, device=dev)
+        desc = op.descriptor(cparams, dt, n)
+        gstruct, grads = op.new_grads(*cparams)
+        cm0 = _lib.Comm()
+        cm0.rank, cm0.world, cm0.nloc = comm.rank, comm.world, comm.nloc
+        ws = _lib.scratch(int(lib.mfx_sharded_workspace_bytes(C.byref(desc), C.byref(cm0), n, k, p)), dev)
+        cm, keep = comm.struct(ws, tensors=(Lam, Lamfull), plans=ctx.sop.plans)
+        with _lib.busy(ws):
+            rc = lib.mfx_lanczos_adjoint_sharded(C.byref(desc), C.byref(cm), n, k, p, _lib.ptr(xs), _lib.ptr(alpha), _lib.ptr(beta),
+                                                 _lib.ptr(vnorm), _lib.ptr(dxs), _lib.ptr(dalpha), _lib.ptr(dbeta), _lib.ptr(dv),
+                                                 _lib.ptr(Lam), _lib.ptr(Lamfull), C.byref(gstruct), _lib.ptr(ws), ws.numel(),
+                                                 _lib.stream_ptr(dev))
+        if keep[2]:
+            raise keep[2][0]
+        _lib.check(rc)
+        if comm.world > 1 and grads:  # partial sums over this rank's rows -> the complete gradient, ONE small all-reduce
+            flat = torch.cat([g.reshape(-1) for g in grads])
+            comm.all_reduce_(flat)
+            off = 0
+            for g in grads:
+                g.copy_(flat[off : off + g.numel()].reshape(g.shape))
+                off += g.numel()
         return (None, None, None, dv, *grads)
 
 

@@ -287,6 +287,20 @@ int mfx_arnoldi_adjoint_sharded(const mfx_operator* op, const mfx_comm* comm, in
                                 const void* dQ, const void* dH, const void* dr, const void* dc, int reortho, void* dv,
                                 void* Lambda, const mfx_op_grads* grads, void* ws, int64_t ws_bytes, void* stream);
 
+/* The three-term recurrence and its adjoint (mfx_lanczos_forward / mfx_lanczos_adjoint below; lanczos.py:231-335) on row
+ * shards.  Vectors hold this rank's rows: v0, dv (p, nrows); xs, dxs (p, k + 1, nrows); Lambda (p, k, nrows).  alpha, beta,
+ * vnorm and their cotangents are replicated.  Lambdafull (p, k, n) receives the gathered adjoint states -- the operator input
+ * of every adjoint step and the right factor of the parameter-gradient sweep, whose result (`grads`) is this rank's PARTIAL sum
+ * over its rows: the caller adds the ranks up.  Collectives per step: one all-gather of the iterate, the dots as small
+ * all-reduces.  Workspace: mfx_sharded_workspace_bytes. */
+int mfx_lanczos_forward_sharded(const mfx_operator* op, const mfx_comm* comm, const void* v0, int64_t n, int64_t k,
+                                int64_t p, void* xs, void* alpha, void* beta, void* vnorm, void* ws, int64_t ws_bytes,
+                                void* stream);
+int mfx_lanczos_adjoint_sharded(const mfx_operator* op, const mfx_comm* comm, int64_t n, int64_t k, int64_t p,
+                                const void* xs, const void* alpha, const void* beta, const void* vnorm, const void* dxs,
+                                const void* dalpha, const void* dbeta, void* dv, void* Lambda, void* Lambdafull,
+                                const mfx_op_grads* grads, void* ws, int64_t ws_bytes, void* stream);
+
 /* ---- linear solves ("next" tier: the Mahalanobis half of the GP log-marginal likelihood) -------------------------
  *
  * (Preconditioned) conjugate gradients on a (p, n) batch of right-hand sides  (cg.py:19-60 pcg_fixed_step,

@@ -335,6 +335,105 @@ def test_c4_shape_on_two_row_shards_equals_the_single_process_estimate(tmp_path)
         assert torch.allclose(a, b.cpu(), rtol=5e-4, atol=5e-4 * b.abs().max().item()), (a, b)
 
 
+# ---- the three-term recurrence (tridiag(reortho="none"), lanczos.py:231-335) on row shards ---------------------------------
+_LZ = (1900, 7, 3)  # n (3 ranks own 640, 640, 620 rows), depth, start vectors
+
+
+def _lz_problem(kind):
+    g = torch.Generator().manual_seed(21)
+    n, k, p = _LZ
+    if kind == "rbf":
+        op, params = _rbf(n, 5, torch.float64, "fp32", ard=True, seed=4)
+    else:  # a banded SPD matrix as CSR: the neighbour-exchange path of a row-sharded sparse operator
+        from matfree_extensions.operators import CsrOp
+
+        rows, cols, vals = [], [], []
+        for off, val in ((0, 4.0), (1, -1.0), (-1, -1.0), (17, -0.5), (-17, -0.5)):
+            i = torch.arange(max(0, -off), min(n, n - off))
+            rows.append(i), cols.append(i + off), vals.append(torch.full((len(i),), val, dtype=torch.float64))
+        rows, cols, vals = torch.cat(rows), torch.cat(cols), torch.cat(vals)
+        vals = vals * (1.0 + 0.1 * torch.rand(len(vals), generator=g, dtype=torch.float64))  # non-symmetric on purpose (Q4: A, not A^T)
+        op, stored, _ = CsrOp.from_coo(rows, cols, vals, n, _dev())
+        params = [stored]
+    V = torch.randn((p, n), generator=g, dtype=torch.float64).to(_dev())
+    wa = torch.randn((p, k), generator=g, dtype=torch.float64).to(_dev())
+    wb = torch.randn((p, k - 1), generator=g, dtype=torch.float64).to(_dev())
+    wx = torch.randn((p, k, n), generator=g, dtype=torch.float64).to(_dev())
+    wl = torch.randn((p, n), generator=g, dtype=torch.float64).to(_dev())
+    return op, params, V, (wa, wb, wx, wl)
+
+
+def _lz_loss(out, weights, rows=slice(None)):
+    (xs, (alpha, beta)), (xlast, blast) = out
+    wa, wb, wx, wl = weights
+    local = (xs * wx[:, :, rows]).sum() + (xlast * wl[:, rows]).sum()
+    return local, (alpha * wa).sum() + (beta * wb).sum() + (blast ** 2).sum()
+
+
+def _lz_worker(rank, world, port, out, kind):
+    for p in (ROOT, os.path.join(ROOT, "experiments-lanczos-adjoints_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import datetime
+
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    from matfree_extensions import lanczos
+    from matfree_extensions.distributed import RowComm
+    from matfree_extensions.operators import RowShardedOp
+
+    op, params, V, weights = _lz_problem(kind)
+    comm = RowComm(_LZ[0])
+    sl = slice(comm.row0, comm.row0 + comm.nrows)
+    ps = [q.clone().requires_grad_(True) for q in params]
+    v = V[:, sl].clone().requires_grad_(True)
+    res = lanczos.tridiag(RowShardedOp(op, comm), _LZ[1], reortho="none")(v, *ps)
+    local, replicated = _lz_loss(res, weights, sl)
+    # this rank's part of the row-wise loss + the loss on the replicated coefficients, which every rank evaluates in full (the
+    # convention of the sharded drivers: cotangents of replicated outputs are complete on every rank)
+    (local + replicated).backward()
+    (xs, (alpha, beta)), _ = res
+    torch.cuda.synchronize()
+    got = {"alpha": alpha.detach().cpu(), "beta": beta.detach().cpu(), "xs": comm.gather_rows(xs.detach().reshape(-1, comm.nrows)).cpu(),
+           "dv": comm.gather_rows(v.grad).cpu(), "grads": [q.grad.cpu() for q in ps]}
+    if rank == world - 1:
+        torch.save(got, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["rbf", "csr"])
+def test_row_sharded_three_term_recurrence_and_adjoint(tmp_path, kind):
+    """tridiag(reortho="none") on 3 processes (ragged last shard; CSR: neighbour exchange) against the single-process drivers:
+    alpha, beta, the basis, dv and the parameter gradients, fp64."""
+    import torch.multiprocessing as mp
+
+    from matfree_extensions import lanczos
+
+    op, params, V, weights = _lz_problem(kind)
+    ps = [q.clone().requires_grad_(True) for q in params]
+    v = V.clone().requires_grad_(True)
+    res = lanczos.tridiag(op, _LZ[1], reortho="none")(v, *ps)
+    local, replicated = _lz_loss(res, weights)
+    (local + replicated).backward()
+    (xs, (alpha, beta)), _ = res
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "lz.pt")
+    mp.spawn(_lz_worker, args=(3, port, out, kind), nprocs=3, join=True)
+    got = torch.load(out)
+    n, k, p = _LZ
+    assert torch.allclose(got["alpha"], alpha.detach().cpu(), rtol=1e-10, atol=1e-12)
+    assert torch.allclose(got["beta"], beta.detach().cpu(), rtol=1e-10, atol=1e-12)
+    assert torch.allclose(got["xs"].reshape(p, k, n), xs.detach().cpu(), rtol=1e-9, atol=1e-11)
+    assert torch.allclose(got["dv"], v.grad.cpu(), rtol=1e-8, atol=1e-10 * v.grad.abs().max().item())
+    for a, b in zip(got["grads"], ps):
+        assert torch.allclose(a, b.grad.cpu(), rtol=1e-8, atol=1e-10 * b.grad.abs().max().item()), (a, b.grad)
+
+
 def test_rccl_one_rank_group_runs_the_collective_callbacks():
     """RCCL needs one GPU per rank, so the multi-rank runs of this file go through gloo and the host.  What a one-GPU box CAN
     check of the RCCL path: a one-rank "nccl" group with the collectives forced through it -- all_reduce / all_gather_into_tensor on
