@@ -54,6 +54,7 @@ struct CgArgs {
   const int* active;  // (p) or null = all active
   T atol, rtol;
   int kmax, nblk, first, has_z;
+  int nblk_in;   // slices the consumers sum over (= nblk; 1 in the row-sharded mode, where the partials arrive summed)
   T* qrow;       // re-orthogonalising variant: row i of Q = r_old / sqrt(r_old . z_old)  (cg.py:200), or null
   int64_t ldq;   // batch stride of Q
 };
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_xr(CgArgs<T> a) {
   if (a.active && !a.active[b]) return;
   const int64_t slice0 = (int64_t)blk * ((int64_t)blockDim.x * kEpt);
   if (tid < 64) {
-    const T pap = reduce_partials_group<T, 64>(a.part_pap + (int64_t)b * a.kmax * a.nblk, a.nblk, tid);
+    const T pap = reduce_partials_group<T, 64>(a.part_pap + (int64_t)b * a.kmax * a.nblk_in, a.nblk_in, tid);
     if (tid == 0) {
       alpha_sh = safe_div(a.rz_cur[b], pap);
       const T rzv = a.rz_cur[b];
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_dir(CgArgs<T> a) {
   if (a.active && !a.active[b]) return;
   const int64_t slice0 = (int64_t)blk * ((int64_t)blockDim.x * kEpt);
   if (tid < 64) {
-    const T rz_new = reduce_partials_group<T, 64>(a.part_rz + (int64_t)b * a.nblk, a.nblk, tid);
+    const T rz_new = reduce_partials_group<T, 64>(a.part_rz + (int64_t)b * a.nblk_in, a.nblk_in, tid);
     if (tid == 0) {
       beta_sh = a.first ? T(0) : safe_div(rz_new, a.rz_cur[b]);
       if (blk == 0) a.rz_next[b] = rz_new;
@@ -265,18 +266,23 @@ struct Precond {
   int64_t rank;
 };
 
+// row-sharded (c.comm): lt holds this rank's columns of L^T (rank, nrows); L^T v is summed over the ranks (launch_dots), and
+// the r.z partials go through `stage_rz` (per-slice) into part_rz (summed over slices and ranks)
 template <typename T>
 static int precond_apply_t(const Ctx<T>& c, const Precond& pc, const T* v, int64_t ldv, T* z, int64_t ldz, T* part_t,
-                           T* u, T* part_rz, const int* active) {
+                           T* u, T* part_rz, const int* active, T* stage_rz = nullptr) {
   const int rank = (int)pc.rank;
   MFX_TRY(launch_dots<T>(c, (const T*)pc.lt, 0, c.n, rank, v, ldv, part_t));
-  k_pre_small<T><<<(unsigned)c.p, 256, rank * sizeof(T), c.stream>>>(part_t, c.kmax, c.nblk, rank, (const T*)pc.minv, u,
+  k_pre_small<T><<<(unsigned)c.p, 256, rank * sizeof(T), c.stream>>>(part_t, c.kmax, c.nblk_in, rank, (const T*)pc.minv, u,
                                                                     active);
   MFX_CHECK_LAUNCH();
   const size_t sh = (size_t)(rank + 4) * sizeof(T);
+  T* const prod_rz = (c.comm && part_rz) ? stage_rz : part_rz;
+  if (c.comm && part_rz && active) MFX_TRY(zero_async(stage_rz, sizeof(T) * c.p * c.nblk, c.stream));  // frozen right-hand sides write nothing
   MFX_VEC_SWITCH(c.vec, (k_pre_finish<T, VEC><<<c.grid(), c.wg, sh, c.stream>>>(
-                            (const T*)pc.lt, rank, u, (const T*)pc.shift, v, ldv, z, ldz, c.n, part_rz, c.nblk, active)));
+                            (const T*)pc.lt, rank, u, (const T*)pc.shift, v, ldv, z, ldz, c.n, prod_rz, c.nblk, active)));
   MFX_CHECK_LAUNCH();
+  if (c.comm && part_rz) MFX_TRY(c.finish_from(stage_rz, part_rz, 1, 1));
   return MFX_OK;
 }
 
@@ -286,10 +292,13 @@ static int precond_apply_t(const Ctx<T>& c, const Precond& pc, const T* v, int64
 struct CgWs {
   void *Ap, *pv, *z, *part_a, *part_rz, *part_err, *u, *rz, *active, *nsteps, *flag, *opws;
   int64_t opws_bytes;
+  // row-sharded solve only
+  void *stage, *stage_rz, *stage_err, *send, *gathered, *xfull;
 };
 
+// n = length of the vectors this process holds (the operator size, or the rows of its shard: comm != NULL)
 static int64_t cg_carve(const mfx_operator* op, int64_t n, int64_t p, int64_t rank, void* ws, int64_t ws_bytes,
-                        CgWs* out) {
+                        CgWs* out, const mfx_comm* comm = nullptr) {
   const size_t es = op ? dtype_size(op->dtype) : 8;
   const int64_t nblk = (n + 64 * kEpt - 1) / (64 * kEpt);
   const int64_t kmax = (rank > 0 ? rank : 1) + 1;
@@ -308,6 +317,15 @@ static int64_t cg_carve(const mfx_operator* op, int64_t n, int64_t p, int64_t ra
   r.flag = cv.take(256);
   r.opws_bytes = op ? op_workspace_bytes(op, p, p) : 0;
   r.opws = cv.take(r.opws_bytes);
+  r.stage = r.stage_rz = r.stage_err = r.send = r.gathered = r.xfull = nullptr;
+  if (comm) {
+    r.stage = cv.take(p * kmax * nblk * es);
+    r.stage_rz = cv.take(p * nblk * es);
+    r.stage_err = cv.take(p * nblk * es);
+    r.send = cv.take(p * comm->nloc * es);
+    r.gathered = cv.take(comm->world * p * comm->nloc * es);
+    r.xfull = cv.take(p * op->n * es);
+  }
   if (out) *out = r;
   return cv.off;
 }
@@ -318,10 +336,18 @@ static int64_t cg_carve(const mfx_operator* op, int64_t n, int64_t p, int64_t ra
 template <typename T>
 static int pcg_t(const mfx_operator* op, const T* b, int64_t ldb, int64_t n, int64_t p, const Precond* pc,
                  int64_t maxiter, int64_t miniter, double atol, double rtol, int adaptive, T* x, T* r,
-                 int64_t* num_steps, T* Q, const CgWs& ws, hipStream_t stream) {
+                 int64_t* num_steps, T* Q, const CgWs& ws, hipStream_t stream, const mfx_comm* comm = nullptr) {
+  // comm != NULL: row-sharded -- n = this rank's rows of every vector (and columns of L^T), op->n = the system size; the
+  // operator input is gathered, every inner product (p.Ap, r.z, the error sum, L^T v) is summed over the ranks, so all ranks
+  // take the same steps and stop together
   const int64_t rank = pc ? pc->rank : 0;
   const int64_t kdim = Q ? (rank > maxiter ? rank : maxiter) : rank;
   Ctx<T> c(n, kdim > 0 ? kdim : 1, p, pick_vec<T>(n, {x, r, ws.Ap, ws.pv, ws.z, pc ? pc->lt : nullptr, Q}), stream);
+  if (comm) c.shard(comm, static_cast<T*>(ws.stage));
+  KrylovWs kws{};
+  kws.opws = ws.opws; kws.opws_bytes = ws.opws_bytes; kws.send = ws.send; kws.gathered = ws.gathered;
+  T* const stage_rz = (T*)ws.stage_rz;
+  T* const stage_err = (T*)ws.stage_err;
   T* Ap = (T*)ws.Ap;
   T* pv = (T*)ws.pv;
   T* z = (T*)ws.z;
@@ -336,21 +362,30 @@ static int pcg_t(const mfx_operator* op, const T* b, int64_t ldb, int64_t n, int
   CgArgs<T> a{};
   a.x = x; a.r = r; a.pv = pv; a.z = z; a.Ap = Ap; a.n = n;
   a.part_pap = (T*)ws.part_a; a.part_rz = (T*)ws.part_rz; a.part_err = adaptive ? (T*)ws.part_err : nullptr;
-  a.active = nullptr; a.atol = (T)atol; a.rtol = (T)rtol; a.kmax = c.kmax; a.nblk = c.nblk; a.has_z = pc ? 1 : 0;
+  a.active = nullptr; a.atol = (T)atol; a.rtol = (T)rtol; a.kmax = c.kmax; a.nblk = c.nblk; a.nblk_in = c.nblk_in; a.has_z = pc ? 1 : 0;
+  if (comm) {  // producers write per-slice partials into their staging buffers; the summed values land where the consumers read
+    a.part_rz = stage_rz;
+    if (adaptive) a.part_err = stage_err;
+  }
+  T* const part_rz = (T*)ws.part_rz;
+  T* const part_err = (T*)ws.part_err;
   {
     ScopedTimer t(2, stream);
     if (pc) {
-      MFX_TRY(precond_apply_t<T>(c, *pc, r, n, z, n, (T*)ws.part_a, (T*)ws.u, (T*)ws.part_rz, nullptr));
+      MFX_TRY(precond_apply_t<T>(c, *pc, r, n, z, n, (T*)ws.part_a, (T*)ws.u, part_rz, nullptr, stage_rz));
     } else {
-      MFX_TRY(launch_sumsq<T>(c, r, n, (T*)ws.part_rz));
+      MFX_TRY(launch_sumsq<T>(c, r, n, part_rz));
     }
-    a.first = 1; a.rz_cur = rz; a.rz_next = rz;
-    MFX_VEC_SWITCH(c.vec, (k_cg_dir<T, VEC><<<c.grid(), c.wg, 0, stream>>>(a)));
+    CgArgs<T> d = a;  // k_cg_dir only READS the r.z partials: always the summed ones
+    d.part_rz = part_rz;
+    d.first = 1; d.rz_cur = rz; d.rz_next = rz;
+    MFX_VEC_SWITCH(c.vec, (k_cg_dir<T, VEC><<<c.grid(), c.wg, 0, stream>>>(d)));
     MFX_CHECK_LAUNCH();
     a.first = 0;
     if (adaptive) {
-      MFX_VEC_SWITCH(c.vec, (k_cg_err0<T, VEC><<<c.grid(), c.wg, 0, stream>>>(r, n, (T)atol, (T*)ws.part_err, c.nblk)));
+      MFX_VEC_SWITCH(c.vec, (k_cg_err0<T, VEC><<<c.grid(), c.wg, 0, stream>>>(r, n, (T)atol, comm ? stage_err : part_err, c.nblk)));
       MFX_CHECK_LAUNCH();
+      if (comm) MFX_TRY(c.finish_from(stage_err, part_err, 1, 1));
       MFX_CHECK_HIP(hipMemsetAsync(nsteps, 0, sizeof(int64_t) * p, stream));
     } else {
       k_fill_i64<T><<<(unsigned)((p + 255) / 256), 256, 0, stream>>>(nsteps, p, maxiter);
@@ -361,7 +396,7 @@ static int pcg_t(const mfx_operator* op, const T* b, int64_t ldb, int64_t n, int
   for (int64_t it = 0; it < maxiter; ++it) {
     if (adaptive) {
       MFX_CHECK_HIP(hipMemsetAsync(flag, 0, sizeof(int), stream));
-      k_cg_cond<T><<<(unsigned)((p + 255) / 256), 256, 0, stream>>>((T*)ws.part_err, c.nblk, n, p, miniter, maxiter,
+      k_cg_cond<T><<<(unsigned)((p + 255) / 256), 256, 0, stream>>>(part_err, c.nblk_in, op->n, p, miniter, maxiter,
                                                                    active, nsteps, flag);
       MFX_CHECK_LAUNCH();
       int host_flag = 0;
@@ -369,7 +404,11 @@ static int pcg_t(const mfx_operator* op, const T* b, int64_t ldb, int64_t n, int
       MFX_CHECK_HIP(hipStreamSynchronize(stream));
       if (!host_flag) break;
     }
-    MFX_TRY(apply_any(op, 0, pv, n, nullptr, 0, Ap, n, p, ws.opws, ws.opws_bytes, stream));
+    if (comm) {
+      MFX_TRY(apply_sharded<T>(op, comm, 0, pv, n, Ap, n, p, static_cast<T*>(ws.xfull), op->n, kws, stream));
+    } else {
+      MFX_TRY(apply_any(op, 0, pv, n, nullptr, 0, Ap, n, p, ws.opws, ws.opws_bytes, stream));
+    }
     ScopedTimer t(2, stream);
     MFX_TRY(launch_dots<T>(c, Ap, n, 0, 1, pv, n, (T*)ws.part_a));
     a.rz_cur = rz + (it & 1) * p;
@@ -378,9 +417,17 @@ static int pcg_t(const mfx_operator* op, const T* b, int64_t ldb, int64_t n, int
       a.qrow = Q + it * n;
       a.ldq = maxiter * n;
     }
+    if (comm && active) {  // frozen right-hand sides write no partials: their staged slices must read as zero
+      if (!pc) MFX_TRY(zero_async(stage_rz, sizeof(T) * p * c.nblk, stream));
+      MFX_TRY(zero_async(stage_err, sizeof(T) * p * c.nblk, stream));
+    }
     MFX_VEC_SWITCH(c.vec, (k_cg_xr<T, VEC><<<c.grid(), c.wg, 0, stream>>>(a)));
     MFX_CHECK_LAUNCH();
-    if (pc) MFX_TRY(precond_apply_t<T>(c, *pc, r, n, z, n, (T*)ws.part_a, (T*)ws.u, (T*)ws.part_rz, active));
+    if (comm) {
+      if (!pc) MFX_TRY(c.finish_from(stage_rz, part_rz, 1, 1));
+      if (adaptive) MFX_TRY(c.finish_from(stage_err, part_err, 1, 1));
+    }
+    if (pc) MFX_TRY(precond_apply_t<T>(c, *pc, r, n, z, n, (T*)ws.part_a, (T*)ws.u, part_rz, active, stage_rz));
     if (Q) {
       // re-orthogonalise against the stored (normalised) residuals, then precondition again (cg.py:199-205):
       //   r -= Q (Q^T z);  z = P(r);  r.z
@@ -390,11 +437,13 @@ static int pcg_t(const mfx_operator* op, const T* b, int64_t ldb, int64_t n, int
       ua.rows = Q; ua.rows_ldb = maxiter * n; ua.row_stride = n; ua.m = m;
       ua.partial_in = (T*)ws.part_a; ua.s1 = T(1);
       ua.x = r; ua.ldx = n; ua.y = r; ua.ldy = n;
-      ua.partial_norm = (T*)ws.part_rz;
+      ua.partial_norm = part_rz;
       MFX_TRY(launch_update<T>(c, ua, false, true));
-      if (pc) MFX_TRY(precond_apply_t<T>(c, *pc, r, n, z, n, (T*)ws.part_a, (T*)ws.u, (T*)ws.part_rz, active));
+      if (pc) MFX_TRY(precond_apply_t<T>(c, *pc, r, n, z, n, (T*)ws.part_a, (T*)ws.u, part_rz, active, stage_rz));
     }
-    MFX_VEC_SWITCH(c.vec, (k_cg_dir<T, VEC><<<c.grid(), c.wg, 0, stream>>>(a)));
+    CgArgs<T> d = a;
+    d.part_rz = part_rz;
+    MFX_VEC_SWITCH(c.vec, (k_cg_dir<T, VEC><<<c.grid(), c.wg, 0, stream>>>(d)));
     MFX_CHECK_LAUNCH();
   }
   if (num_steps)
@@ -608,6 +657,47 @@ int mfx_pcg_solve(const mfx_operator* op, const void* b, int64_t ldb, int64_t n,
                         (float*)x, (float*)r, (int64_t*)num_steps, nullptr, w, s);
   return pcg_t<double>(op, (const double*)b, ldb, n, p, precond_lt ? &pc : nullptr, maxiter, miniter, atol, rtol, adaptive,
                        (double*)x, (double*)r, (int64_t*)num_steps, nullptr, w, s);
+}
+
+static int64_t pcg_shard_rows(const mfx_comm* cm, int64_t n) {
+  const int64_t left = n - (int64_t)cm->rank * cm->nloc;
+  return left < cm->nloc ? left : cm->nloc;
+}
+
+int64_t mfx_pcg_sharded_workspace_bytes(const mfx_operator* op, const mfx_comm* comm, int64_t n, int64_t p, int64_t rank) {
+  if (!op || !comm || comm->nloc < 1 || n <= 0 || p <= 0 || rank < 0) return -1;
+  return cg_carve(op, comm->nloc, p, rank, nullptr, 0, nullptr, comm) + 256;
+}
+
+int mfx_pcg_solve_sharded(const mfx_operator* op, const mfx_comm* comm, const void* b, int64_t ldb, int64_t n, int64_t p,
+                          const void* precond_lt, int64_t rank, const void* precond_minv, const void* precond_shift,
+                          int64_t maxiter, int64_t miniter, double atol, double rtol, int adaptive, void* x, void* r,
+                          void* num_steps, void* ws, int64_t ws_bytes, void* stream) {
+  MFX_REQUIRE(op && comm && b && x && r, MFX_ERR_INVALID, "mfx_pcg_solve_sharded: null argument");
+  MFX_REQUIRE(op->n == n && n >= 1 && p >= 1, MFX_ERR_INVALID, "mfx_pcg_solve_sharded: bad sizes n=%lld p=%lld", (long long)n, (long long)p);
+  MFX_REQUIRE(op->kind != MFX_OP_CALLBACK, MFX_ERR_UNSUPPORTED, "row sharding needs a native operator");
+  MFX_REQUIRE(op->nrows == 0, MFX_ERR_INVALID, "pass the whole operator: the driver takes this rank's rows itself");
+  MFX_REQUIRE(comm->allreduce_sum && comm->allgather, MFX_ERR_INVALID, "communicator without callbacks");
+  MFX_REQUIRE(comm->world >= 1 && comm->rank >= 0 && comm->rank < comm->world, MFX_ERR_INVALID, "bad rank %d of %d", comm->rank, comm->world);
+  MFX_REQUIRE(comm->nloc >= 64 && comm->nloc % 64 == 0, MFX_ERR_INVALID, "rows per rank (%lld) must be a positive multiple of 64", (long long)comm->nloc);
+  MFX_REQUIRE((int64_t)comm->world * comm->nloc >= n && (int64_t)(comm->world - 1) * comm->nloc < n, MFX_ERR_INVALID,
+              "%d ranks x %lld rows do not tile n = %lld with a non-empty last shard", comm->world, (long long)comm->nloc, (long long)n);
+  const int64_t nrows = pcg_shard_rows(comm, n);
+  MFX_REQUIRE(ldb >= nrows, MFX_ERR_INVALID, "ldb = %lld < this rank's %lld rows", (long long)ldb, (long long)nrows);
+  MFX_REQUIRE(p <= 65535, MFX_ERR_UNSUPPORTED, "at most 65535 right-hand sides per call");
+  MFX_REQUIRE(maxiter >= 0 && miniter >= 0, MFX_ERR_INVALID, "negative iteration count");
+  MFX_REQUIRE(op->dtype == MFX_F32 || op->dtype == MFX_F64, MFX_ERR_INVALID, "bad dtype");
+  Precond pc{precond_lt, precond_minv, precond_shift, rank};
+  if (precond_lt) MFX_TRY(check_precond(n, rank, precond_lt, precond_minv, precond_shift));
+  CgWs w;
+  MFX_REQUIRE(ws && cg_carve(op, nrows, p, precond_lt ? rank : 0, ws, ws_bytes, &w, comm) <= ws_bytes, MFX_ERR_WORKSPACE,
+              "mfx_pcg_solve_sharded: workspace too small");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (op->dtype == MFX_F32)
+    return pcg_t<float>(op, (const float*)b, ldb, nrows, p, precond_lt ? &pc : nullptr, maxiter, miniter, atol, rtol, adaptive,
+                        (float*)x, (float*)r, (int64_t*)num_steps, nullptr, w, s, comm);
+  return pcg_t<double>(op, (const double*)b, ldb, nrows, p, precond_lt ? &pc : nullptr, maxiter, miniter, atol, rtol, adaptive,
+                       (double*)x, (double*)r, (int64_t*)num_steps, nullptr, w, s, comm);
 }
 
 int mfx_pcg_solve_reortho(const mfx_operator* op, const void* b, int64_t ldb, int64_t n, int64_t p,

@@ -450,13 +450,6 @@ __global__ __launch_bounds__(kBlock) void k_csr_step(CsrStepArgs<T> a) {
   }
 }
 
-struct KrylovWs {
-  void *w, *p1, *p2, *pn, *small, *opws;
-  void* pb;  // partials of a batch of dQ columns (adjoint, few-slice problems), null when the columns go one by one
-  int64_t opws_bytes;
-  // row-sharded drivers only
-  void *stage, *send, *gathered, *xfull;
-};
 
 // Columns of dQ projected onto the basis per launch (arnoldi.py:128, dQ^T Q): one when a single column already fills the
 // chip, up to k when there are few slices (one vector, n ~ 1e5: k launches of 50 workgroups were 1 ms of config 3's adjoint).
@@ -535,63 +528,6 @@ static int launch_csr_step(const Ctx<T>& c, const mfx_operator* op, int transpos
   return MFX_OK;
 }
 
-// ------------------------------------------------------------------------------------------------
-// row-sharded operator application: all-gather the iterate, apply the rows this rank owns
-// ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void k_pack_shard(const T* __restrict__ x, int64_t ldx, int64_t nrows, int64_t nloc,
-                                                    T* __restrict__ send) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-  if (i < nloc) send[b * nloc + i] = i < nrows ? x[b * ldx + i] : T(0);
-}
-
-// gathered (world, p, nloc) -> full[b][g nloc + i], the first n columns
-template <typename T>
-__global__ __launch_bounds__(256) void k_unshard(const T* __restrict__ gathered, int64_t nloc, int64_t p, int64_t n,
-                                                 T* __restrict__ full, int64_t ldfull) {
-  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-  if (j >= n) return;
-  const int64_t g = j / nloc, i = j - g * nloc;
-  full[b * ldfull + j] = gathered[(g * p + b) * nloc + i];
-}
-
-static inline int64_t shard_row0(const mfx_comm* cm) { return (int64_t)cm->rank * cm->nloc; }
-static inline int64_t shard_nrows(const mfx_comm* cm, int64_t n) {
-  const int64_t left = n - shard_row0(cm);
-  return left < cm->nloc ? left : cm->nloc;
-}
-
-// y (p rows of nrows, this rank's rows of A x or A^T x) from the sharded x; `full` (p, n) receives the gathered iterate
-template <typename T>
-static int apply_sharded(const mfx_operator* op, const mfx_comm* cm, int transpose, const T* x, int64_t ldx, T* y,
-                         int64_t ldy, int64_t p, T* full, int64_t ldfull, const KrylovWs& ws, hipStream_t stream) {
-  const int64_t n = op->n, nloc = cm->nloc, nrows = shard_nrows(cm, n);
-  if (cm->exchange) {  // neighbour exchange: own rows into place, then only the entries this rank's rows read from other ranks
-    ScopedTimer t(3, stream);
-    MFX_CHECK_HIP(hipMemcpy2DAsync(full + shard_row0(cm), sizeof(T) * ldfull, x, sizeof(T) * ldx, sizeof(T) * nrows, p,
-                                   hipMemcpyDeviceToDevice, stream));
-    const int rc = cm->exchange(cm->ctx, x, ldx, full, ldfull, p, op->dtype, transpose, stream);
-    MFX_REQUIRE(rc == 0, MFX_ERR_CALLBACK, "exchange callback failed with code %d", rc);
-  } else if (cm->allgather_rows && nrows == nloc && (int64_t)cm->world * nloc == n) {
-    // every rank owns exactly nloc rows: the shards go straight into the (p, n) operator input, no pack / unpack copies
-    ScopedTimer t(3, stream);
-    const int rc = cm->allgather_rows(cm->ctx, x, ldx, full, ldfull, p, nloc, op->dtype, stream);
-    MFX_REQUIRE(rc == 0, MFX_ERR_CALLBACK, "all-gather (rows) failed with code %d", rc);
-  } else {
-    ScopedTimer t(3, stream);
-    k_pack_shard<T><<<dim3((unsigned)((nloc + 255) / 256), (unsigned)p), 256, 0, stream>>>(x, ldx, nrows, nloc, (T*)ws.send);
-    MFX_CHECK_LAUNCH();
-    const int rc = cm->allgather(cm->ctx, ws.send, ws.gathered, p * nloc, op->dtype, stream);
-    MFX_REQUIRE(rc == 0, MFX_ERR_CALLBACK, "all-gather callback failed with code %d", rc);
-    k_unshard<T><<<dim3((unsigned)((n + 255) / 256), (unsigned)p), 256, 0, stream>>>((const T*)ws.gathered, nloc, p, n, full, ldfull);
-    MFX_CHECK_LAUNCH();
-  }
-  mfx_operator rows = *op;
-  rows.row0 = shard_row0(cm);
-  rows.nrows = nrows;
-  ScopedTimer t(0, stream);
-  return op_apply(&rows, full, ldfull, y, ldy, p, transpose, ws.opws, ws.opws_bytes, stream);
-}
 
 // ------------------------------------------------------------------------------------------------
 // drivers

@@ -145,6 +145,11 @@ SYMBOLS = {
     "mfx_slq_quadform_bwd": (_I, [_P, _P, _P, _P, _P, _I64, _I64, _I, _P, _P, _I64, _P]),
     "mfx_rademacher": (_I, [C.c_uint64, _I64, _I64, _I64, _I, _P, _P]),
     "mfx_pcg_workspace_bytes": (_I64, [_OPP, _I64, _I64, _I64]),
+    "mfx_pcg_sharded_workspace_bytes": (_I64, [_OPP, _CMP, _I64, _I64, _I64]),
+    "mfx_pcg_solve_sharded": (
+        _I,
+        [_OPP, _CMP, _P, _I64, _I64, _I64, _P, _I64, _P, _P, _I64, _I64, C.c_double, C.c_double, _I, _P, _P, _P, _P, _I64, _P],
+    ),
     "mfx_pcg_solve": (
         _I,
         [_OPP, _P, _I64, _I64, _I64, _P, _I64, _P, _P, _I64, _I64, C.c_double, C.c_double, _I, _P, _P, _P, _P, _I64, _P],

@@ -9,7 +9,9 @@ Same functional surface as the reference's ``matfree_extensions/cg.py``:
 with the whole iteration (cg.py:27-58, 85-135) executed by libmfx (``mfx_pcg_solve``).  ``A`` is a native operator
 (``op.bind(*params)``) or any callable ``A(v)``; ``b`` may be a batch (p, n) of right-hand sides (each is solved
 independently, adaptive stopping included).  ``P`` is ``low_rank.Preconditioner.bind(s)`` (or ``None``): arbitrary Python
-preconditioners are not supported inside the HIP loop.
+preconditioners are not supported inside the HIP loop.  ``A`` may be an ``operators.RowShardedOp`` (bound): ``b``, ``x`` and the
+residuals are then this rank's rows, ``P`` is the same (replicated) preconditioner object on every rank -- its rows are taken
+here -- and the loop runs in ``mfx_pcg_solve_sharded`` (not for the re-orthogonalising variant).
 
 Differentiation is the rule of ``jax.lax.custom_linear_solve(..., symmetric=True)`` (cg.py:23-25): the cotangent of the
 right-hand side is another solve with the same solver, the cotangent of the operator's parameters is the parameter sweep
@@ -89,8 +91,8 @@ def pcg_adaptive(*, atol: float, rtol, maxiter: int, miniter: int = 0):
 
 def _solve(A, b, P, cfg):
     op, bound = as_operator(A)
-    if isinstance(op, RowShardedOp):
-        raise NotImplementedError("PCG is not row-sharded in the MI355X build: pass the operator itself (all rows on one GPU)")
+    if isinstance(op, RowShardedOp) and cfg.get("reortho", False):
+        raise NotImplementedError("the re-orthogonalising PCG variant is not row-sharded in the MI355X build")
     params = tuple(bound) if bound is not None else ()
     if P is not None and not isinstance(P, BoundPreconditioner):
         raise TypeError("P must be None or low_rank.Preconditioner.bind(s): the PCG loop runs inside libmfx and "
@@ -104,8 +106,47 @@ def _solve(A, b, P, cfg):
     return x, r, steps
 
 
+def _run_sharded(sop, cfg, P, B, cparams):
+    """One mfx_pcg_solve_sharded call: B, x, r are this rank's rows; steps replicated."""
+    lib = _lib.get()
+    op, comm = sop.op, sop.comm
+    B = B.contiguous()
+    p, nrows = B.shape
+    n = comm.n
+    if nrows != comm.nrows:
+        raise ValueError(f"row-sharded operator: expected this rank's {comm.nrows} rows of the right-hand side, got {nrows}")
+    dt, dev = B.dtype, B.device
+    desc = op.descriptor(cparams, dt, n)
+    rank, lt, minv, shift = 0, None, None, None
+    if P is not None:
+        pre = P.pre
+        if pre.n != n or pre.lt.dtype != dt:
+            raise ValueError(f"preconditioner of size {pre.n} ({pre.lt.dtype}) used for a system of size {n} ({dt})")
+        rank = pre.rank
+        lt = pre.lt[:, comm.row0 : comm.row0 + comm.nrows].contiguous()  # this rank's columns of L^T
+        minv, shift = pre.minv(P.s)  # from the whole L: replicated
+    cm0 = _lib.Comm()
+    cm0.rank, cm0.world, cm0.nloc = comm.rank, comm.world, comm.nloc
+    ws = _lib.scratch(int(lib.mfx_pcg_sharded_workspace_bytes(C.byref(desc), C.byref(cm0), n, p, rank)), dev)
+    x = torch.empty_like(B)
+    r = torch.empty_like(B)
+    steps = torch.empty((p,), dtype=torch.int64, device=dev)
+    cm, keep = comm.struct(ws, tensors=(), plans=sop.plans)
+    with _lib.busy(ws):
+        rc = lib.mfx_pcg_solve_sharded(C.byref(desc), C.byref(cm), _lib.ptr(B), nrows, n, p, _lib.ptr(lt), rank, _lib.ptr(minv),
+                                       _lib.ptr(shift), cfg["maxiter"], cfg["miniter"], cfg["atol"], cfg["rtol"],
+                                       int(cfg["adaptive"]), _lib.ptr(x), _lib.ptr(r), _lib.ptr(steps), _lib.ptr(ws), ws.numel(),
+                                       _lib.stream_ptr(dev))
+    if keep[2]:
+        raise keep[2][0]
+    _lib.check(rc)
+    return x, r, steps
+
+
 def _run(op, cfg, P, B, cparams):
     """One mfx_pcg_solve call on detached tensors -> (x, r, steps)."""
+    if isinstance(op, RowShardedOp):
+        return _run_sharded(op, cfg, P, B, cparams)
     lib = _lib.get()
     B = B.contiguous()
     p, n = B.shape
@@ -173,7 +214,24 @@ class _PcgFn(torch.autograd.Function):
         op = ctx.op
         lam, _r, _s = _run(op, ctx.cfg, ctx.P, dx, cparams)  # symmetric=True: the transpose solve is the same solve
         p, n = x.shape
-        if isinstance(op, CallbackOp):
+        if isinstance(op, RowShardedOp):  # this rank's rows of -lambda against ALL entries of x; partial sums -> one all-reduce
+            nat, comm = op.op, op.comm
+            desc = nat.descriptor(cparams, x.dtype, comm.n)
+            desc.row0, desc.nrows = comm.row0, comm.nrows
+            gstruct, grads = nat.new_grads(*cparams)
+            ws = _lib.workspace(desc, comm.n, 1, p, x.device)
+            L = (-lam).contiguous()
+            xfull = comm.gather_rows(x)
+            _lib.check(_lib.get().mfx_op_vjp_params(C.byref(desc), _lib.ptr(L), comm.nrows, _lib.ptr(xfull), comm.n, p,
+                                                    C.byref(gstruct), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(x.device)))
+            if comm.world > 1 and grads:
+                flat = torch.cat([g.reshape(-1) for g in grads])
+                comm.all_reduce_(flat)
+                off = 0
+                for g in grads:
+                    g.copy_(flat[off : off + g.numel()].reshape(g.shape))
+                    off += g.numel()
+        elif isinstance(op, CallbackOp):
             grads = []
             diff_idx = [i for i, q in enumerate(cparams) if torch.is_tensor(q) and q.is_floating_point()]
             acc = {i: torch.zeros_like(cparams[i]) for i in diff_idx}

@@ -319,6 +319,17 @@ int mfx_pcg_solve(const mfx_operator* op, const void* b, int64_t ldb, int64_t n,
                   int adaptive, void* x, void* r, void* num_steps, void* ws, int64_t ws_bytes,
                   void* stream);
 
+/* mfx_pcg_solve on row shards (cg.py:19-137, rows partitioned as util/gp_util.py:496-509): b, x, r hold this rank's rows
+ * (p, nrows; ldb >= nrows); precond_lt holds this rank's COLUMNS of L^T, (rank, nrows) row-major; minv, shift replicated (built
+ * from the whole L).  Per iteration: one all-gather of the search direction, and p.Ap, r.z, the adaptive error sum and L^T r as
+ * small all-reduces -- every rank sees the same scalars, takes the same steps and stops at the same iteration.  num_steps is
+ * replicated.  The re-orthogonalising variant is not sharded. */
+int64_t mfx_pcg_sharded_workspace_bytes(const mfx_operator* op, const mfx_comm* comm, int64_t n, int64_t p, int64_t rank);
+int mfx_pcg_solve_sharded(const mfx_operator* op, const mfx_comm* comm, const void* b, int64_t ldb, int64_t n, int64_t p,
+                          const void* precond_lt, int64_t rank, const void* precond_minv, const void* precond_shift,
+                          int64_t maxiter, int64_t miniter, double atol, double rtol, int adaptive, void* x, void* r,
+                          void* num_steps, void* ws, int64_t ws_bytes, void* stream);
+
 /* Fixed-step PCG that re-orthogonalises the residual against the stored, normalised earlier residuals each step
  * (cg.pcg_fixed_step_reortho, cg.py:140-219): q (p, num_matvecs, n) receives the rows r_i / sqrt(r_i . z_i), the
  * transpose of the reference's info["Q"].  Workspace: mfx_pcg_workspace_bytes with rank = max(rank, num_matvecs). */

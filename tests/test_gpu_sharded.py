@@ -434,6 +434,86 @@ def test_row_sharded_three_term_recurrence_and_adjoint(tmp_path, kind):
         assert torch.allclose(a, b.grad.cpu(), rtol=1e-8, atol=1e-10 * b.grad.abs().max().item()), (a, b.grad)
 
 
+# ---- (preconditioned) conjugate gradients on row shards (cg.py:19-137) ---------------------------------------------------
+_CG = (1900, 5, 3, 12)  # n, d, right-hand sides, preconditioner rank
+
+
+def _cg_problem():
+    n, d, p, rank = _CG
+    g = torch.Generator().manual_seed(31)
+    op, params = _rbf(n, d, torch.float64, "fp32", ard=True, seed=6)
+    params[2] = torch.tensor(0.5, dtype=torch.float64, device=_dev())  # a noise level CG converges on in tens of steps
+    B = torch.randn((p, n), generator=g, dtype=torch.float64).to(_dev())
+    W = torch.randn((p, n), generator=g, dtype=torch.float64).to(_dev())
+    return op, params, B, W
+
+
+def _cg_solve(matvec_op, params, B, W, rows=slice(None)):
+    """-> {fixed-step PCG solution + its gradients, adaptive CG solution + step counts}; B, W: the rows this caller holds."""
+    from matfree_extensions import cg, low_rank
+
+    n, _, _, rank = _CG
+    ps = [q.clone().requires_grad_(True) for q in params]
+    b = B.clone().requires_grad_(True)
+    native = getattr(matvec_op, "op", matvec_op)
+    with torch.no_grad():  # the preconditioner: replicated, from the whole operator (every rank builds the same one)
+        pre, _ = low_rank.preconditioner(low_rank.cholesky_partial_pivot(rank=rank))(low_rank.without_noise(native.bind(*params)), n)
+        noise = native.constrain(*params)[2]
+    x, info = cg.pcg_fixed_step(8)(matvec_op.bind(*ps), b, pre.bind(noise))
+    (x * W).sum().backward()
+    with torch.no_grad():
+        xa, ainfo = cg.cg_adaptive(atol=1e-8, rtol=0.0, maxiter=300, miniter=2)(matvec_op.bind(*params), B)
+    return {"x": x.detach(), "db": b.grad, "grads": [q.grad for q in ps], "xa": xa, "steps": ainfo["num_steps"],
+            "res": info["residual_abs"].detach()}
+
+
+def _cg_worker(rank, world, port, out):
+    for p in (ROOT, os.path.join(ROOT, "experiments-lanczos-adjoints_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import datetime
+
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    from matfree_extensions.distributed import RowComm
+    from matfree_extensions.operators import RowShardedOp
+
+    op, params, B, W = _cg_problem()
+    comm = RowComm(_CG[0])
+    got = _cg_solve(RowShardedOp(op, comm), params, comm.rows(B), comm.rows(W))
+    torch.cuda.synchronize()
+    full = {k: comm.gather_rows(got[k]).cpu() for k in ("x", "db", "xa", "res")}
+    full["grads"] = [g.cpu() for g in got["grads"]]
+    full["steps"] = got["steps"].cpu()
+    if rank == world - 1:
+        torch.save(full, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_sharded_pcg_and_its_gradient_rule(tmp_path):
+    """pcg_fixed_step with the Woodbury preconditioner (solution, residual, d/db, parameter gradients) and cg_adaptive (solution,
+    step counts) on 3 processes against the single-process solver, fp64."""
+    import torch.multiprocessing as mp
+
+    op, params, B, W = _cg_problem()
+    want = _cg_solve(op, params, B, W)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "cg.pt")
+    mp.spawn(_cg_worker, args=(3, port, out), nprocs=3, join=True)
+    got = torch.load(out)
+    for key, tol in (("x", 1e-9), ("res", 1e-7), ("db", 1e-8), ("xa", 1e-7)):
+        w = want[key].cpu()
+        assert torch.allclose(got[key], w, rtol=tol, atol=tol * w.abs().max().item()), key
+    assert torch.equal(got["steps"], want["steps"].cpu())
+    for a, b in zip(got["grads"], want["grads"]):
+        assert torch.allclose(a, b.cpu(), rtol=1e-7, atol=1e-9 * b.abs().max().item()), (a, b)
+
+
 def test_rccl_one_rank_group_runs_the_collective_callbacks():
     """RCCL needs one GPU per rank, so the multi-rank runs of this file go through gloo and the host.  What a one-GPU box CAN
     check of the RCCL path: a one-rank "nccl" group with the collectives forced through it -- all_reduce / all_gather_into_tensor on
