@@ -75,6 +75,40 @@ def test_csr_op(dtype, tol):
     assert close(gvals, ref[order.numpy()], tol)
 
 
+@pytest.mark.parametrize("skew", ["dense_row_and_column", "short_rows"])
+def test_csr_skewed_rows_pick_the_step_kernel_by_the_longest_row(skew):
+    """One dense row and one dense column over a banded matrix (mean row length 5, longest 1500): libmfx decides fused-step vs
+    8-lanes-per-row kernels on `mfx_operator.max_row_nnz` (mean-based, this matrix would serialise a whole row in one lane);
+    the banded matrix alone stays on the fused step.  Arnoldi forward + adjoint and the three-term pair against the oracle, fp64."""
+    n, k = 1500, 9
+    rng = np.random.default_rng(8)
+    rows, cols = [np.arange(n)] * 3, [np.arange(n), (np.arange(n) + 1) % n, (np.arange(n) - 1) % n]
+    if skew == "dense_row_and_column":
+        rows += [np.full(n, 700), np.arange(n)]
+        cols += [np.arange(n), np.full(n, 31)]
+    r, c = np.concatenate(rows), np.concatenate(cols)
+    key = np.unique(r * n + c)
+    r, c = key // n, key % n
+    vals = rng.standard_normal(len(r)) * 0.2 + np.where(r == c, 4.0, 0.0)
+    op, v_dev, order = CsrOp.from_coo(r, c, vals, n, DEV)
+    assert (op.max_row_nnz > 64) == (skew == "dense_row_and_column")
+    o = orc.CooOp(r, c, n)
+    v = rng.standard_normal(n)
+    wQ, wH = rng.standard_normal((n, k)), rng.standard_normal((k, k))
+    vt, pt = T(v, grad=True), v_dev.to(torch.float64).requires_grad_(True)
+    Q, H, rr, cc = arnoldi.hessenberg(op, k, reortho="full")(vt, pt)
+    ((Q * T(wQ)).sum() + (H * T(wH)).sum()).backward()
+    Qo, Ho, ro, co = orc.arnoldi_forward(o, k, v, vals, reortho="full")
+    assert close(Q, Qo, 1e-10) and close(H, Ho, 1e-10)
+    dv, dp = orc.arnoldi_adjoint(o, (vals,), Q=Qo, H=Ho, r=ro, c=co, dQ=wQ, dH=wH, dr=np.zeros(n), dc=0.0, reortho="full")
+    assert close(vt.grad, dv, 1e-8) and close(pt.grad, dp[0][order.numpy()], 1e-8)
+    # three-term recurrence on the symmetrised values (same structure: the pattern is symmetric by construction of the band;
+    # the dense row / column make it non-symmetric, which the forward does not mind)
+    (xs, (al, be)), _ = lanczos.tridiag(op, k, reortho="none")(T(v), v_dev.to(torch.float64))
+    (xo, (ao, bo)), _ = orc.tridiag(o, k, v, vals, reortho="none")
+    assert close(al, ao, 1e-9) and close(be, bo, 1e-9) and close(xs, xo, 1e-8)
+
+
 @pytest.mark.parametrize("dtype,tol,precision", [(torch.float64, 1e-11, "fp32"), (torch.float32, 5e-5, "fp32"),
                                                  (torch.float32, 5e-5, "f16x3-matvec"), (torch.float32, 5e-5, "f16x3")])
 @pytest.mark.parametrize("kernel", ["rbf", "matern32", "matern12"])

@@ -1,12 +1,12 @@
 #!/bin/bash
 # one PMC pass over the Gram matvec (C4 shape, 64 vectors): shader cycles, clock and matrix-pipe share of the kernel whose name
-# contains $1 (default pc_apply).  MFX_* environment selects the kernel / the build.   usage: tools/prof_cycles.sh [filter] [tag]
+# contains $1 (default pc_apply).  MFX_* environment selects the kernel / the build, P the number of vectors (default 64).   usage: [P=32] tools/prof_cycles.sh [filter] [tag]
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 FILTER=${1:-pc_apply}
 OUT=/tmp/prof_cycles_$$
 rm -rf $OUT && mkdir -p $OUT
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $OUT -- python3 $R/tools/bench_matvec_one.py 64 6 > $OUT/log 2>&1 || { tail -5 $OUT/log; exit 1; }
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $OUT -- python3 $R/tools/bench_matvec_one.py ${P:-64} 6 > $OUT/log 2>&1 || { tail -5 $OUT/log; exit 1; }
 python3 - "$OUT" "$FILTER" "${2:-}" <<'PY'
 import csv, sys, glob, collections
 out, filt, tag = sys.argv[1:4]
