@@ -68,6 +68,17 @@ struct FatPlan<1> {
   static constexpr int slot_of(int m) { return m < 3 ? m : (m == 3 ? 4 : m + 2); }
 };
 
+#ifndef MFX_FAT_FP8_EMU
+#define MFX_FAT_FP8_EMU 0
+#endif
+// f16 values rounded (to nearest, in magnitude) to the 3 mantissa bits of an e4m3 number, still held as f16
+__device__ __forceinline__ half8 fp8_round(half8 v) {
+  uintx4 u = __builtin_bit_cast(uintx4, v);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) u[i] = (u[i] + 0x00400040u) & 0xFF80FF80u;
+  return __builtin_bit_cast(half8, u);
+}
+
 template <int DPAD, int NB>
 struct FatSmem {
   static constexpr int KD = DPAD + 2;
@@ -291,8 +302,19 @@ __global__ __launch_bounds__(256, 1) void k_rbf_fat_apply(const float* __restric
         } else {
           const int m = Plan::contr_m(slot);
           const int s = m / (3 * NB), nb = (m / 3) % NB, w = m % 3;
+#if MFX_FAT_FP8_EMU
+          // ACCURACY experiment (never a product build): what the cross products hi lo and lo hi would carry on the FP8 MFMA --
+          // both operands rounded to 3 mantissa bits (e4m3; range ignored, as under block scaling)
+          half8 opa = w == 2 ? alc[s] : ahc[s], opb = w == 1 ? vf[s][nb][1] : vf[s][nb][0];
+          if (w != 0) {
+            opa = fp8_round(opa);
+            opb = fp8_round(opb);
+          }
+          acc[mi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(opa, opb, acc[mi][nb], 0, 0, 0);
+#else
           acc[mi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w == 2 ? alc[s] : ahc[s], w == 1 ? vf[s][nb][1] : vf[s][nb][0],
                                                                acc[mi][nb], 0, 0, 0);
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
         split_slot(slot, 1, wc, ahc, alc, lpc, neg_c);  // this block's late pairs first (their consumers are a few slots away)
