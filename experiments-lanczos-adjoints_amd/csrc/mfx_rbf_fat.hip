@@ -306,11 +306,23 @@ __global__ __launch_bounds__(256, 1) void k_rbf_fat_apply(const float* __restric
           // ACCURACY experiment (never a product build): what the cross products hi lo and lo hi would carry on the FP8 MFMA --
           // both operands rounded to 3 mantissa bits (e4m3; range ignored, as under block scaling)
           half8 opa = w == 2 ? alc[s] : ahc[s], opb = w == 1 ? vf[s][nb][1] : vf[s][nb][0];
-          if (w != 0) {
+          if (MFX_FAT_FP8_EMU == 1 && w != 0) {
             opa = fp8_round(opa);
             opb = fp8_round(opb);
           }
-          acc[mi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(opa, opb, acc[mi][nb], 0, 0, 0);
+          // 2: no hi(K) lo(V) product at all (the probes as plain f16); 3: only that product on FP8 precision
+          if (MFX_FAT_FP8_EMU == 3 && w == 1) {
+            opa = fp8_round(opa);
+            opb = fp8_round(opb);
+          }
+          if (MFX_FAT_FP8_EMU == 4 && w == 1) {  // hi(K) on e5m2 precision (2 mantissa bits: the top byte of the f16), lo(V) on e4m3
+            uintx4 u = __builtin_bit_cast(uintx4, opa);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) u[i] = (u[i] + 0x00800080u) & 0xFF00FF00u;
+            opa = __builtin_bit_cast(half8, u);
+            opb = fp8_round(opb);
+          }
+          if (!(MFX_FAT_FP8_EMU == 2 && w == 1)) acc[mi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(opa, opb, acc[mi][nb], 0, 0, 0);
 #else
           acc[mi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w == 2 ? alc[s] : ahc[s], w == 1 ? vf[s][nb][1] : vf[s][nb][0],
                                                                acc[mi][nb], 0, 0, 0);

@@ -38,6 +38,9 @@ __device__ __forceinline__ void chain_op(float (&w)[16], half8 (&ah)[2], half8 (
 }
 
 // SHAPE 0: 32x32x16, 14 slots per block.  SHAPE 1: 16x16x32, 28 slots per block.
+// SHAPE 2: the hi(K) lo(V) product on the block-scaled FP8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, k = 64 = BOTH column blocks of a
+// tile, 64 cycles): even blocks 8 contraction + 2 distance f16 MFMAs, odd blocks the same + 2 FP8 MFMAs; 8 more VALU instructions per
+// block (v_cvt_scalef32_pk_fp8_f32 of hi(K)).  Accuracy of that arithmetic: profiles/r03j_*.
 template <int SHAPE, int CHAIN>
 __global__ __launch_bounds__(256, 1) void k(const _Float16* __restrict__ rnd, float* out, long long* cyc, int blocks) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -52,9 +55,9 @@ __global__ __launch_bounds__(256, 1) void k(const _Float16* __restrict__ rnd, fl
   float agpr_seed = 0.f;
   asm volatile("; agpr" : "+a"(agpr_seed));
   constexpr int NACC = 8;  // 128 accumulator registers either way: 8 x floatx16 or 32 x floatx4
-  floatx16 acc16[SHAPE == 0 ? NACC : 1];
+  floatx16 acc16[SHAPE != 1 ? NACC : 1];
   floatx4 acc4[SHAPE == 1 ? 4 * NACC : 1];
-  for (int q = 0; q < (SHAPE == 0 ? NACC : 1); ++q)
+  for (int q = 0; q < (SHAPE != 1 ? NACC : 1); ++q)
     for (int r = 0; r < 16; ++r) acc16[q][r] = 0.f;
   for (int q = 0; q < (SHAPE == 1 ? 4 * NACC : 1); ++q)
     for (int r = 0; r < 4; ++r) acc4[q][r] = 0.f;
@@ -78,6 +81,13 @@ __global__ __launch_bounds__(256, 1) void k(const _Float16* __restrict__ rnd, fl
   }
   for (int q = 0; q < 16; ++q) wn[q] = -0.5f * (float)(q + 1) - 1e-3f * lane;
   for (int q = 0; q < 8; ++q) lp[q] = 0;
+  typedef int intx8 __attribute__((ext_vector_type(8)));
+  typedef short shortx2 __attribute__((ext_vector_type(2)));
+  intx8 kq = {0, 0, 0, 0, 0, 0, 0, 0}, vq[2];
+  for (int q = 0; q < 2; ++q) {
+    vq[q] = *reinterpret_cast<const intx8*>(smem + lane * 32 + q * 2048);
+    for (int i = 0; i < 8; ++i) vq[q][i] &= (int)0xBFBFBFBF;  // random bytes as e4m3, top exponent bit cleared: no NaN encodings
+  }
   constexpr int NSLOT = SHAPE == 0 ? 14 : 28;
   // placement of the 40 chain steps: exp i behind slot e[i], hi-cvt of pair p behind h[p], mix step i behind m[i] (in units of slots of THIS shape)
   const long long t0 = __builtin_readcyclecounter();
@@ -85,10 +95,26 @@ __global__ __launch_bounds__(256, 1) void k(const _Float16* __restrict__ rnd, fl
     const char* vb = base + (b4 & 3) * 12288;  // other probe fragments every four blocks
    auto body = [&](auto bc) {   // (compile-time block position: every register index below is static)
     constexpr int b = decltype(bc)::value;
+    constexpr int NS = SHAPE == 2 ? ((b & 1) ? 12 : 10) : NSLOT;
 #pragma unroll
-    for (int slot = 0; slot < NSLOT; ++slot) {
+    for (int slot = 0; slot < NS; ++slot) {
       __builtin_amdgcn_sched_barrier(0);
-      if (SHAPE == 0) {
+      if (SHAPE == 2) {
+        if (slot == 6 || slot == 8) {
+          const int q = (slot - 6) / 2;
+          if (q == 0) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(wd16) : "a"(aj[q]), "a"(bi[q]));
+          else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(wd16) : "a"(aj[q]), "a"(bi[q]));
+        } else if (slot >= 10) {  // odd blocks: hi(K) lo(V) of the whole tile, one FP8 MFMA per probe block
+          const int nb = slot - 10;
+          const int a = ((b & 3) >> 1) * 4 + 2 + nb;  // (the model keeps 8 accumulators busy; which one is immaterial)
+          acc16[a] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kq, vq[nb], acc16[a], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        } else {
+          const int m = slot < 6 ? slot : (slot == 7 ? 6 : 7);  // 8 contraction MFMAs: (s, nb, hi hi / lo hi)
+          const int s = m / 4, nb = (m / 2) % 2, w = m % 2;
+          const int a = (b & 3) * 2 + nb;
+          acc16[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w == 1 ? alc[s] : ahc[s], vf[s * 4 + nb * 2], acc16[a], 0, 0, 0);
+        }
+      } else if (SHAPE == 0) {
         if (slot == 10 || slot == 12) {
           const int q = (slot - 10) / 2;
           if (q == 0) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(wd16) : "a"(aj[q]), "a"(bi[q]));
@@ -120,18 +146,30 @@ __global__ __launch_bounds__(256, 1) void k(const _Float16* __restrict__ rnd, fl
         constexpr int e1[16] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15};
         constexpr int h1[8] = {16, 16, 17, 17, 22, 22, 23, 23};
         constexpr int m1[16] = {18, 19, 18, 19, 20, 21, 20, 21, 24, 25, 24, 25, 26, 27, 26, 27};
+        // SHAPE 2: the 14-slot table squeezed onto this block's NS slots
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-          if ((SHAPE == 0 ? e0[i] : e1[i]) % NSLOT == slot) chain_op(wn, ahn, aln, lp, 0, i);
+          if ((SHAPE == 2 ? (e0[i] % 14) * NS / 14 : (SHAPE == 0 ? e0[i] : e1[i]) % NSLOT) == slot) chain_op(wn, ahn, aln, lp, 0, i);
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-          if ((SHAPE == 0 ? h0[i] : h1[i]) % NSLOT == slot) chain_op(wn, ahn, aln, lp, 1, i);
+          if ((SHAPE == 2 ? (h0[i] % 14) * NS / 14 : (SHAPE == 0 ? h0[i] : h1[i]) % NSLOT) == slot) chain_op(wn, ahn, aln, lp, 1, i);
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-          if ((SHAPE == 0 ? m0[i] : m1[i]) % NSLOT == slot) chain_op(wn, ahn, aln, lp, 2, i);
+          if ((SHAPE == 2 ? (m0[i] % 14) * NS / 14 : (SHAPE == 0 ? m0[i] : m1[i]) % NSLOT) == slot) chain_op(wn, ahn, aln, lp, 2, i);
+        if (SHAPE == 2 && slot < 8) {  // hi(K) of this block as e4m3: two entries per instruction into its 16-bit half of the operand
+          shortx2 pk = __builtin_bit_cast(shortx2, kq[(b & 1) * 4 + slot / 2]);
+          if (slot & 1) pk = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(pk, wn[2 * slot], wn[2 * slot + 1], 128.0f, true);
+          else pk = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(pk, wn[2 * slot], wn[2 * slot + 1], 128.0f, false);
+          kq[(b & 1) * 4 + slot / 2] = __builtin_bit_cast(int, pk);
+        }
       }
       // probe fragments of the next column block, one read per slot in the block before a column block starts
-      if ((b & 3) == 3 && slot < 8) vf[slot] = *reinterpret_cast<const half8*>(vb + slot * 1024 + 1024);
+      if ((b & 3) == 3 && slot < 8 && (SHAPE != 2 || (slot & 1) == 0)) vf[slot] = *reinterpret_cast<const half8*>(vb + slot * 1024 + 1024);
+      if (SHAPE == 2 && (b & 3) == 3 && slot >= 8 && slot < 10) {
+        vq[slot - 8] = *reinterpret_cast<const intx8*>(vb + lane * 16 + (slot - 8) * 2048 + 512);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) vq[slot - 8][i] &= (int)0xBFBFBFBF;
+      }
       if ((b & 3) == 1 && slot < 2) aj[slot] = *reinterpret_cast<const half8*>(vb + (9 + slot) * 1024);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -153,7 +191,7 @@ __global__ __launch_bounds__(256, 1) void k(const _Float16* __restrict__ rnd, fl
   const long long t1 = __builtin_readcyclecounter();
   if (tid == 0) cyc[blockIdx.x] = t1 - t0;
   float s = 0;
-  for (int q = 0; q < (SHAPE == 0 ? NACC : 1); ++q)
+  for (int q = 0; q < (SHAPE != 1 ? NACC : 1); ++q)
     for (int r = 0; r < 16; ++r) s += acc16[q][r];
   for (int q = 0; q < (SHAPE == 1 ? 4 * NACC : 1); ++q)
     for (int r = 0; r < 4; ++r) s += acc4[q][r];
@@ -202,6 +240,8 @@ int main() {
   hipMalloc(&rnd, n * 2);
   hipMemcpy(rnd, h, n * 2, hipMemcpyHostToDevice);
   for (int rep = 0; rep < 2; ++rep) {
+    run<2, 1>("32x32x16 + FP8 hi lo + chain", rnd);
+    run<2, 0>("32x32x16 + FP8 hi lo, MFMAs", rnd);
     run<0, 1>("32x32x16 + chain", rnd);
     run<1, 1>("16x16x32 + chain", rnd);
     run<0, 0>("32x32x16, MFMAs only", rnd);
