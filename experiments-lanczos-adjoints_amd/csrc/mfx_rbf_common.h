@@ -48,7 +48,10 @@ constexpr float kKShift = 15.f;
 // spare registers: no partial sums through HBM.  (Round 2 first cut the sweep into 16 column splits with partial sums in HBM:
 // same accuracy, +7.6 % per matvec and 1.1 GB of extra traffic per launch; negating the accumulators in registers instead of
 // restarting them did nothing.)
-constexpr int kChainTiles = 128;
+#ifndef MFX_CHAIN_TILES
+#define MFX_CHAIN_TILES 128
+#endif
+constexpr int kChainTiles = MFX_CHAIN_TILES;
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));  // 16-B pack as a native vector (HIP's uint4 struct went to scratch)
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
