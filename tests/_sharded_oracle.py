@@ -113,3 +113,81 @@ def integrand_value_and_grad(op, k, v0_local, params):
     dH = np.diag(ddiag) + 0.5 * (np.diag(doff, 1) + np.diag(doff, -1))
     _, dparams = arnoldi_adjoint(op, params, Q=Q, H=H, r=r, c=c, dH=dH)
     return scale**2 * g, tuple(scale**2 * d for d in dparams)
+
+
+# ---- the three-term recurrence and its adjoint on row shards (oracle tridiag_none :345-362, tridiag_none_vjp :365-390) ------------
+def tridiag_none(op, k, v, *params):
+    """xs (k + 1, nrows) row shards, a, b (k,) replicated -- the layout of mfx_lanczos_forward_sharded"""
+    nrows = v.shape[0]
+    xs = np.zeros((k + 1, nrows))
+    a, b = np.zeros(k), np.zeros(k)
+    vnorm = np.sqrt(op.allsum(v @ v))
+    xs[0] = v / vnorm
+    prev, bprev = np.zeros_like(v), 0.0
+    for i in range(k):
+        w = op.apply_rows(xs[i], *params)
+        a[i] = op.allsum(xs[i] @ w)
+        rr = w - a[i] * xs[i] - bprev * prev
+        b[i] = np.sqrt(op.allsum(rr @ rr))
+        xs[i + 1] = rr / b[i]
+        prev, bprev = xs[i], b[i]
+    return xs, a, b, vnorm
+
+
+def tridiag_none_vjp(op, k, params, xs, a, b, vnorm, dxs, da, db):
+    """cotangents dxs (k + 1, nrows) local, da, db (k,) replicated -> (dv local, parameter gradients complete)"""
+    xi = -dxs[-1]
+    lam_plus = np.zeros_like(xi)
+    lams, cots = [], []
+    for j in range(k - 1, -1, -1):
+        xplus, x = xs[j + 1], xs[j]
+        xi = xi / b[j]
+        d = op.allsum(np.array([lam_plus @ x, xplus @ xi, x @ xi]))  # the three dots of a step: ONE all-reduce
+        mu = db[j] - d[0] + d[1]
+        nu = da[j] + d[2]
+        lam = -xi + mu * xplus + nu * x
+        Alam = op.apply_rows(lam, *params)
+        lams.append(lam)
+        cots.append(x)
+        xi = -dxs[j] - Alam + a[j] * lam + b[j] * lam_plus - b[j] * nu * xplus
+        lam_plus = lam
+    dvec = (op.allsum(xi @ xs[0]) * xs[0] - xi) / vnorm
+    return dvec, op.param_vjp_rows(np.stack(lams), np.stack(cots), *params)
+
+
+# ---- conjugate gradients on row shards (oracle pcg_fixed_step :587-598, pcg_adaptive :601-618) ----------------------------------------
+def pcg(op, b, params, *, Lt=None, maxiter, adaptive=False, atol=1.0, rtol=0.0, miniter=0):
+    """b, x, r: row shards; Lt: this rank's columns of L^T (rank, nrows) of the Woodbury preconditioner, or None.  Every scalar is an
+    all-reduced sum, so every rank takes the same steps -- the layout of mfx_pcg_solve_sharded."""
+    _, _, noise = op.constrained(*params)
+    if Lt is not None:
+        r_ = Lt.shape[0]
+        minv = np.linalg.inv(noise * np.eye(r_) + op.allsum(Lt @ Lt.T))
+
+    def P(v):
+        if Lt is None:
+            return v
+        return (v - Lt.T @ (minv @ op.allsum(Lt @ v))) / noise
+
+    x = np.zeros_like(b)
+    r = b.copy()
+    z = P(r)
+    p = z
+    rz = op.allsum(r @ z)
+    steps = 0
+    for _ in range(maxiter):
+        if adaptive:
+            err = op.allsum(((r / (atol + np.abs(x) * rtol)) ** 2).sum())
+            if not ((np.sqrt(err / op.comm.n) > 1.0 or steps < miniter) and steps < maxiter):
+                break
+        Ap = op.apply_rows(p, *params)
+        alpha = orc.safe_divide(rz, op.allsum(p @ Ap))
+        x = x + alpha * p
+        r = r - alpha * Ap
+        z = P(r)
+        rz_new = op.allsum(r @ z)
+        p = z + orc.safe_divide(rz_new, rz) * p
+        rz = rz_new
+        steps += 1
+    return x, r, steps
+

@@ -147,6 +147,75 @@ def test_rows_x_probes_grid_2x2_equals_single_process(tmp_path):
     _run_grid(tmp_path, 4, 2)
 
 
+# ---- the other row-sharded drivers: three-term recurrence + adjoint, (P)CG -- decomposition under gloo -----------------------------
+def _lz_cg_worker(rank, world, port, out):
+    _setup_paths()
+    import datetime
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    import _sharded_oracle as so
+    from matfree_extensions.distributed import RowComm
+
+    X, raw, v, cot, b, L = _lz_cg_problem()
+    comm = RowComm(N2)
+    rows = slice(comm.row0, comm.row0 + comm.nrows)
+    op = so.ShardedRbf(X, comm, noise_minval=1e-4)
+    xs, a, bb, vnorm = so.tridiag_none(op, K2, v[rows], *raw)
+    (dxs, da, db) = cot
+    dv, dp = so.tridiag_none_vjp(op, K2, raw, xs, a, bb, vnorm, dxs[:, rows], da, db)
+    x_fix, r_fix, _ = so.pcg(op, b[rows], raw, Lt=L.T[:, rows], maxiter=5)
+    x_ad, _r, steps = so.pcg(op, b[rows], raw, maxiter=200, adaptive=True, atol=1e-8, rtol=0.0, miniter=2)
+    gather = lambda t: comm.gather_rows(torch.as_tensor(np.ascontiguousarray(t))).numpy()
+    got = {"xs": gather(xs), "a": a, "b": bb, "dv": gather(dv), "dp": [float(g) for g in dp], "x_fix": gather(x_fix), "r_fix": gather(r_fix),
+           "x_ad": gather(x_ad), "steps": steps}
+    if rank == world - 1:
+        torch.save(got, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _lz_cg_problem():
+    rng = np.random.default_rng(4)
+    X = rng.standard_normal((N2, D2))
+    raw = (np.array(0.4), np.array(0.2), np.array(-1.0))
+    v = rng.standard_normal(N2)
+    cot = (rng.standard_normal((K2 + 1, N2)), rng.standard_normal(K2), rng.standard_normal(K2))
+    b = rng.standard_normal(N2)
+    L = 0.3 * rng.standard_normal((N2, 5))  # any low-rank factor makes a valid Woodbury preconditioner
+    return X, raw, v, cot, b, L
+
+
+def test_row_sharded_three_term_recurrence_and_pcg_equal_single_process(tmp_path):
+    """tridiag(reortho="none") + its adjoint and (P)CG, restated on row shards with the collectives of mfx_lanczos_*_sharded /
+    mfx_pcg_solve_sharded (one gather per operator application, all-reduced scalars), under gloo with 2 ranks (128 + 72 rows)."""
+    _setup_paths()
+    from oracle import slq_oracle as orc
+
+    X, raw, v, (dxs, da, db), b, L = _lz_cg_problem()
+    o = orc.RbfGramOp(X, noise_minval=1e-4)
+    (xs_, (a, b_)), (xl, bl) = orc.tridiag_none(o, K2, v, *raw)
+    cot = ((dxs[:-1], (da, db[:-1])), (dxs[-1], db[-1]))
+    dv, dp = orc.tridiag_none_vjp(o, K2, v, raw, cot)
+    _, _, noise = o.constrained(*raw)
+    A = lambda u: o.apply(u, *raw)
+    x_fix, info = orc.pcg_fixed_step(A, b, lambda u: orc.precondition_solve(L, u, noise), num_matvecs=5)
+    x_ad, ainfo = orc.pcg_adaptive(A, b, None, atol=1e-8, rtol=0.0, maxiter=200, miniter=2)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "lzcg.pt")
+    mp.spawn(_lz_cg_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=False)
+    assert np.allclose(got["xs"], np.concatenate([xs_, xl[None]]), rtol=1e-10, atol=1e-12)
+    assert np.allclose(got["a"], a, rtol=1e-11) and np.allclose(got["b"], np.concatenate([b_, [bl]]), rtol=1e-11)
+    assert np.allclose(got["dv"], dv, rtol=1e-9, atol=1e-11 * np.abs(dv).max())
+    assert np.allclose(got["dp"], [float(g) for g in dp], rtol=1e-9)
+    assert np.allclose(got["x_fix"], x_fix, rtol=1e-10, atol=1e-12) and np.allclose(got["r_fix"], info["residual_abs"], rtol=1e-8, atol=1e-12)
+    assert got["steps"] == ainfo["num_steps"] and np.allclose(got["x_ad"], x_ad, rtol=1e-7, atol=1e-8 * np.abs(x_ad).max())  # 42 CG steps amplify the different summation order
+
+
 # ---- neighbour exchange plan of a sparse operator (the halo of a stencil) ------------------------------------------------------
 def _halo_worker(rank, world, port, out):
     _setup_paths()
