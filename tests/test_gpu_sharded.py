@@ -434,6 +434,40 @@ def test_row_sharded_three_term_recurrence_and_adjoint(tmp_path, kind):
         assert torch.allclose(a, b.grad.cpu(), rtol=1e-8, atol=1e-10 * b.grad.abs().max().item()), (a, b.grad)
 
 
+@pytest.mark.parametrize("k", [1, 2, 9])
+def test_three_term_and_pcg_with_a_one_rank_communicator_equal_the_single_device_drivers(k):
+    """The sharded drivers with world = 1 (all-gather = copy, all-reduce = identity): depth 1 and 2 (the three dots of an adjoint step need
+    more staging rows than the depth has), adaptive PCG with the preconditioner."""
+    from matfree_extensions import cg, lanczos, low_rank
+    from matfree_extensions.distributed import RowComm
+    from matfree_extensions.operators import RowShardedOp
+
+    n, d, p = 1216, 6, 4
+    op, params = _rbf(n, d, torch.float64, "fp32", ard=True, seed=9)
+    g = torch.Generator().manual_seed(2)
+    V = torch.randn((p, n), generator=g, dtype=torch.float64).to(_dev())
+    sop = RowShardedOp(op, RowComm(n))
+
+    def run(mv):
+        ps = [q.clone().requires_grad_(True) for q in params]
+        v = V.clone().requires_grad_(True)
+        (xs, (al, be)), (xl, bl) = lanczos.tridiag(mv, k, reortho="none")(v, *ps)
+        ((xs ** 2).sum() * 0.5 + (al * be.sum(-1, keepdim=True)).sum() + (xl[:, ::7]).sum() + (bl ** 2).sum()).backward()
+        return [al.detach(), be.detach(), xs.detach(), v.grad] + [q.grad for q in ps]
+
+    for a, b in zip(run(op), run(sop)):
+        assert a.shape == b.shape
+        if a.numel():  # (depth 1 has no off-diagonal)
+            assert torch.allclose(a, b, rtol=1e-10, atol=1e-12 * max(1.0, a.abs().max().item()))
+    with torch.no_grad():
+        pre, _ = low_rank.preconditioner(low_rank.cholesky_partial_pivot(rank=8))(low_rank.without_noise(op.bind(*params)), n)
+        noise = op.constrain(*params)[2]
+        solve = cg.pcg_adaptive(atol=1e-9, rtol=0.0, maxiter=400, miniter=1)
+        x0, i0 = solve(op.bind(*params), V, pre.bind(noise))
+        x1, i1 = solve(sop.bind(*params), V, pre.bind(noise))
+    assert torch.equal(i0["num_steps"], i1["num_steps"]) and torch.allclose(x0, x1, rtol=1e-9, atol=1e-11)
+
+
 # ---- (preconditioned) conjugate gradients on row shards (cg.py:19-137) ---------------------------------------------------
 _CG = (1900, 5, 3, 12)  # n, d, right-hand sides, preconditioner rank
 
