@@ -57,6 +57,21 @@ def main():
     same = torch.equal(v1, v2) and all(torch.equal(a, b) for a, b in zip(g1, g2))
     print("native communicator: values", v2[:3].tolist(), "bit-identical to the callback path:", same)
     ok = ok and same
+    # the other sharded drivers through the native communicator: three-term recurrence + adjoint, (P)CG -- against the callback path
+    from matfree_extensions import cg
+
+    def others(comm_):
+        sop = RowShardedOp(op, comm_)
+        ps = [q.clone().requires_grad_(True) for q in params]
+        (xs, (al, be)), (xl, bl) = lanczos.tridiag(sop, 6, reortho="none")(probes[:3], *ps)
+        ((al * al).sum() + (be * be).sum() + (bl * bl).sum() + xs[:, :, ::5].sum()).backward()
+        with torch.no_grad():
+            x, info = cg.cg_adaptive(atol=1e-5, rtol=0.0, maxiter=100, miniter=1)(sop.bind(*params), probes[:3])
+        return [al.detach(), be.detach(), x, info["num_steps"]] + [q.grad for q in ps]
+
+    same2 = all(torch.equal(a, b) for a, b in zip(others(comm), others(ncomm)))
+    print("native communicator, three-term + CG: bit-identical to the callback path:", same2)
+    ok = ok and same2
     ncomm.close()
     # what Layout does by default on an RCCL group: native communicator after an agreed availability check and self-test; when the
     # self-test (here: made to) fails on a rank, ALL ranks take the torch.distributed callbacks, with a warning
