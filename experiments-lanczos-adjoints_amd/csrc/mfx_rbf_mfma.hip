@@ -1214,6 +1214,16 @@ struct GradSmemH {
 // gradient is 9.8e-6 / 3.0e-5 off fp64, without either 2.2e-2 / 5.6e-2 (profiles/r02h_*) -- so the chunks and the master
 // accumulators are gone, which is what makes room for the 256 x 256 tile.
 
+#ifndef MFX_GRAD_FP8_EMU
+#define MFX_GRAD_FP8_EMU 0
+#endif
+__device__ __forceinline__ half8 fp8_round_h8(half8 v) {  // f16 values rounded to 3 mantissa bits (magnitude, to nearest), still f16
+  uintx4 u = __builtin_bit_cast(uintx4, v);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) u[i] = (u[i] + 0x00400040u) & 0xFF80FF80u;
+  return __builtin_bit_cast(half8, u);
+}
+
 template <int DPAD, int NBW, bool REGEPI>
 __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restrict__ xs, const float* __restrict__ sq,
                                                             int64_t n, int64_t npad_l, int64_t npad_r, int ard, int kind,
@@ -1363,8 +1373,17 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
 #pragma unroll
         for (int b = 0; b < NBW; ++b) {
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+#if MFX_GRAD_FP8_EMU
+          // ACCURACY experiment (never a product build): the cross products with both operands rounded to e4m3 precision (3 mantissa
+          // bits, range ignored) -- 1: both, 2: only hi(L) lo(R), 3: only lo(L) hi(R)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(MFX_GRAD_FP8_EMU != 3 ? fp8_round_h8(ah[a]) : ah[a],
+                                                             MFX_GRAD_FP8_EMU != 3 ? fp8_round_h8(bl[b]) : bl[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(MFX_GRAD_FP8_EMU != 2 ? fp8_round_h8(al[a]) : al[a],
+                                                             MFX_GRAD_FP8_EMU != 2 ? fp8_round_h8(bh[b]) : bh[b], acc[a][b], 0, 0, 0);
+#else
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
+#endif
         }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
