@@ -7,6 +7,7 @@ namespace mfx {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 
 // -log2(e)/2: exp(-dist/2) = exp2(kNegHalfLog2e * dist)

@@ -1180,19 +1180,26 @@ __global__ __launch_bounds__(256) void k_pack_f16(const float* __restrict__ x, i
 constexpr int kHM = 256;
 constexpr int kHLd = kHM + 4;
 
-// NBW = 32-column blocks per wave: the workgroup tile is 256 rows x (2 NBW 32) columns, 8 waves as 4 x 2 of 64 x (NBW 32).
+// NBW = 32-column groups per wave: the workgroup tile is 256 rows x (2 NBW 32) columns, 8 waves as 4 x 2 of 64 x (NBW 32).
 //   NBW = 2: 256 x 128 (round 1);  NBW = 4: 256 x 256 -- (256 + 256) instead of 2 x (256 + 128) operand columns through L2 -> LDS
-//   per stage and per 256 x 256 of S, i.e. a third less of the traffic this kernel is bound by.  Its 128 accumulator registers
+//   per stage and per 256 x 256 of S, i.e. a third less of that traffic.  Its 128 accumulator registers
 //   fit since the fp32 master accumulators are gone (see the note on the floor bias below).
+// Round 4: the contraction runs on v_mfma_f32_16x16x32_f16 (a wave's 64 x (NBW 32) sub-tile = 4 x 2 NBW blocks of 16 x 16, the same 32 NBW
+// accumulator registers): same flops and the same matrix-pipe cycles as on 32x32x16, but the chip holds a HIGHER CLOCK under this shape
+// (tools/gradk_bench.hip, the K-loop alone on one box, alternating: 49.1 ms / 1.45 GHz on 32x32x16, 44.6 ms / 1.61 GHz on 16x16x32, both 90 %
+// matrix pipe; MI355X_MICROARCH.md 'DVFS give-back' item 7).  One wave per SIMD on 128 x 128 (the round-3 plan) was measured there too and
+// is SLOWER (51.9 ms: 88 % pipe with LDS-DMA issued by the computing wave, 82 % with register staging) -- a third fewer fragment bytes from LDS
+// buy no clock.  A stage is now 32 batch rows (one K = 32 MFMA step): two 64-KB LDS images instead of a ring of four 16-row ones.
 template <int DPAD, int NBW, bool REGEPI = false>
 struct GradSmemH {
   static constexpr int TN = 2 * NBW * 32;  // columns of the workgroup tile
+  static constexpr int KQ = (DPAD + 2 + 3) / 4;  // k-steps of the epilogue's distance product (v_mfma_f32_16x16x4_f32)
   union {
     struct {
-      _Float16 a_hi[4][2][kHM][8];  // [ring slot][kb within the 16-row stage][i][8]
-      _Float16 a_lo[4][2][kHM][8];
-      _Float16 b_hi[4][2][TN][8];
-      _Float16 b_lo[4][2][TN][8];
+      _Float16 a_hi[2][4][kHM][8];  // [slot][kb-group within the 32-row stage][i][8]
+      _Float16 a_lo[2][4][kHM][8];
+      _Float16 b_hi[2][4][TN][8];
+      _Float16 b_lo[2][4][TN][8];
     } st;
     float s_t[kGN][kHLd];  // S^T of ONE 128-column pass of the epilogue
   } u;
@@ -1201,7 +1208,7 @@ struct GradSmemH {
   float xj[kGN][DPAD];
   float sqj[kGN];
   float sgj[kGN];  // tau_j of the staged columns (+-1)
-  float bq[REGEPI ? DPAD + 2 : 1][REGEPI ? TN : 1];  // register epilogue: B' = [x_j, 1, |x_j|^2] of the tile's columns, k-major
+  float bq[REGEPI ? 4 * KQ : 1][REGEPI ? TN : 1];  // register epilogue: B' = [x_j, 1, |x_j|^2, 0..] of the tile's columns, k-major
   double red[8][DPAD + 2];
 };
 
@@ -1214,16 +1221,6 @@ struct GradSmemH {
 // gradient is 9.8e-6 / 3.0e-5 off fp64, without either 2.2e-2 / 5.6e-2 (profiles/r02h_*) -- so the chunks and the master
 // accumulators are gone, which is what makes room for the 256 x 256 tile.
 
-#ifndef MFX_GRAD_FP8_EMU
-#define MFX_GRAD_FP8_EMU 0
-#endif
-__device__ __forceinline__ half8 fp8_round_h8(half8 v) {  // f16 values rounded to 3 mantissa bits (magnitude, to nearest), still f16
-  uintx4 u = __builtin_bit_cast(uintx4, v);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) u[i] = (u[i] + 0x00400040u) & 0xFF80FF80u;
-  return __builtin_bit_cast(half8, u);
-}
-
 template <int DPAD, int NBW, bool REGEPI>
 __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restrict__ xs, const float* __restrict__ sq,
                                                             int64_t n, int64_t npad_l, int64_t npad_r, int ard, int kind,
@@ -1235,11 +1232,12 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
   // rows: the nrow points row0 .. of X that the L operand covers (a row shard, or all n); columns: all n points
   using Smem = GradSmemH<DPAD, NBW, REGEPI>;
   constexpr int TN = Smem::TN;
+  constexpr int NB16 = 2 * NBW;  // 16-column blocks of a wave's sub-tile
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   Smem& sm = *reinterpret_cast<Smem*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, lhi = lane >> 5;
+  const int l15 = lane & 15, lq = lane >> 4;
   const int wm = wid >> 1, wn = wid & 1;
   // blockIdx.x = XCD label (workgroups are dealt to XCDs round-robin in linear order); within an XCD, blockIdx.y
   // enumerates (row block, column sub-range) with the sub-range fastest, see kGSub
@@ -1260,130 +1258,98 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
 #pragma unroll
   for (int c = 0; c < NG; ++c) gsum[c] = 0.0;
 
-  // staging by LDS-DMA: per stage 2 kb-groups x (256 | TN) columns x 16 B per operand piece, chunk c lives at byte 16 c of its
-  // piece: no staging registers.  Addresses are 32-bit byte offsets from the (scalar) piece bases, advanced by one constant
-  // per stage.  Ring of FOUR 16-row stages, three of them in flight.  Per stage: wait for MY pieces of stage st (counted
-  // vmcnt: the later stages stay in flight), barrier (everybody's pieces landed AND everybody is done reading stage st - 1),
-  // refill the slot of stage st - 1 with stage st + 3, compute.
-  // Pieces per stage (1 KiB = one wave-instruction): L hi / lo 2 x 256 columns = 8 each (wave w: piece w of both);
-  // R hi / lo 2 x TN columns: TN = 128: 4 each (waves 0-3 hi, 4-7 lo); TN = 256: 8 each (wave w: piece w of both).
-  constexpr int kRPieces = TN / 32;              // 1-KiB pieces of R hi (and of R lo) per stage
-  constexpr int kGlds = kRPieces == 8 ? 4 : 3;   // glds per thread and stage
-  const int64_t nstage = nkb / 2;
-  const uint32_t stage_bytes_l = (uint32_t)(2 * npad_l * 16);  // 2 kb-groups of npad columns x 8 halves
-  const uint32_t stage_bytes_r = (uint32_t)(2 * npad_r * 16);
-  const int cwa = wid * 64 + lane;                          // my chunk of an L piece: kb-group cwa >> 8, column cwa & 255
-  const int cwb = (kRPieces == 8 ? wid : (wid & 3)) * 64 + lane;  // my chunk of an R piece: kb-group cwb / TN, column cwb % TN
-  const uint32_t offL = (uint32_t)((((int64_t)(cwa >> 8) * npad_l) + i0 + (cwa & 255)) * 16);
-  const uint32_t offR0 = (uint32_t)((((int64_t)(cwb / TN) * npad_r) + (cwb % TN)) * 16);
+  // Staging by LDS-DMA, no staging registers: a stage = 4 kb-groups (32 batch rows) x (256 | TN) columns x 16 B per operand image,
+  // 1-KiB pieces (one wave-instruction = 64 columns of one kb-group).  Wave w moves, per stage:
+  //   L hi and lo: columns 64 (w & 3) .., kb-groups (w >> 2) and (w >> 2) + 2                                  -> 4 pieces
+  //   R hi and lo: TN = 256 the same -> 4 pieces;  TN = 128: columns 64 (w & 1) .., kb-group w >> 1             -> 2 pieces
+  // Addresses are 32-bit byte offsets from the (scalar) image bases, advanced by one constant per stage.  TWO slots: the stage
+  // being read and the next one in flight (requested when the last readers of its slot are done, a whole stage = 3072 matrix-pipe
+  // cycles of the SIMD earlier for the lower half of the workgroup, half that for the upper half).
+  const int nstage = (int)(nkb / 4);
+  const uint32_t stage_bytes_l = (uint32_t)(4 * npad_l * 16), stage_bytes_r = (uint32_t)(4 * npad_r * 16);
+  const int lcol = (wid & 3) * 64, lkb = wid >> 2;                          // wave-uniform
+  const int rcol = TN == 256 ? (wid & 3) * 64 : (wid & 1) * 64, rkb = TN == 256 ? (wid >> 2) : (wid >> 1);
+  const uint32_t offL = (uint32_t)(((int64_t)lkb * npad_l + i0 + lcol + lane) * 16);
+  const uint32_t offR0 = (uint32_t)(((int64_t)rkb * npad_r + rcol + lane) * 16);
+  const uint32_t kb2_l = (uint32_t)(2 * npad_l * 16), kb2_r = (uint32_t)(2 * npad_r * 16);
   const char* Lhb = reinterpret_cast<const char*>(Lh);
   const char* Llb = reinterpret_cast<const char*>(Ll);
   const char* Rhb = reinterpret_cast<const char*>(Rh);
   const char* Rlb = reinterpret_cast<const char*>(Rl);
-  const int ca = wid * 64, cb = (kRPieces == 8 ? wid : (wid & 3)) * 64;  // first chunks of this wave's instructions (wave-uniform)
   auto issue_stage = [&](uint32_t l_off, uint32_t r_off, int slot) {
-    glds16(Lhb + l_off, &sm.u.st.a_hi[slot][ca >> 8][ca & 255][0]);
-    glds16(Llb + l_off, &sm.u.st.a_lo[slot][ca >> 8][ca & 255][0]);
-    if constexpr (kRPieces == 8) {
-      glds16(Rhb + r_off, &sm.u.st.b_hi[slot][cb / TN][cb % TN][0]);
-      glds16(Rlb + r_off, &sm.u.st.b_lo[slot][cb / TN][cb % TN][0]);
-    } else {
-      glds16((wid < 4 ? Rhb : Rlb) + r_off, wid < 4 ? &sm.u.st.b_hi[slot][cb / TN][cb % TN][0] : &sm.u.st.b_lo[slot][cb / TN][cb % TN][0]);
+    glds16(Lhb + l_off, &sm.u.st.a_hi[slot][lkb][lcol][0]);
+    glds16(Llb + l_off, &sm.u.st.a_lo[slot][lkb][lcol][0]);
+    glds16(Lhb + l_off + kb2_l, &sm.u.st.a_hi[slot][lkb + 2][lcol][0]);
+    glds16(Llb + l_off + kb2_l, &sm.u.st.a_lo[slot][lkb + 2][lcol][0]);
+    glds16(Rhb + r_off, &sm.u.st.b_hi[slot][rkb][rcol][0]);
+    glds16(Rlb + r_off, &sm.u.st.b_lo[slot][rkb][rcol][0]);
+    if constexpr (TN == 256) {
+      glds16(Rhb + r_off + kb2_r, &sm.u.st.b_hi[slot][rkb + 2][rcol][0]);
+      glds16(Rlb + r_off + kb2_r, &sm.u.st.b_lo[slot][rkb + 2][rcol][0]);
     }
   };
 
   for (int64_t tj = tj_begin; tj < tj_end; ++tj) {
     const int64_t j0 = tj * TN;
-    floatx16 acc[2][NBW];
+    floatx4 acc[4][NB16];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int b = 0; b < NBW; ++b)
+      for (int b = 0; b < NB16; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.f;
 
     uint32_t ol = offL, orr = offR0 + (uint32_t)(j0 * 16);
     if (!REGEPI || tj == tj_begin) {
       __syncthreads();  // previous tile's epilogue reads of the overlaid S^T tile are done
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        if (q < nstage) issue_stage(ol, orr, q);
-        ol += stage_bytes_l;
-        orr += stage_bytes_r;
-      }
-    } else {  // REGEPI: the first three stages of this tile were issued before the previous tile's epilogue
-      ol += 3 * stage_bytes_l;
-      orr += 3 * stage_bytes_r;
-    }
+      issue_stage(ol, orr, 0);
+    }  // (REGEPI: stage 0 of this tile was requested before the previous tile's epilogue)
+    ol += stage_bytes_l;
+    orr += stage_bytes_r;
     // PING-PONG: waves w and w + 4 share a SIMD.  With one barrier per stage all eight waves read their fragments from LDS
-    // together (96 KB per stage: ~770 cycles with the matrix pipe idle) and then queue their MFMAs together.  Here the two
+    // together (192 KB per stage with the matrix pipe idle) and then queue their MFMAs together.  Here the two
     // halves of the workgroup run half a stage apart: two barriers per stage -- B1 before the fragment reads, B2 before the
     // MFMAs -- and the upper half takes one extra barrier first, so that while one wave of a SIMD is in its MFMA cluster
     // (raised priority) the other one is in its read cluster.  Who needs what by when (A = waves 0-3, B = waves 4-7; barrier
     // numbers in A's count: A.B1(st) = 2 st, A.B2(st) = B.B1(st) = 2 st + 1, B.B2(st) = 2 st + 2):
-    //   * stage st + 1 must have landed for everybody before barrier 2 st + 2 (A reads it after that one): every wave waits
-    //     for ITS pieces of stage st + 1 before its B2(st);  stage 0 before the first barrier;
-    //   * the slot of stage st - 1 is free after barrier 2 st (A read it before 2 st - 1, B before 2 st): every wave refills
-    //     it (stage st + 3) after its B1(st).
-    {
-      const int64_t left0 = nstage - 1;  // stages after stage 0 that are in flight
-      if (left0 >= 2) {
-        if constexpr (kGlds == 4) __builtin_amdgcn_s_waitcnt(0x0F78); else __builtin_amdgcn_s_waitcnt(0x0F76);
-      } else if (left0 == 1) {
-        if constexpr (kGlds == 4) __builtin_amdgcn_s_waitcnt(0x0F74); else __builtin_amdgcn_s_waitcnt(0x0F73);
-      } else {
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-      }
-    }
+    //   * A reads stage st between barriers 2 st and 2 st + 1, B between 2 st + 1 and 2 st + 2 (each waits for its reads,
+    //     lgkmcnt(0), before its B2);
+    //   * the slot of stage st - 1 is therefore free after barrier 2 st: every wave requests stage st + 1 into it after its
+    //     B1(st) (A behind barrier 2 st, B behind 2 st + 1);
+    //   * stage st + 1 is first read behind barrier 2 st + 2: every wave waits for ITS pieces (vmcnt(0): nothing younger is in
+    //     flight) before it ARRIVES there -- A before its B1(st + 1), B before its B2(st);  stage 0 before the first barrier.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     if (wid >= 4) __builtin_amdgcn_s_barrier();  // the half-stage offset of the upper half
-    for (int64_t st = 0; st < nstage; ++st) {
-      const int slot = (int)(st & 3);
+    for (int st = 0; st < nstage; ++st) {
+      const int slot = st & 1;
+      if (wid < 4) __builtin_amdgcn_s_waitcnt(0x0F70);  // (A) my pieces of this stage, requested a stage ago
       __builtin_amdgcn_s_barrier();  // B1
-      if (st + 3 < nstage) issue_stage(ol, orr, (int)((st + 3) & 3));
+      if (st + 1 < nstage) issue_stage(ol, orr, slot ^ 1);
       ol += stage_bytes_l;
       orr += stage_bytes_r;
-      half8 ah[2], al[2], bh[NBW], bl[NBW];
+      half8 ah[4], al[4], bh[NB16], bl[NB16];
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        ah[a] = *reinterpret_cast<const half8*>(&sm.u.st.a_hi[slot][lhi][wm * 64 + a * 32 + l31][0]);
-        al[a] = *reinterpret_cast<const half8*>(&sm.u.st.a_lo[slot][lhi][wm * 64 + a * 32 + l31][0]);
+      for (int a = 0; a < 4; ++a) {
+        ah[a] = *reinterpret_cast<const half8*>(&sm.u.st.a_hi[slot][lq][wm * 64 + a * 16 + l15][0]);
+        al[a] = *reinterpret_cast<const half8*>(&sm.u.st.a_lo[slot][lq][wm * 64 + a * 16 + l15][0]);
       }
 #pragma unroll
-      for (int b = 0; b < NBW; ++b) {
-        bh[b] = *reinterpret_cast<const half8*>(&sm.u.st.b_hi[slot][lhi][wn * (NBW * 32) + b * 32 + l31][0]);
-        bl[b] = *reinterpret_cast<const half8*>(&sm.u.st.b_lo[slot][lhi][wn * (NBW * 32) + b * 32 + l31][0]);
-      }
-      // my pieces of stage st + 1 (issued three stages ago); stages st + 2, st + 3 stay in flight
-      const int64_t later = nstage - 2 - st;  // stages after st + 1 that have been issued
-      if (st + 1 < nstage) {
-        if (later >= 2) {
-          if constexpr (kGlds == 4) __builtin_amdgcn_s_waitcnt(0x0F78); else __builtin_amdgcn_s_waitcnt(0x0F76);  // vmcnt(8 | 6)
-        } else if (later == 1) {
-          if constexpr (kGlds == 4) __builtin_amdgcn_s_waitcnt(0x0F74); else __builtin_amdgcn_s_waitcnt(0x0F73);  // vmcnt(4 | 3)
-        } else {
-          __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-        }
+      for (int b = 0; b < NB16; ++b) {
+        bh[b] = *reinterpret_cast<const half8*>(&sm.u.st.b_hi[slot][lq][wn * (NBW * 32) + b * 16 + l15][0]);
+        bl[b] = *reinterpret_cast<const half8*>(&sm.u.st.b_lo[slot][lq][wn * (NBW * 32) + b * 16 + l15][0]);
       }
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the fragments are in registers
+      if (wid >= 4) __builtin_amdgcn_s_waitcnt(0x0F70);  // (B) my pieces of stage st + 1
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();  // B2
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < NBW; ++b) {
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
-#if MFX_GRAD_FP8_EMU
-          // ACCURACY experiment (never a product build): the cross products with both operands rounded to e4m3 precision (3 mantissa
-          // bits, range ignored) -- 1: both, 2: only hi(L) lo(R), 3: only lo(L) hi(R)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(MFX_GRAD_FP8_EMU != 3 ? fp8_round_h8(ah[a]) : ah[a],
-                                                             MFX_GRAD_FP8_EMU != 3 ? fp8_round_h8(bl[b]) : bl[b], acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(MFX_GRAD_FP8_EMU != 2 ? fp8_round_h8(al[a]) : al[a],
-                                                             MFX_GRAD_FP8_EMU != 2 ? fp8_round_h8(bh[b]) : bh[b], acc[a][b], 0, 0, 0);
-#else
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
-#endif
+        for (int b = 0; b < NB16; ++b) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
         }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
@@ -1396,77 +1362,66 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
       int z;
       asm volatile("s_mov_b32 %0, 0" : "=s"(z));
       // ---- register epilogue (one lengthscale): the kernel entries are formed IN THE ACCUMULATOR LAYOUT -- the distance block
-      //      D = A' B'^T with A' = [-2 x_i, |x_i|^2, 1], B' = [x_j, 1, |x_j|^2] on the fp32 MFMA (lane = column j, register r
-      //      <-> row i, exactly like acc) -- so S o dK is 16 elementwise products per block: no S^T through LDS, no barriers,
-      //      and the ring is free, so the next tile's first stages are in flight while this runs.
-      constexpr int KS = (DPAD + 2) / 2;
+      //      D = A' B'^T with A' = [-2 x_i, |x_i|^2, 1], B' = [x_j, 1, |x_j|^2] on the fp32 MFMA (v_mfma_f32_16x16x4_f32: lane =
+      //      column j, register r <-> row 4 (lane >> 4) + r, exactly like acc) -- so S o dK is 4 elementwise products per block:
+      //      no S^T through LDS, no barriers, and the slots are free, so the next tile's first stage is in flight while this runs.
+      constexpr int KQ = Smem::KQ;
       // (bq of the previous tile: every wave has passed at least one K-loop barrier since it read it)
-      uint32_t taub[NBW];
+      uint32_t taub[NB16];
 #pragma unroll
-      for (int b = 0; b < NBW; ++b) taub[b] = grad_col_sign(j0 + wn * (NBW * 32) + b * 32 + l31, salt_r) ? 1u : 0u;
-      for (int t = tid; t < TN * (DPAD + 2); t += 512) {  // B' of the tile's columns (xs is a few MB: L2), BEFORE the prefetch
+      for (int b = 0; b < NB16; ++b) taub[b] = grad_col_sign(j0 + wn * (NBW * 32) + b * 16 + l15, salt_r) ? 1u : 0u;
+      for (int t = tid; t < TN * 4 * KQ; t += 512) {  // B' of the tile's columns (xs is a few MB: L2), BEFORE the prefetch
         const int col = t % TN, c = t / TN;
         const int64_t j = j0 + col;
         float v = 0.f;
         if (c < DPAD) v = j < n ? xs[j * DPAD + c] : 0.f;
         else if (c == DPAD) v = 1.f;
-        else v = j < n ? sq[j] : 0.f;
+        else if (c == DPAD + 1) v = j < n ? sq[j] : 0.f;
         sm.bq[c][col] = v;
       }
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): my bq writes have landed (the DMA counter is left alone)
-      __builtin_amdgcn_s_barrier();        // every wave is done reading the last stages of this tile, and bq is complete
-      if (tj + 1 < tj_end) {
-        uint32_t nl = offL, nr = offR0 + (uint32_t)((j0 + TN) * 16);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          if (q < nstage) issue_stage(nl, nr, q);
-          nl += stage_bytes_l;
-          nr += stage_bytes_r;
-        }
-      }
+      __builtin_amdgcn_s_barrier();        // every wave is done reading the last stage of this tile, and bq is complete
+      if (tj + 1 < tj_end) issue_stage(offL, offR0 + (uint32_t)((j0 + TN) * 16), 0);
       const bool diag_tile = (row0 + i0 < j0 + TN) && (j0 < row0 + i0 + kHM);
       float gl = 0.f, gs = 0.f, gn = 0.f;
       // one straight-line copy of the body per (tile meets the diagonal or not), kernel family fixed: with `kind` and the diagonal
-      // test as run-time branches inside the 256 unrolled entries the compiler spills 1.7 KB per lane
+      // test as run-time branches inside the 512 unrolled entries the compiler spills
       auto body = [&](auto kind_c, auto diag_c) {
         constexpr int KIND = decltype(kind_c)::value;
         constexpr bool DIAG = decltype(diag_c)::value;
-        int dj[NBW];  // column of block b's lane, relative to the first row of the workgroup's tile
+        int dj[NB16];  // column of block b's lane, relative to the first row of the workgroup's tile
 #pragma unroll
-        for (int b = 0; b < NBW; ++b) dj[b] = (int)(j0 + wn * (NBW * 32) + b * 32 + l31 - (row0 + i0));
+        for (int b = 0; b < NB16; ++b) dj[b] = (int)(j0 + wn * (NBW * 32) + b * 16 + l15 - (row0 + i0));
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-          const int il = wm * 64 + a * 32 + l31 + z;
-          float ai[KS];
+        for (int a = 0; a < 4; ++a) {
+          const int il = wm * 64 + a * 16 + l15 + z;
+          float ai[KQ];
 #pragma unroll
-          for (int sI = 0; sI < KS; ++sI) {
-            const int c = 2 * sI + lhi;
-            ai[sI] = c < DPAD ? -2.f * sm.xi[il][c < DPAD ? c : 0] : (c == DPAD ? sm.sqi[il] : 1.f);
+          for (int sI = 0; sI < KQ; ++sI) {
+            const int c = 4 * sI + lq;
+            ai[sI] = c < DPAD ? -2.f * sm.xi[il][c < DPAD ? c : 0] : (c == DPAD ? sm.sqi[il] : (c == DPAD + 1 ? 1.f : 0.f));
           }
           uint32_t sgbits = 0;  // bit r = sigma of the row of register r
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            sgbits |= (grad_col_sign(i0 + z + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi, salt_l) ? 1u : 0u) << r;
+          for (int r = 0; r < 4; ++r)
+            sgbits |= (grad_col_sign(i0 + z + wm * 64 + a * 16 + 4 * lq + r, salt_l) ? 1u : 0u) << r;
 #pragma unroll
-          for (int b = 0; b < NBW; ++b) {
-            floatx16 D;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) D[r] = 0.f;
-            // one distance block in flight: its first operand waits (through an opaque move) for the sums of the previous
-            // block -- otherwise the optimiser gathers the MFMAs of all blocks up front: 16 live registers each, spills
+          for (int b = 0; b < NB16; ++b) {
+            floatx4 D = {0.f, 0.f, 0.f, 0.f};
+            // a few distance blocks in flight, not all of them: the first operand of every other block waits (through an opaque
+            // move) for the sums of the previous ones -- otherwise the optimiser gathers the MFMAs of all blocks up front
             float a0 = ai[0];
-            asm volatile("" : "+v"(a0), "+v"(gs), "+v"(gl));
+            if ((b & 1) == 0) asm volatile("" : "+v"(a0), "+v"(gs), "+v"(gl));
 #pragma unroll
-            for (int sI = 0; sI < KS; ++sI)
-              D = __builtin_amdgcn_mfma_f32_32x32x2f32(sI == 0 ? a0 : ai[sI], sm.bq[2 * sI + lhi][wn * (NBW * 32) + b * 32 + l31], D, 0,
-                                                       0, 0);
+            for (int sI = 0; sI < KQ; ++sI)
+              D = __builtin_amdgcn_mfma_f32_16x16x4f32(sI == 0 ? a0 : ai[sI], sm.bq[4 * sI + lq][wn * (NBW * 32) + b * 16 + l15], D, 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < 4; ++r) {
               float dist = fmaxf(D[r], 0.f);
               // sigma_i tau_j S_ij -> S_ij: flip the sign bit
               const float s_ij = __uint_as_float(__float_as_uint(acc[a][b][r]) ^ ((((sgbits >> r) & 1u) ^ taub[b]) << 31));
               if constexpr (DIAG) {
-                const bool on = dj[b] == wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                const bool on = dj[b] == wm * 64 + a * 16 + 4 * lq + r;
                 dist = on ? 0.f : dist;
                 gn += on ? s_ij : 0.f;
               }
@@ -1475,7 +1430,6 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
               gs = fmaf(s_ij, kv, gs);
               gl = fmaf(s_ij * wl, dist, gl);
             }
-            __builtin_amdgcn_sched_barrier(0);  // one distance block at a time: 16 registers, not 16 per block of the tile
           }
         }
       };
@@ -1491,19 +1445,17 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
     //      dump them, then thread = row i walks 64 of the pass's columns (as in k_rbf_mfma_grad) -------------------------
 #pragma unroll
     for (int pass = 0; pass < TN / kGN; ++pass) {
-      __syncthreads();  // all waves are done with the ring (pass 0) / with the previous pass's S^T
+      __syncthreads();  // all waves are done with the stage images (pass 0) / with the previous pass's S^T
 #pragma unroll
-      for (int b = 0; b < NBW; ++b) {
-        const int blk = wn * NBW + b;  // 32-column block of the tile
-        if (blk / 4 != pass) continue;
+      for (int b = 0; b < NB16; ++b) {
+        const int cb = wn * (NBW * 32) + b * 16;  // first column of the block within the tile
+        if (cb / kGN != pass) continue;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            float4 q;
-            q.x = acc[a][b][4 * g + 0]; q.y = acc[a][b][4 * g + 1]; q.z = acc[a][b][4 * g + 2]; q.w = acc[a][b][4 * g + 3];
-            *reinterpret_cast<float4*>(&sm.u.s_t[(blk & 3) * 32 + l31][wm * 64 + a * 32 + 8 * g + 4 * lhi]) = q;
-          }
+        for (int a = 0; a < 4; ++a) {
+          float4 q;
+          q.x = acc[a][b][0]; q.y = acc[a][b][1]; q.z = acc[a][b][2]; q.w = acc[a][b][3];
+          *reinterpret_cast<float4*>(&sm.u.s_t[(cb % kGN) + l15][wm * 64 + a * 16 + 4 * lq]) = q;
+        }
       }
       const int64_t jp = j0 + pass * kGN;
       for (int t = tid; t < kGN * DPAD; t += 512) {
@@ -1568,6 +1520,7 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
       for (int c = 0; c < DPAD + 2; ++c) gsum[c] += (double)gt[c];
     }
   }
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // no LDS-DMA of mine is left in flight
   if (tid < 8 * (DPAD + 2)) (&sm.red[0][0])[tid] = 0.0;
   __syncthreads();
 #pragma unroll
