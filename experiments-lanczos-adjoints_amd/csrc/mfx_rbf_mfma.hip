@@ -1300,6 +1300,9 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
         for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.f;
 
     uint32_t ol = offL, orr = offR0 + (uint32_t)(j0 * 16);
+    // (opaque per tile: otherwise the four 64-bit L addresses of a stage, which do not depend on the tile, are hoisted out of the
+    //  tile loop and sit in -- or spill from -- registers the K-loop needs)
+    asm volatile("" : "+v"(ol));
     if (!REGEPI || tj == tj_begin) {
       __syncthreads();  // previous tile's epilogue reads of the overlaid S^T tile are done
       issue_stage(ol, orr, 0);
@@ -1310,7 +1313,7 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
     // together (192 KB per stage with the matrix pipe idle) and then queue their MFMAs together.  Here the two
     // halves of the workgroup run half a stage apart: two barriers per stage -- B1 before the fragment reads, B2 before the
     // MFMAs -- and the upper half takes one extra barrier first, so that while one wave of a SIMD is in its MFMA cluster
-    // (raised priority) the other one is in its read cluster.  Who needs what by when (A = waves 0-3, B = waves 4-7; barrier
+    // the other one is in its read cluster.  Who needs what by when (A = waves 0-3, B = waves 4-7; barrier
     // numbers in A's count: A.B1(st) = 2 st, A.B2(st) = B.B1(st) = 2 st + 1, B.B2(st) = 2 st + 2):
     //   * A reads stage st between barriers 2 st and 2 st + 1, B between 2 st + 1 and 2 st + 2 (each waits for its reads,
     //     lgkmcnt(0), before its B2);
@@ -1341,8 +1344,7 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the fragments are in registers
       if (wid >= 4) __builtin_amdgcn_s_waitcnt(0x0F70);  // (B) my pieces of stage st + 1
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();  // B2
-      __builtin_amdgcn_s_setprio(1);
+      __builtin_amdgcn_s_barrier();  // B2  (no s_setprio around the MFMA cluster: measured 0.5 % faster without, tools/gradk_bench.hip)
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -1351,7 +1353,6 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
           acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
           acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
         }
-      __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (wid < 4) __builtin_amdgcn_s_barrier();  // the lower half catches up: both halves have taken 2 nstage + 1 barriers
@@ -1367,9 +1368,9 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
       //      no S^T through LDS, no barriers, and the slots are free, so the next tile's first stage is in flight while this runs.
       constexpr int KQ = Smem::KQ;
       // (bq of the previous tile: every wave has passed at least one K-loop barrier since it read it)
-      uint32_t taub[NB16];
+      uint32_t taub[NB16];  // tau_j as a sign-bit mask
 #pragma unroll
-      for (int b = 0; b < NB16; ++b) taub[b] = grad_col_sign(j0 + wn * (NBW * 32) + b * 16 + l15, salt_r) ? 1u : 0u;
+      for (int b = 0; b < NB16; ++b) taub[b] = grad_col_sign(j0 + wn * (NBW * 32) + b * 16 + l15, salt_r) ? 0x80000000u : 0u;
       for (int t = tid; t < TN * 4 * KQ; t += 512) {  // B' of the tile's columns (xs is a few MB: L2), BEFORE the prefetch
         const int col = t % TN, c = t / TN;
         const int64_t j = j0 + col;
@@ -1381,13 +1382,16 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
       }
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): my bq writes have landed (the DMA counter is left alone)
       __builtin_amdgcn_s_barrier();        // every wave is done reading the last stage of this tile, and bq is complete
-      if (tj + 1 < tj_end) issue_stage(offL, offR0 + (uint32_t)((j0 + TN) * 16), 0);
+      if (tj + 1 < tj_end) issue_stage(ol - (uint32_t)(nstage + 1) * stage_bytes_l, offR0 + (uint32_t)((j0 + TN) * 16), 0);
       const bool diag_tile = (row0 + i0 < j0 + TN) && (j0 < row0 + i0 + kHM);
       float gl = 0.f, gs = 0.f, gn = 0.f;
-      // one straight-line copy of the body per (tile meets the diagonal or not), kernel family fixed: with `kind` and the diagonal
-      // test as run-time branches inside the 512 unrolled entries the compiler spills
-      auto body = [&](auto kind_c, auto diag_c) {
-        constexpr int KIND = decltype(kind_c)::value;
+      // one straight-line copy of the body per (tile meets the diagonal or not): with the diagonal test as a run-time branch inside
+      // the 128 unrolled entries the compiler spills.  Per entry FIVE VALU instructions (the two waves of a SIMD run their epilogues
+      // side by side, VALU-bound): the distance block comes out of the MFMA already scaled, t = c dist with c = -log2(e) / 2 folded
+      // into A'; k = v_exp_f32(t) with the clamp modifier (k <= 1: the reference's max(dist, 0), util/gp_util.py:173, where it matters);
+      // sigma_i tau_j undone by ONE v_xor3 with two sign masks; u = s k; sum u; sum u t (= c sum s k dist, unscaled at the end --
+      // a distance that is negative by round-off enters as it is, ~1e-7 of one entry).
+      auto body = [&](auto diag_c) {
         constexpr bool DIAG = decltype(diag_c)::value;
         int dj[NB16];  // column of block b's lane, relative to the first row of the workgroup's tile
 #pragma unroll
@@ -1399,12 +1403,12 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
 #pragma unroll
           for (int sI = 0; sI < KQ; ++sI) {
             const int c = 4 * sI + lq;
-            ai[sI] = c < DPAD ? -2.f * sm.xi[il][c < DPAD ? c : 0] : (c == DPAD ? sm.sqi[il] : (c == DPAD + 1 ? 1.f : 0.f));
+            const float v = c < DPAD ? -2.f * sm.xi[il][c < DPAD ? c : 0] : (c == DPAD ? sm.sqi[il] : (c == DPAD + 1 ? 1.f : 0.f));
+            ai[sI] = kNegHalfLog2e * v;
           }
-          uint32_t sgbits = 0;  // bit r = sigma of the row of register r
+          uint32_t sgm[4];  // sigma of the row of register r as a sign-bit mask
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            sgbits |= (grad_col_sign(i0 + z + wm * 64 + a * 16 + 4 * lq + r, salt_l) ? 1u : 0u) << r;
+          for (int r = 0; r < 4; ++r) sgm[r] = grad_col_sign(i0 + z + wm * 64 + a * 16 + 4 * lq + r, salt_l) ? 0x80000000u : 0u;
 #pragma unroll
           for (int b = 0; b < NB16; ++b) {
             floatx4 D = {0.f, 0.f, 0.f, 0.f};
@@ -1417,27 +1421,25 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
               D = __builtin_amdgcn_mfma_f32_16x16x4f32(sI == 0 ? a0 : ai[sI], sm.bq[4 * sI + lq][wn * (NBW * 32) + b * 16 + l15], D, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              float dist = fmaxf(D[r], 0.f);
+              float t = D[r];
               // sigma_i tau_j S_ij -> S_ij: flip the sign bit
-              const float s_ij = __uint_as_float(__float_as_uint(acc[a][b][r]) ^ ((((sgbits >> r) & 1u) ^ taub[b]) << 31));
+              const float s_ij = __uint_as_float(__float_as_uint(acc[a][b][r]) ^ sgm[r] ^ taub[b]);
               if constexpr (DIAG) {
                 const bool on = dj[b] == wm * 64 + a * 16 + 4 * lq + r;
-                dist = on ? 0.f : dist;
+                t = on ? 0.f : t;
                 gn += on ? s_ij : 0.f;
               }
-              float kv, wl;
-              grad_weights(KIND, dist, kv, wl);
-              gs = fmaf(s_ij, kv, gs);
-              gl = fmaf(s_ij * wl, dist, gl);
+              float kv;
+              asm("v_exp_f32_e64 %0, %1 clamp" : "=v"(kv) : "v"(t));
+              const float u = s_ij * kv;
+              gs += u;
+              gl = fmaf(u, t, gl);
             }
           }
         }
       };
-      // (RBF only: with the two Matern bodies in the same kernel the allocator spills around the branch on EVERY tile --
-      // 2.8 GB of scratch writes per launch in the PMC counters; the Matern kernels keep the LDS epilogue)
-      constexpr std::integral_constant<int, MFX_KERNEL_RBF> rbf_c{};
-      if (diag_tile) body(rbf_c, std::true_type{}); else body(rbf_c, std::false_type{});
-      gsum[0] += (double)gl;
+      if (diag_tile) body(std::true_type{}); else body(std::false_type{});
+      gsum[0] += (double)gl * (1.0 / (double)kNegHalfLog2e);
       gsum[1] += (double)gs;
       gsum[2] += (double)gn;
     } else

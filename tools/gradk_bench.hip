@@ -31,9 +31,10 @@ typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
 
 constexpr int kTM = 256, kTN = 256, kSub = 8, kSplit = 8;
 
+template <int AUX = 0>
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, AUX);
 }
 
 // ---- operands: x ~ U(-1, 1) * 2^14 * 2^-(3 (b % 5)), hi = f16(x), lo = f16(x - hi), packed [kb][col][8] -------------------------------
@@ -213,6 +214,9 @@ __device__ __forceinline__ double block_sum16(const floatx4& c, int rowlabel0, i
   for (int r = 0; r < 4; ++r) t = fmaf(c[r], wlow(4 * lq + r), t);
   return (double)t * (double)(wblk(rowlabel0 >> 5) * wblk(collabel0 >> 5) * wlow(l15));
 }
+// VAR: 0 as built into the product; 1 column blocks outer; 2 no s_setprio; 3 products grouped (all hh, all hl, all lh);
+//      timing diagnostics with WRONG sums: 4 no LDS-DMA in the loop, 5 no fragment reads in the loop, 6 neither, 7 neither and no barriers
+template <int VAR, int AUX = 0>
 __global__ __launch_bounds__(512, 1) void k_v3(Args g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(512, 1) void k_v3(Args g) {
     for (int i = 0; i < 8; ++i) {
       const int arr = i >> 1, hi2 = i & 1;
       const uint32_t so = arr < 2 ? l_off + (hi2 ? kb2L : 0u) : r_off + (hi2 ? kb2R : 0u);
-      glds16(gbase[arr] + (so + lane16), smem + slot * kSlot3 + ((arr * 4 + 2 * hi2 + kb0) * 256 + chunk * 64) * 16);
+      glds16<AUX>(gbase[arr] + (so + lane16), smem + slot * kSlot3 + ((arr * 4 + 2 * hi2 + kb0) * 256 + chunk * 64) * 16);
     }
   };
   auto a_ptr = [&](int slot, int hl, int a) {
@@ -267,39 +271,78 @@ __global__ __launch_bounds__(512, 1) void k_v3(Args g) {
     orr += stage_bytes_r;
     __builtin_amdgcn_s_waitcnt(0x0F70);  // stage 0 (requested here or before the previous tile's checksum)
     if (wid >= 4) __builtin_amdgcn_s_barrier();
-    for (int st = 0; st < nstage; ++st) {
-      const int slot = st & 1;
-      if (wid < 4) __builtin_amdgcn_s_waitcnt(0x0F70);  // lower half: my pieces of this stage, requested a stage ago
-      __builtin_amdgcn_s_barrier();  // B1
-      // the other slot's last readers (the upper half, stage st - 1) passed this barrier: refill it with stage st + 1
-      if (st + 1 < nstage) issue_stage(ol, orr, slot ^ 1);
-      ol += stage_bytes_l;
-      orr += stage_bytes_r;
-      half8 ah[4], al[4], bh[8], bl[8];
+    half8 ah[4], al[4], bh[8], bl[8];
+    if constexpr (VAR >= 5) {
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-        ah[a] = *a_ptr(slot, 0, a);
-        al[a] = *a_ptr(slot, 1, a);
+        ah[a] = *a_ptr(0, 0, a);
+        al[a] = *a_ptr(0, 1, a);
       }
 #pragma unroll
       for (int b = 0; b < 8; ++b) {
-        bh[b] = *b_ptr(slot, 0, b);
-        bl[b] = *b_ptr(slot, 1, b);
+        bh[b] = *b_ptr(0, 0, b);
+        bl[b] = *b_ptr(0, 1, b);
+      }
+    }
+    for (int st = 0; st < nstage; ++st) {
+      const int slot = st & 1;
+      if (wid < 4) __builtin_amdgcn_s_waitcnt(0x0F70);  // lower half: my pieces of this stage, requested a stage ago
+      if constexpr (VAR != 7) __builtin_amdgcn_s_barrier();  // B1
+      // the other slot's last readers (the upper half, stage st - 1) passed this barrier: refill it with stage st + 1
+      if constexpr (VAR != 4 && VAR != 6 && VAR != 7)
+        if (st + 1 < nstage) issue_stage(ol, orr, slot ^ 1);
+      ol += stage_bytes_l;
+      orr += stage_bytes_r;
+      if constexpr (VAR < 5) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          ah[a] = *a_ptr(slot, 0, a);
+          al[a] = *a_ptr(slot, 1, a);
+        }
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+          bh[b] = *b_ptr(slot, 0, b);
+          bl[b] = *b_ptr(slot, 1, b);
+        }
+      } else {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) asm volatile("" : "+v"(ah[a]), "+v"(al[a]));
+#pragma unroll
+        for (int b = 0; b < 8; ++b) asm volatile("" : "+v"(bh[b]), "+v"(bl[b]));
       }
       __builtin_amdgcn_s_waitcnt(0xC07F);
       if (wid >= 4) __builtin_amdgcn_s_waitcnt(0x0F70);  // upper half: my pieces of stage st + 1 before the barrier the lower half reads it behind
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();  // B2
-      __builtin_amdgcn_s_setprio(1);
+      if constexpr (VAR != 7) __builtin_amdgcn_s_barrier();  // B2
+      if constexpr (VAR != 2) __builtin_amdgcn_s_setprio(1);
+      if constexpr (VAR == 1) {
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 8; ++b)
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
-        }
-      __builtin_amdgcn_s_setprio(0);
+          for (int a = 0; a < 4; ++a) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
+          }
+      } else if constexpr (VAR == 3) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w == 2 ? al[a] : ah[a], w == 1 ? bl[b] : bh[b], acc[a][b], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 8; ++b) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
+          }
+      }
+      if constexpr (VAR != 2) __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (wid < 4) __builtin_amdgcn_s_barrier();
@@ -513,25 +556,30 @@ int main(int argc, char** argv) {
   const int tiles_per_block = (int)(ntj / (kSplit * kSub));
   const dim3 grid(kSplit, (unsigned)(nti * kSub));
   const int64_t nwg = (int64_t)grid.x * grid.y;
-  double* out[4];
+  double* out[16];
   long long* stamps;
-  for (int v = 0; v < 4; ++v) CK(hipMalloc(&out[v], nwg * 8));
+  for (int v = 0; v < 16; ++v) CK(hipMalloc(&out[v], nwg * 8));
   CK(hipMalloc(&stamps, nwg * 16));
   Args a{Lh, Ll, Rh, Rl, rows, cols, nkb, tiles_per_block, nullptr, stamps};
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_v0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmemV0)));
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fat<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kSlotBytes));
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fat<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kSlotBytes));
-  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_v3), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kSlot3));
+#define V3ATTR(V) CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_v3<V>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kSlot3))
+#define V3ATTRA(V, A) CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_v3<V, A>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kSlot3))
+  V3ATTRA(2, 1); V3ATTRA(2, 2); V3ATTRA(2, 16); V3ATTRA(2, 3);
+  V3ATTR(0); V3ATTR(1); V3ATTR(2); V3ATTR(3); V3ATTR(4); V3ATTR(5); V3ATTR(6); V3ATTR(7);
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const double mfma_cycles_per_simd_per_tile = (double)(nkb / 2) * 48.0 * 32.0;  // both layouts: 48 MFMAs per SIMD and 16-row stage
-  const char* names[4] = {"V0 product loop (8 waves, ping-pong, LDS-DMA)", "V1 fat waves, LDS-DMA", "V2 fat waves, register staging",
-                          "V3 as V0 on 16x16x32 (K = 32 stages)"};
+  const char* names[15] = {"V0 round-3 loop (32x32x16, 8 waves, ping-pong)", "V1 fat waves, LDS-DMA", "V2 fat waves, register staging",
+                           "V3 as V0 on 16x16x32 (K = 32 stages)", "V3.1 column blocks outer", "V3.2 no s_setprio", "V3.3 products grouped",
+                           "V3.4 [diag] no LDS-DMA", "V3.5 [diag] no fragment reads", "V3.6 [diag] neither", "V3.7 [diag] neither, no barriers",
+                           "V3.2 + sc0 loads", "V3.2 + nt loads", "V3.2 + sc1 loads", "V3.2 + sc0 nt loads"};
   const unsigned vmask = argc > 5 ? (unsigned)strtoul(argv[5], nullptr, 0) : 0xFu;
-  std::vector<double> ref(nwg), cur(nwg);
+  std::vector<double> ref, cur(nwg);
   std::vector<long long> st(2 * nwg);
   for (int rep = 0; rep < reps; ++rep)
-    for (int v = 0; v < 4; ++v) {
+    for (int v = 0; v < 15; ++v) {
       if (!((vmask >> v) & 1)) continue;
       a.out = out[v];
       CK(hipMemset(out[v], 0, nwg * 8));
@@ -539,7 +587,18 @@ int main(int argc, char** argv) {
       if (v == 0) k_v0<<<grid, 512, sizeof(SmemV0)>>>(a);
       else if (v == 1) k_fat<1><<<grid, 256, 4 * kSlotBytes>>>(a);
       else if (v == 2) k_fat<2><<<grid, 256, 2 * kSlotBytes>>>(a);
-      else k_v3<<<grid, 512, 2 * kSlot3>>>(a);
+      else if (v == 3) k_v3<0><<<grid, 512, 2 * kSlot3>>>(a);
+      else if (v == 4) k_v3<1><<<grid, 512, 2 * kSlot3>>>(a);
+      else if (v == 5) k_v3<2><<<grid, 512, 2 * kSlot3>>>(a);
+      else if (v == 6) k_v3<3><<<grid, 512, 2 * kSlot3>>>(a);
+      else if (v == 7) k_v3<4><<<grid, 512, 2 * kSlot3>>>(a);
+      else if (v == 8) k_v3<5><<<grid, 512, 2 * kSlot3>>>(a);
+      else if (v == 9) k_v3<6><<<grid, 512, 2 * kSlot3>>>(a);
+      else if (v == 10) k_v3<7><<<grid, 512, 2 * kSlot3>>>(a);
+      else if (v == 11) k_v3<2, 1><<<grid, 512, 2 * kSlot3>>>(a);
+      else if (v == 12) k_v3<2, 2><<<grid, 512, 2 * kSlot3>>>(a);
+      else if (v == 13) k_v3<2, 16><<<grid, 512, 2 * kSlot3>>>(a);
+      else k_v3<2, 3><<<grid, 512, 2 * kSlot3>>>(a);
       CK(hipEventRecord(e1));
       CK(hipEventSynchronize(e1));
       CK(hipGetLastError());
@@ -547,9 +606,10 @@ int main(int argc, char** argv) {
       CK(hipEventElapsedTime(&ms, e0, e1));
       CK(hipMemcpy(cur.data(), out[v], nwg * 8, hipMemcpyDeviceToHost));
       CK(hipMemcpy(st.data(), stamps, nwg * 16, hipMemcpyDeviceToHost));
-      if (v == 0) ref = cur;
-      double worst = 0.0;
-      for (int64_t i = 0; i < nwg; ++i) worst = std::max(worst, fabs(cur[i] - ref[i]) / (fabs(ref[i]) + 1e-300));
+      if (ref.empty() || (v == 0)) ref = cur;
+      double worst = 0.0, big = 0.0;  // largest difference relative to the largest checksum (single checksums cancel to ~0)
+      for (int64_t i = 0; i < nwg; ++i) { worst = std::max(worst, fabs(cur[i] - ref[i])); big = std::max(big, fabs(ref[i])); }
+      worst /= big + 1e-300;
       std::vector<double> clk(nwg), util(nwg);
       for (int64_t i = 0; i < nwg; ++i) {
         clk[i] = (double)st[2 * i] / (double)st[2 * i + 1] * 0.1;  // GHz
