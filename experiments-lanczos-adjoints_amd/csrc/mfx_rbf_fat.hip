@@ -23,10 +23,6 @@
 #include "mfx_internal.h"
 #include "mfx_rbf_common.h"
 
-#ifndef MFX_FAT_DIAG
-#define MFX_FAT_DIAG 0  // timing diagnostics (WRONG results): 1 = no LDS-DMA in the tile loop, 2 = also no barrier, 3 = also no fragment reads
-#endif
-
 namespace mfx {
 
 // MFMA slots of a block and the placement of the split chain behind them, by the number NB of 32-probe blocks of a chunk.
@@ -67,17 +63,6 @@ struct FatPlan<1> {
   static constexpr int contr_m(int slot) { return slot < 3 ? slot : (slot == 4 ? 3 : (slot >= 6 ? slot - 2 : -1)); }
   static constexpr int slot_of(int m) { return m < 3 ? m : (m == 3 ? 4 : m + 2); }
 };
-
-#ifndef MFX_FAT_FP8_EMU
-#define MFX_FAT_FP8_EMU 0
-#endif
-// f16 values rounded (to nearest, in magnitude) to the 3 mantissa bits of an e4m3 number, still held as f16
-__device__ __forceinline__ half8 fp8_round(half8 v) {
-  uintx4 u = __builtin_bit_cast(uintx4, v);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) u[i] = (u[i] + 0x00400040u) & 0xFF80FF80u;
-  return __builtin_bit_cast(half8, u);
-}
 
 template <int DPAD, int NB>
 struct FatSmem {
@@ -289,7 +274,7 @@ __global__ __launch_bounds__(256, 1) void k_rbf_fat_apply(const float* __restric
       const int blk1 = (blk + 1) & 7, blk2 = (blk + 2) & 7;
       const int jb2 = blk2 >> 2, mi2 = blk2 & 3;
       const bool neg_c = ((jb + mi) & 1) != 0, neg_n = (((blk1 >> 2) + (blk1 & 3)) & 1) != 0;
-      if (MFX_FAT_DIAG == 0 && blk == 5 && tl + 2 < ntl) issue_tile_dma(tl + 2);  // (this tile's buffer has been dead since the barrier behind block 4)
+      if (blk == 5 && tl + 2 < ntl) issue_tile_dma(tl + 2);  // (this tile's buffer has been dead since the barrier behind block 4)
       // Invariant at this point: (ahc, alc) hold K_blk except for the table's lag-1 steps (still to run on wc); wn holds the
       // distances of block blk + 1, untouched; ajs[jb2 & 1] holds the column operand that block blk + 2 needs from its first
       // distance slot on.
@@ -302,43 +287,20 @@ __global__ __launch_bounds__(256, 1) void k_rbf_fat_apply(const float* __restric
         } else {
           const int m = Plan::contr_m(slot);
           const int s = m / (3 * NB), nb = (m / 3) % NB, w = m % 3;
-#if MFX_FAT_FP8_EMU
-          // ACCURACY experiment (never a product build): what the cross products hi lo and lo hi would carry on the FP8 MFMA --
-          // both operands rounded to 3 mantissa bits (e4m3; range ignored, as under block scaling)
-          half8 opa = w == 2 ? alc[s] : ahc[s], opb = w == 1 ? vf[s][nb][1] : vf[s][nb][0];
-          if (MFX_FAT_FP8_EMU == 1 && w != 0) {
-            opa = fp8_round(opa);
-            opb = fp8_round(opb);
-          }
-          // 2: no hi(K) lo(V) product at all (the probes as plain f16); 3: only that product on FP8 precision
-          if (MFX_FAT_FP8_EMU == 3 && w == 1) {
-            opa = fp8_round(opa);
-            opb = fp8_round(opb);
-          }
-          if (MFX_FAT_FP8_EMU == 4 && w == 1) {  // hi(K) on e5m2 precision (2 mantissa bits: the top byte of the f16), lo(V) on e4m3
-            uintx4 u = __builtin_bit_cast(uintx4, opa);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) u[i] = (u[i] + 0x00800080u) & 0xFF00FF00u;
-            opa = __builtin_bit_cast(half8, u);
-            opb = fp8_round(opb);
-          }
-          if (!(MFX_FAT_FP8_EMU == 2 && w == 1)) acc[mi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(opa, opb, acc[mi][nb], 0, 0, 0);
-#else
           acc[mi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w == 2 ? alc[s] : ahc[s], w == 1 ? vf[s][nb][1] : vf[s][nb][0],
                                                                acc[mi][nb], 0, 0, 0);
-#endif
         }
         __builtin_amdgcn_sched_barrier(0);
         split_slot(slot, 1, wc, ahc, alc, lpc, neg_c);  // this block's late pairs first (their consumers are a few slots away)
         split_slot(slot, 0, wn, ahn, aln, lpn, neg_n);
         // fragment reads, one per gap: the probe fragments of the NEXT column block during this one (blocks mi = 1, 2: sixteen
         // reads... eight per block), the column operand of the column block after that in block mi = 1
-        if (MFX_FAT_DIAG < 3 && mi == 1 && slot < NKD) {
+        if (mi == 1 && slot < NKD) {
           // ajs of column block c + 1 is needed by the distances of block (c + 1, mi 0), issued in block (c, mi 2)
           ajs[(jb + 1) & 1][slot] = *reinterpret_cast<const half8*>(reinterpret_cast<const _Float16*>(fat_smem + (jb == 1 ? buf ^ 1 : buf) * S::kTile) +
                                                                    (((jb + 1) & 1) * 32 + l31) * AROW + slot * 16 + lhi * 8);
         }
-        if (MFX_FAT_DIAG < 3 && mi == 3) {
+        if (mi == 3) {
           // the probe fragments of the next column block roll in behind the last MFMA of this column block that reads the
           // register they replace: fragment (s, nb, hi) is read by MFMAs 3 NB s + 3 nb and + 2, (s, nb, lo) by + 1
 #pragma unroll
@@ -357,7 +319,7 @@ __global__ __launch_bounds__(256, 1) void k_rbf_fat_apply(const float* __restric
         // tile tl + 1 (requested a tile ago) has landed for everybody, and everybody is done with this tile's buffer: its last reads
         // -- the probe fragments of column block 1, rolled in during block 3 -- were consumed by the MFMAs of this block
         __builtin_amdgcn_s_waitcnt(0x0F70);
-        if (MFX_FAT_DIAG < 2) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
       }
       // rotate: next -> current, next-but-one -> next
