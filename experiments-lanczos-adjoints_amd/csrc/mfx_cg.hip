@@ -652,6 +652,7 @@ int mfx_pcg_solve(const mfx_operator* op, const void* b, int64_t ldb, int64_t n,
   MFX_REQUIRE(ws && cg_carve(op, n, p, precond_lt ? rank : 0, ws, ws_bytes, &w) <= ws_bytes, MFX_ERR_WORKSPACE,
               "mfx_pcg_solve: workspace too small");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  PrepScope prep_scope;
   if (op->dtype == MFX_F32)
     return pcg_t<float>(op, (const float*)b, ldb, n, p, precond_lt ? &pc : nullptr, maxiter, miniter, atol, rtol, adaptive,
                         (float*)x, (float*)r, (int64_t*)num_steps, nullptr, w, s);
@@ -693,6 +694,7 @@ int mfx_pcg_solve_sharded(const mfx_operator* op, const mfx_comm* comm, const vo
   MFX_REQUIRE(ws && cg_carve(op, nrows, p, precond_lt ? rank : 0, ws, ws_bytes, &w, comm) <= ws_bytes, MFX_ERR_WORKSPACE,
               "mfx_pcg_solve_sharded: workspace too small");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  PrepScope prep_scope;
   if (op->dtype == MFX_F32)
     return pcg_t<float>(op, (const float*)b, ldb, nrows, p, precond_lt ? &pc : nullptr, maxiter, miniter, atol, rtol, adaptive,
                         (float*)x, (float*)r, (int64_t*)num_steps, nullptr, w, s, comm);
@@ -716,6 +718,7 @@ int mfx_pcg_solve_reortho(const mfx_operator* op, const void* b, int64_t ldb, in
   MFX_REQUIRE(ws && cg_carve(op, n, p, kdim, ws, ws_bytes, &w) <= ws_bytes, MFX_ERR_WORKSPACE,
               "mfx_pcg_solve_reortho: workspace too small (size it with rank = max(rank, num_matvecs))");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  PrepScope prep_scope;
   if (op->dtype == MFX_F32)
     return pcg_t<float>(op, (const float*)b, ldb, n, p, precond_lt ? &pc : nullptr, num_matvecs, 0, 1.0, 0.0, 0, (float*)x,
                         (float*)r, nullptr, (float*)q, w, s);

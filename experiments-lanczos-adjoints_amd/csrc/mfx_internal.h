@@ -100,6 +100,17 @@ struct Carver {
 
 // operator layer (mfx_ops.hip)
 int64_t op_workspace_bytes(const mfx_operator* op, int64_t batch_hint, int64_t p_apply);
+// Within ONE driver call (a Krylov factorisation, its adjoint, a CG solve) neither the operator's data nor its workspace change:
+// the operator's per-call preparation (kernel-Gram: x / lengthscale and |x / lengthscale|^2, k_rbf_prep) then runs once instead
+// of once per matvec (the reference's jit hoists the same loop invariant, util/gp_util.py:160-176).  A driver holds one of these
+// on its stack; op_apply outside any scope (mfx_op_apply) prepares every time.
+struct PrepScope {
+  PrepScope();
+  ~PrepScope();
+  PrepScope(const PrepScope&) = delete;
+  PrepScope& operator=(const PrepScope&) = delete;
+};
+
 int op_apply(const mfx_operator* op, const void* x, int64_t ldx, void* y, int64_t ldy, int64_t p,
              int transpose, void* ws, int64_t ws_bytes, hipStream_t stream);
 int op_apply_cb(const mfx_operator* op, int mode, const void* x, int64_t ldx, const void* aux,

@@ -975,7 +975,8 @@ static GraphKey driver_key(int fn_id, const mfx_operator* op, int64_t n, int64_t
   const int64_t need = carve_ws(op, n, k, p, ws, ws_bytes, &kws);                                \
   MFX_REQUIRE(ws && need <= ws_bytes, MFX_ERR_WORKSPACE, "workspace too small: need %lld bytes", \
               (long long)need);                                                                 \
-  hipStream_t s = static_cast<hipStream_t>(stream)
+  hipStream_t s = static_cast<hipStream_t>(stream);                                               \
+  PrepScope prep_scope
 
 int mfx_arnoldi_forward(const mfx_operator* op, const void* v0, int64_t n, int64_t k, int64_t p,
                         int second_pass, void* Q, void* H, void* r, void* c, void* ws, int64_t ws_bytes,
@@ -1006,6 +1007,7 @@ int mfx_arnoldi_forward_complex(const mfx_operator* op, const void* v0, int64_t 
   const int64_t need = carve_complex_ws(op, n, k, p, ws, ws_bytes, &cw);
   MFX_REQUIRE(ws && need <= ws_bytes, MFX_ERR_WORKSPACE, "workspace too small: need %lld bytes", (long long)need);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  PrepScope prep_scope;
   if (op->dtype == MFX_F32)
     return arnoldi_forward_complex_t<float>(op, (const float*)v0, n, k, p, second_pass, (float*)Q, (float*)H, (float*)r, (float*)c, cw, s);
   return arnoldi_forward_complex_t<double>(op, (const double*)v0, n, k, p, second_pass, (double*)Q, (double*)H, (double*)r, (double*)c, cw, s);
@@ -1049,7 +1051,8 @@ static int check_sharded(const mfx_operator* op, const mfx_comm* cm, int64_t n, 
   const int64_t need = carve_ws(op, nrows, k, p, ws, ws_bytes, &kws, comm);                      \
   MFX_REQUIRE(ws && need <= ws_bytes, MFX_ERR_WORKSPACE, "workspace too small: need %lld bytes", \
               (long long)need);                                                                 \
-  hipStream_t s = static_cast<hipStream_t>(stream)
+  hipStream_t s = static_cast<hipStream_t>(stream);                                               \
+  PrepScope prep_scope
 
 int64_t mfx_sharded_workspace_bytes(const mfx_operator* op, const mfx_comm* comm, int64_t n, int64_t k, int64_t p) {
   if (!op || !comm || comm->nloc < 1) return -1;

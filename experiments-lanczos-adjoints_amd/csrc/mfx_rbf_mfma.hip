@@ -296,6 +296,37 @@ __global__ void k_row_scale_from_bits(const unsigned* __restrict__ amax_bits, in
   scale[2 * b + 1] = 1.f / s;
 }
 
+// 2^(14 - e) for |max| = f 2^e (1 for an all-zero row); tiny / denormal rows (|max| < 2^-112): s and 1/s stay finite and normal
+__device__ __forceinline__ float row_scale_of(float m) {
+  int e = 0;
+  float s = 1.f;
+  if (m > 0.f && m < 3.0e38f) {
+    frexpf(m, &e);
+    s = ldexpf(1.f, 14 - e < 126 ? 14 - e : 126);
+  }
+  return s;
+}
+
+// Pre-packed path: ONE launch in front of k_pack_tiles instead of three (zero + atomic maxima + scales).  Slice maxima of |x| per
+// row, no atomics: part[b gx + slice]; k_pack_tiles folds a row's <= 64 slice maxima into its scale itself.  Block (0, 0) also
+// clears the f16 range flag, which k_pack_tiles (behind this launch in stream order) raises.
+__global__ __launch_bounds__(256) void k_row_amax_part(const float* __restrict__ x, int64_t ldx, int64_t n, float* __restrict__ part,
+                                                       int* __restrict__ flag) {
+  __shared__ float sm[4];
+  const int64_t b = blockIdx.y;
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    m = fmaxf(m, fabsf(x[b * ldx + i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[b * gridDim.x + blockIdx.x] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    if (blockIdx.x == 0 && blockIdx.y == 0) *flag = 0;
+  }
+}
+
 // scale (rows, 2) = [s, 1/s]; the amax bit patterns live right behind it in the caller's buffer
 static int row_scales(const float* x, int64_t ldx, int64_t n, int64_t rows, float* scale, hipStream_t stream) {
   unsigned* bits = reinterpret_cast<unsigned*>(scale + 2 * rows);
@@ -877,9 +908,9 @@ __global__ __launch_bounds__(256) void k_split_reduce(const float* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 template <int DPAD, int NB, int KIND>
 __global__ __launch_bounds__(256) void k_pack_tiles(const float* __restrict__ xs, const float* __restrict__ sq, int64_t n,
-                                                    const float* __restrict__ vscale, const float* __restrict__ x,
-                                                    int64_t ldx, int64_t p, uintx4* __restrict__ pkv,
-                                                    uintx4* __restrict__ pka, int* __restrict__ rangeflag) {
+                                                    float* __restrict__ vscale, const float* __restrict__ amax_part, int gx,
+                                                    const float* __restrict__ x, int64_t ldx, int64_t p,
+                                                    uintx4* __restrict__ pkv, uintx4* __restrict__ pka, int* __restrict__ rangeflag) {
   constexpr int kTJ = 64;
   using Tile = RbfTileH3<DPAD, NB, kTJ>;
   constexpr int KD = Tile::KD, P = Tile::P, AROW = Tile::AROW;
@@ -889,6 +920,24 @@ __global__ __launch_bounds__(256) void k_pack_tiles(const float* __restrict__ xs
   if ((int)blockIdx.y < (int)gridDim.y - 1) {
     const int64_t b0 = (int64_t)blockIdx.y * P;
     uintx4* dst = pkv + ((int64_t)blockIdx.y * ntile + t) * (2 * 8 * P);
+    // the power-of-two scales of this chunk's vectors from their slice maxima (k_row_amax_part); tile 0 publishes [s, 1/s] for the
+    // epilogue of the matvec kernel
+    __shared__ float svs[P];
+    if (tid < P) {
+      const int64_t b = b0 + tid;
+      float sc = 0.f;
+      if (b < p) {
+        float m = 0.f;
+        for (int g = 0; g < gx; ++g) m = fmaxf(m, amax_part[b * gx + g]);
+        sc = row_scale_of(m);
+        if (t == 0) {
+          vscale[2 * b] = sc;
+          vscale[2 * b + 1] = 1.f / sc;
+        }
+      }
+      svs[tid] = sc;
+    }
+    __syncthreads();
     for (int f0 = tid; f0 < 8 * P; f0 += 256) {
       // 8 consecutive lanes read the 64 consecutive columns (256 B) of ONE probe row; the 16-B stores of a lane group land in
       // 8 different image rows, 8 consecutive probes each (a first version with lanes along the probes read 4 B per 512-KB
@@ -897,7 +946,7 @@ __global__ __launch_bounds__(256) void k_pack_tiles(const float* __restrict__ xs
       const int jb = row >> 2, s = (row >> 1) & 1, h = row & 1;
       const int64_t b = b0 + bq;
       half8 hh, ll;
-      const float vs = b < p ? vscale[2 * b] : 0.f;
+      const float vs = svs[bq];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int64_t j = j0 + 32 * jb + 16 * s + 8 * (e >> 2) + 4 * h + (e & 3);
@@ -997,12 +1046,24 @@ static int launch_apply_h3k(const mfx_operator* op, const float* xs, const float
   const int64_t n = op->n;
   const int64_t row0 = op_row0(op), nrow = op_nrows(op), rend = row0 + nrow;
   MFX_REQUIRE(row0 % 64 == 0, MFX_ERR_INVALID, "matrix-core Gram matvec: row0 = %lld must be a multiple of 64", (long long)row0);
-  MFX_TRY(row_scales(x, ldx, n, p, vscale, stream));
+  const bool pack = pk != nullptr;  // the pre-packed tile images need the caller's pack workspace (mfx_workspace_bytes sizes it)
+  // vscale region (65536 x 3 floats): [0, 2p) scales, [2p, 3p) |max| bit patterns (in-kernel-split path only), [3p] f16 range flag,
+  // [3p + 64, ...) slice maxima of the pre-packed path
+  int* rangeflag = reinterpret_cast<int*>(vscale + 3 * p);
+  float* amax_part = vscale + 3 * p + 64;
+  int64_t gx = (n + 8191) / 8192;
+  if (gx > 64) gx = 64;
+  while (gx > 1 && 3 * p + 64 + p * gx > (int64_t)65536 * 3) --gx;
+  if (pack) {
+    k_row_amax_part<<<dim3((unsigned)gx, (unsigned)p), 256, 0, stream>>>(x, ldx, n, amax_part, rangeflag);
+    MFX_CHECK_LAUNCH();
+  } else {
+    MFX_TRY(row_scales(x, ldx, n, p, vscale, stream));
+  }
   const unsigned chunks = (unsigned)((p + NB * 32 - 1) / (NB * 32));
   const dim3 grid((unsigned)((nrow + 255) / 256), chunks);  // 4-wave workgroups (256 rows); the pre-packed variant uses grid_pk
   const bool vec4 = (n % 4 == 0) && (nrow % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) &&
                     (reinterpret_cast<uintptr_t>(y) % 16 == 0);
-  const bool pack = pk != nullptr;  // the pre-packed tile images need the caller's pack workspace (mfx_workspace_bytes sizes it)
   uintx4* pkv = nullptr;
   uintx4* pka = nullptr;
   const int64_t ntile = (n + 63) / 64;
@@ -1013,11 +1074,10 @@ static int launch_apply_h3k(const mfx_operator* op, const float* xs, const float
   const int nsplit = part ? rbf_split_count(nrow, n, p, DPAD) : 1;
   const dim3 grid3(grid.x, grid.y, (unsigned)nsplit);
   const dim3 grid_pk((unsigned)((nrow + 511) / 512), grid.y, (unsigned)nsplit);
-  int* rangeflag = reinterpret_cast<int*>(vscale + 3 * p);  // zeroed by row_scales
   if (pack) {
     pkv = static_cast<uintx4*>(pk);
     pka = reinterpret_cast<uintx4*>(static_cast<char*>(pk) + off_a);
-    k_pack_tiles<DPAD, NB, KIND><<<dim3((unsigned)ntile, chunks + 1), 256, 0, stream>>>(xs, sq, n, vscale, x, ldx, p, pkv, pka, rangeflag);
+    k_pack_tiles<DPAD, NB, KIND><<<dim3((unsigned)ntile, chunks + 1), 256, 0, stream>>>(xs, sq, n, vscale, amax_part, (int)gx, x, ldx, p, pkv, pka, rangeflag);
     MFX_CHECK_LAUNCH();
   }
   // LDS: the two tile buffers + (pre-packed variant) the chain masters of 8 waves x (2 NB - 1) blocks x 16 registers x 64 lanes
