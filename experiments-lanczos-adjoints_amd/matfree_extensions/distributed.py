@@ -28,6 +28,122 @@ import torch.distributed as dist
 from . import _lib
 
 
+class LocalWorld:
+    """R logical ranks as R THREADS of one process sharing one GPU: the rehearsal stand-in for a process group on a box with fewer
+    GPUs than ranks (a GPU box admits few processes on its card; eight threads are one process).  ``LocalWorld(8).ranks()`` gives
+    the eight group handles; pass one as ``group=`` to `RowComm`, `Layout`, `reduce_estimate` in the thread that plays that rank.
+    Collectives are host rendezvous (a barrier, device copies in rank order -- sums are deterministic) -- every kernel launch, every
+    workspace layout and every callback of the row-sharded drivers is the real one; only the transport is not RCCL.  Timings
+    mean nothing.  ``run(fn)`` starts the threads, passes each its handle and returns the results in rank order (first exception re-raised)."""
+
+    def __init__(self, world: int, timeout: float = 120.0):
+        import threading
+
+        self.world = int(world)
+        self._barrier = threading.Barrier(self.world, timeout=timeout)
+        self._slots = [None] * self.world
+
+    def ranks(self):
+        return [LocalRank(self, r) for r in range(self.world)]
+
+    def run(self, fn):
+        import threading
+
+        out, err = [None] * self.world, [None] * self.world
+
+        def body(handle):
+            try:
+                # a stream of its own per logical rank: the scratch cache of the host layer is keyed by (device, stream), so the ranks
+                # get separate workspaces exactly as separate processes would
+                own = torch.cuda.stream(torch.cuda.Stream()) if torch.cuda.is_available() else contextlib.nullcontext()
+                # backward passes in THIS thread: the autograd engine otherwise runs every rank's backward nodes on the one worker
+                # thread of the device, one after the other -- the first rank's adjoint driver then waits in its first collective
+                # for ranks whose backward is queued behind it
+                with own, torch.autograd.set_multithreading_enabled(False):
+                    out[handle.rank] = fn(handle)
+                    if torch.cuda.is_available():
+                        torch.cuda.synchronize()
+            except BaseException as exc:  # noqa: BLE001 -- a rank that dies must not leave the others in a rendezvous
+                err[handle.rank] = exc
+                self._barrier.abort()
+
+        threads = [threading.Thread(target=body, args=(h,), name=f"mfx-rank-{h.rank}") for h in self.ranks()]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        first = next((e for e in err if e is not None and not isinstance(e, __import__("threading").BrokenBarrierError)), None)
+        if first is None:
+            first = next((e for e in err if e is not None), None)
+        if first is not None:
+            raise first
+        return out
+
+
+class LocalRank:
+    """One logical rank of a `LocalWorld` (the ``group=`` argument of this module's classes in the thread that plays it)."""
+
+    def __init__(self, shared: LocalWorld, rank: int):
+        self.shared, self.rank, self.world = shared, int(rank), shared.world
+
+    def _publish(self, t):
+        if t.is_cuda:
+            torch.cuda.synchronize(t.device)
+        self.shared._slots[self.rank] = t
+        self.shared._barrier.wait()
+
+    def all_reduce(self, t, op="sum"):
+        self._publish(t)
+        acc = self.shared._slots[0].clone()
+        for r in range(1, self.world):
+            other = self.shared._slots[r]
+            acc = acc + other if op == "sum" else (torch.minimum(acc, other) if op == "min" else torch.maximum(acc, other))
+        if t.is_cuda:
+            torch.cuda.synchronize(t.device)
+        self.shared._barrier.wait()  # everybody has read everybody's input
+        t.copy_(acc)
+        return t
+
+    def all_gather_into_tensor(self, out, inp):
+        self._publish(inp)
+        blocks = out.view(self.world, -1)
+        for r in range(self.world):
+            blocks[r].copy_(self.shared._slots[r].reshape(-1))
+        if out.is_cuda:
+            torch.cuda.synchronize(out.device)
+        self.shared._barrier.wait()
+        return out
+
+    def barrier(self):
+        self.shared._barrier.wait()
+
+
+def _group_size(group):
+    if isinstance(group, LocalRank):
+        return group.world
+    return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def _group_rank(group):
+    if isinstance(group, LocalRank):
+        return group.rank
+    return dist.get_rank(group) if (dist.is_available() and dist.is_initialized()) else 0
+
+
+def _all_reduce_sum(t, group):
+    if isinstance(group, LocalRank):
+        return group.all_reduce(t)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def _all_gather(out, inp, group):
+    if isinstance(group, LocalRank):
+        return group.all_gather_into_tensor(out, inp)
+    dist.all_gather_into_tensor(out, inp, group=group)
+    return out
+
+
 def shard_probes(num_total: int, rank: int, world_size: int):
     """Contiguous split of ``num_total`` probes -> (first_probe, count) of this rank."""
     base, rem = divmod(num_total, world_size)
@@ -47,6 +163,8 @@ def rows_per_rank(n: int, world_size: int) -> int:
 
 
 def _active(group=None):
+    if isinstance(group, LocalRank):
+        return group.world > 1
     return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
 
 
@@ -64,7 +182,7 @@ def reduce_estimate(local_values, local_grads, num_total: int, group=None, repli
     flat += [g.reshape(-1).double() for g in local_grads]
     buf = torch.cat(flat).contiguous()
     if _active(group):
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        _all_reduce_sum(buf, group)
     buf = buf / replicas
     mean = buf[0] / num_total
     var = torch.clamp_min(buf[1] / num_total - mean**2, 0.0)
@@ -104,9 +222,8 @@ class RowComm:
 
     def __init__(self, n: int, group=None):
         self.group = group
-        on = dist.is_available() and dist.is_initialized()
-        self.world = dist.get_world_size(group) if on else 1
-        self.rank = dist.get_rank(group) if on else 0
+        self.world = _group_size(group)
+        self.rank = _group_rank(group)
         self.n = int(n)
         self.nloc = rows_per_rank(self.n, self.world)
         self.row0 = self.rank * self.nloc
@@ -122,7 +239,7 @@ class RowComm:
 
     def all_reduce_(self, t):
         if self.world > 1 or (self.force_collectives and dist.is_available() and dist.is_initialized()):
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            _all_reduce_sum(t, self.group)
         return t
 
     def gather_rows(self, t_local):
@@ -133,7 +250,7 @@ class RowComm:
         send[:, : self.nrows] = flat
         out = torch.empty((self.world * flat.shape[0], self.nloc), dtype=t_local.dtype, device=t_local.device)
         if self.world > 1:
-            dist.all_gather_into_tensor(out, send, group=self.group)  # rank-major blocks along axis 0
+            _all_gather(out, send, self.group)  # rank-major blocks along axis 0
         else:
             out.copy_(send)
         out = out.reshape(self.world, flat.shape[0], self.nloc).movedim(0, 1).reshape(flat.shape[0], self.world * self.nloc)
@@ -144,6 +261,8 @@ class RowComm:
         """Which entries of the iterate do this rank's rows of a CSR matrix (crow, col: device int32) read from other ranks?
         -> (recv, send): lists of (peer, lo, hi) column ranges -- one bounding range per owner, which is tight for banded / block
         structures (stencils) -- to receive from / send to each peer.  Collective over the row group (one all_gather_object)."""
+        if isinstance(self.group, LocalRank):
+            raise NotImplementedError("the neighbour exchange needs a torch.distributed process group (LocalWorld rehearses the all-gather layout)")
         c = col[int(crow[self.row0]) : int(crow[self.row0 + self.nrows])].to(torch.int64)
         owner = torch.div(c, self.nloc, rounding_mode="floor")
         recv = []
@@ -229,7 +348,7 @@ class RowComm:
             try:
                 if collective:
                     with on(stream):
-                        dist.all_reduce(view(buf, count, dtype_code), op=dist.ReduceOp.SUM, group=group)
+                        _all_reduce_sum(view(buf, count, dtype_code), group)
                 return 0
             except Exception as exc:  # never let an exception cross the C boundary
                 failure.append(exc)
@@ -240,7 +359,7 @@ class RowComm:
                 tin, tout = view(inp, count, dtype_code), view(out, count * world, dtype_code)
                 with on(stream):
                     if collective:
-                        dist.all_gather_into_tensor(tout, tin, group=group)
+                        _all_gather(tout, tin, group)
                     else:
                         tout.copy_(tin)
                 return 0
@@ -268,13 +387,22 @@ class NativeRowComm(RowComm):
         super().__init__(n, group)
         lib = _lib.get()
         uid = torch.zeros(128, dtype=torch.uint8)
+        # rank 0 ALWAYS takes part in the broadcast, also when it could not make the id: (ok, message, id) travels, and every rank
+        # raises -- or goes on -- after the same collective (a rank 0 that raised before the broadcast would leave its peers inside it)
+        ok, why = True, ""
         if self.rank == 0:
-            _lib.check(lib.mfx_rccl_unique_id(uid.data_ptr(), uid.numel()))
+            try:
+                _lib.check(lib.mfx_rccl_unique_id(uid.data_ptr(), uid.numel()))
+            except Exception as exc:  # noqa: BLE001
+                ok, why = False, str(exc)
         if self.world > 1:
-            box = [bytes(uid.tolist())]
+            box = [(ok, why, bytes(uid.tolist()))]
             src = dist.get_process_group_ranks(group)[0] if group is not None else 0
             dist.broadcast_object_list(box, src=src, group=group)
-            uid = torch.tensor(list(box[0]), dtype=torch.uint8)
+            ok, why, raw = box[0]
+            uid = torch.tensor(list(raw), dtype=torch.uint8)
+        if not ok:
+            raise RuntimeError(f"the first rank of the row group could not make an RCCL unique id: {why}")
         self._cm = _lib.Comm()
         _lib.check(lib.mfx_comm_create_rccl(uid.data_ptr(), uid.numel(), self.rank, self.world, self.nloc, C.byref(self._cm)))
 
@@ -418,13 +546,20 @@ class Layout:
     def __init__(self, n: int, row_group_size: int = 1, group=None, native: bool | None = None):
         """native: the row group's collectives as libmfx's own RCCL calls (NativeRowComm); default: whenever the process
         group's backend is "nccl" (= RCCL), i.e. one GPU per rank -- gloo rehearsals keep the callback path."""
-        on = dist.is_available() and dist.is_initialized()
+        on = isinstance(group, LocalRank) or (dist.is_available() and dist.is_initialized())
         self.group = group
-        self.world = dist.get_world_size(group) if on else 1
-        rank = dist.get_rank(group) if on else 0
+        self.world = _group_size(group)
+        rank = _group_rank(group)
         self.n = int(n)
         self.replicas = int(row_group_size)
         if self.replicas > 1:
+            if isinstance(group, LocalRank):  # in-process rehearsal: pure row sharding over the logical ranks, host-rendezvous collectives
+                if self.world != self.replicas:
+                    raise ValueError("a LocalWorld rehearses pure row sharding: row_group_size must equal its number of ranks")
+                self.probe_index, self.probe_groups = 0, 1
+                self.comm = RowComm(n, group)
+                self.native = False
+                return
             if self.world > self.replicas:
                 row_group, self.probe_index, self.probe_groups = make_grid(self.replicas, group)
             elif self.world == self.replicas:

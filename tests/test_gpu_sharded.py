@@ -564,3 +564,34 @@ def test_rccl_one_rank_group_runs_the_collective_callbacks():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rccl_one_rank.py"), str(port)], env=env, capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+# ---- the 8-way row shard of BASELINE config 4, rehearsed on ONE GPU in ONE process ---------------------------------------------
+@pytest.mark.parametrize("dtype_name,precision,vtol,gtol", [("float64", "fp32", 1e-10, 1e-8), ("float32", "f16x3", 2e-5, 5e-4)])
+@pytest.mark.parametrize("n", [8 * 2048, 8 * 2048 - 700])
+def test_eight_logical_ranks_in_one_process_reproduce_the_single_rank_estimate(dtype_name, precision, vtol, gtol, n):
+    """`bench.py --gpus 8` shards the rows of config 4 eight ways.  A GPU box admits at most six processes on its card, so the
+    eight ranks are eight THREADS here (`distributed.LocalWorld`: host-rendezvous collectives, everything else -- the sharded
+    drivers, their workspaces and callbacks, the row-block matvec with its column splits, the row-block gradient sweep, the fused
+    reduction of the estimate -- is the code the eight processes run).  Even shards (8 x 2048 rows) and a ragged last shard."""
+    from matfree_extensions.distributed import LocalWorld, slq_value_and_grad
+
+    dtype = getattr(torch, dtype_name)
+    d, k, p = 8, 10, 16
+    op, params = _rbf(n, d, dtype, precision, ard=False)
+    ps = [q.clone().requires_grad_(True) for q in params]
+    mean, std, grads = slq_value_and_grad(op, torch.log, k, ps, n=n, seed=3, num_probes=p, dtype=dtype, device=_dev())
+
+    def rank_body(handle):
+        mine = [q.detach().clone().requires_grad_(True) for q in params]
+        m, s, g = slq_value_and_grad(op, torch.log, k, mine, n=n, seed=3, num_probes=p, row_group_size=handle.world, group=handle,
+                                     dtype=dtype, device=_dev())
+        return m.item(), s.item(), [t.detach().cpu() for t in g]
+
+    results = LocalWorld(8).run(rank_body)
+    for m, s, g in results:  # identical on every rank, equal to the single-rank estimate
+        assert m == results[0][0] and s == results[0][1]
+        assert np.isclose(m, mean.item(), rtol=vtol)
+        assert np.isclose(s, std.item(), rtol=1e-4, atol=1e-6 * abs(mean.item()))
+        for a, b in zip(g, grads):
+            assert torch.allclose(a, b.cpu(), rtol=gtol, atol=gtol * b.abs().max().item()), (a, b)

@@ -58,6 +58,8 @@ struct Args {
   const _Float16 *Lh, *Ll, *Rh, *Rl;
   int64_t npad_l, npad_r, nkb;
   int tiles_per_block;
+  int chunk_major;    // V3 only: 1 = ONE tile per workgroup, workgroups ordered (column chunk of 64 tiles, row block, tile of the chunk): the
+                      // 168-MB R chunk all XCDs are working on stays in the Infinity Cache while the row blocks stream past it
   double* out;        // one checksum per workgroup
   long long* stamps;  // per workgroup: shader cycles, 100 MHz ticks
 };
@@ -223,10 +225,17 @@ __global__ __launch_bounds__(512, 1) void k_v3(Args g) {
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lq = lane >> 4;
   const int wm = wid >> 1, wn = wid & 1;
-  const int64_t i0 = (int64_t)(blockIdx.y / kSub) * kTM;
+  int64_t i0 = (int64_t)(blockIdx.y / kSub) * kTM;
   const int64_t ntj = g.npad_r / kTN;
-  const int64_t tj_begin = ((int64_t)blockIdx.x * kSub + blockIdx.y % kSub) * g.tiles_per_block;
+  int64_t tj_begin = ((int64_t)blockIdx.x * kSub + blockIdx.y % kSub) * g.tiles_per_block;
   int64_t tj_end = tj_begin + g.tiles_per_block;
+  if (g.chunk_major) {
+    const int64_t per_chunk = (g.npad_l / kTM) * kSub;  // workgroups (per XCD label) of one column chunk
+    const int64_t chunk = blockIdx.y / per_chunk, rem = blockIdx.y % per_chunk;
+    i0 = (rem / kSub) * kTM;
+    tj_begin = chunk * (kSplit * kSub) + (int64_t)blockIdx.x * kSub + rem % kSub;
+    tj_end = tj_begin + 1;
+  }
   if (tj_end > ntj) tj_end = ntj;
   const int nstage = (int)(g.nkb / 4);
   const char* gbase[4] = {(const char*)g.Lh, (const char*)g.Ll, (const char*)g.Rh, (const char*)g.Rl};
@@ -556,11 +565,11 @@ int main(int argc, char** argv) {
   const int tiles_per_block = (int)(ntj / (kSplit * kSub));
   const dim3 grid(kSplit, (unsigned)(nti * kSub));
   const int64_t nwg = (int64_t)grid.x * grid.y;
-  double* out[16];
+  double* out[17];
   long long* stamps;
-  for (int v = 0; v < 16; ++v) CK(hipMalloc(&out[v], nwg * 8));
-  CK(hipMalloc(&stamps, nwg * 16));
-  Args a{Lh, Ll, Rh, Rl, rows, cols, nkb, tiles_per_block, nullptr, stamps};
+  for (int v = 0; v < 17; ++v) CK(hipMalloc(&out[v], nwg * 8 * tiles_per_block));
+  CK(hipMalloc(&stamps, nwg * 16 * tiles_per_block));
+  Args a{Lh, Ll, Rh, Rl, rows, cols, nkb, tiles_per_block, 0, nullptr, stamps};
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_v0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmemV0)));
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fat<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kSlotBytes));
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fat<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kSlotBytes));
@@ -571,18 +580,19 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const double mfma_cycles_per_simd_per_tile = (double)(nkb / 2) * 48.0 * 32.0;  // both layouts: 48 MFMAs per SIMD and 16-row stage
-  const char* names[15] = {"V0 round-3 loop (32x32x16, 8 waves, ping-pong)", "V1 fat waves, LDS-DMA", "V2 fat waves, register staging",
+  const char* names[16] = {"V0 round-3 loop (32x32x16, 8 waves, ping-pong)", "V1 fat waves, LDS-DMA", "V2 fat waves, register staging",
                            "V3 as V0 on 16x16x32 (K = 32 stages)", "V3.1 column blocks outer", "V3.2 no s_setprio", "V3.3 products grouped",
                            "V3.4 [diag] no LDS-DMA", "V3.5 [diag] no fragment reads", "V3.6 [diag] neither", "V3.7 [diag] neither, no barriers",
-                           "V3.2 + sc0 loads", "V3.2 + nt loads", "V3.2 + sc1 loads", "V3.2 + sc0 nt loads"};
+                           "V3.2 + sc0 loads", "V3.2 + nt loads", "V3.2 + sc1 loads", "V3.2 + sc0 nt loads", "V3.2 chunk-major, one tile per workgroup"};
   const unsigned vmask = argc > 5 ? (unsigned)strtoul(argv[5], nullptr, 0) : 0xFu;
   std::vector<double> ref, cur(nwg);
   std::vector<long long> st(2 * nwg);
   for (int rep = 0; rep < reps; ++rep)
-    for (int v = 0; v < 15; ++v) {
+    for (int v = 0; v < 16; ++v) {
       if (!((vmask >> v) & 1)) continue;
       a.out = out[v];
-      CK(hipMemset(out[v], 0, nwg * 8));
+      const int64_t nwg_v = v == 15 ? nwg * tiles_per_block : nwg;
+      CK(hipMemset(out[v], 0, nwg_v * 8));
       CK(hipEventRecord(e0));
       if (v == 0) k_v0<<<grid, 512, sizeof(SmemV0)>>>(a);
       else if (v == 1) k_fat<1><<<grid, 256, 4 * kSlotBytes>>>(a);
@@ -598,28 +608,43 @@ int main(int argc, char** argv) {
       else if (v == 11) k_v3<2, 1><<<grid, 512, 2 * kSlot3>>>(a);
       else if (v == 12) k_v3<2, 2><<<grid, 512, 2 * kSlot3>>>(a);
       else if (v == 13) k_v3<2, 16><<<grid, 512, 2 * kSlot3>>>(a);
-      else k_v3<2, 3><<<grid, 512, 2 * kSlot3>>>(a);
+      else if (v == 14) k_v3<2, 3><<<grid, 512, 2 * kSlot3>>>(a);
+      else {
+        a.chunk_major = 1;
+        k_v3<2><<<dim3(grid.x, grid.y * tiles_per_block), 512, 2 * kSlot3>>>(a);
+        a.chunk_major = 0;
+      }
       CK(hipEventRecord(e1));
       CK(hipEventSynchronize(e1));
       CK(hipGetLastError());
       float ms;
       CK(hipEventElapsedTime(&ms, e0, e1));
-      CK(hipMemcpy(cur.data(), out[v], nwg * 8, hipMemcpyDeviceToHost));
-      CK(hipMemcpy(st.data(), stamps, nwg * 16, hipMemcpyDeviceToHost));
-      if (ref.empty() || (v == 0)) ref = cur;
+      cur.resize(nwg_v);
+      st.resize(2 * nwg_v);
+      CK(hipMemcpy(cur.data(), out[v], nwg_v * 8, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(st.data(), stamps, nwg_v * 16, hipMemcpyDeviceToHost));
       double worst = 0.0, big = 0.0;  // largest difference relative to the largest checksum (single checksums cancel to ~0)
-      for (int64_t i = 0; i < nwg; ++i) { worst = std::max(worst, fabs(cur[i] - ref[i])); big = std::max(big, fabs(ref[i])); }
-      worst /= big + 1e-300;
-      std::vector<double> clk(nwg), util(nwg);
-      for (int64_t i = 0; i < nwg; ++i) {
+      if (v == 15) {  // other workgroup numbering: compare the sum over all tiles
+        double tot = 0.0, tot_ref = 0.0, babs = 0.0;
+        for (int64_t i = 0; i < nwg_v; ++i) tot += cur[i];
+        for (size_t i = 0; i < ref.size(); ++i) { tot_ref += ref[i]; babs = std::max(babs, fabs(ref[i])); }
+        worst = fabs(tot - tot_ref) / (babs + 1e-300);
+      } else {
+        if (ref.empty() || (v == 0)) ref = cur;
+        for (int64_t i = 0; i < nwg; ++i) { worst = std::max(worst, fabs(cur[i] - ref[i])); big = std::max(big, fabs(ref[i])); }
+        worst /= big + 1e-300;
+      }
+      const int tpb = v == 15 ? 1 : tiles_per_block;
+      std::vector<double> clk(nwg_v), util(nwg_v);
+      for (int64_t i = 0; i < nwg_v; ++i) {
         clk[i] = (double)st[2 * i] / (double)st[2 * i + 1] * 0.1;  // GHz
-        util[i] = mfma_cycles_per_simd_per_tile * tiles_per_block / (double)st[2 * i];
+        util[i] = mfma_cycles_per_simd_per_tile * tpb / (double)st[2 * i];
       }
       std::sort(clk.begin(), clk.end());
       std::sort(util.begin(), util.end());
       const double flops = 2.0 * rows * cols * batch;
       printf("rep %d  %-48s %8.2f ms  %6.1f TFLOP/s algorithmic  clock %.3f GHz  matrix pipe %.1f %% of the workgroup's cycles  max rel diff vs V0 %.2e\n",
-             rep, names[v], ms, flops / ms * 1e-9, clk[nwg / 2], 100.0 * util[nwg / 2], worst);
+             rep, names[v], ms, flops / ms * 1e-9, clk[nwg_v / 2], 100.0 * util[nwg_v / 2], worst);
       fflush(stdout);
     }
   return 0;

@@ -1,0 +1,66 @@
+"""BASELINE config 4 in the layout `bench.py --gpus 8` runs -- the rows of the kernel matrix and of every Krylov vector sharded
+eight ways, all 64 probes on every rank -- rehearsed on ONE GPU: the eight ranks are eight threads of this process
+(`matfree_extensions.distributed.LocalWorld`; a GPU box admits at most six processes on its card).  Everything but the transport
+of the collectives is the code the eight processes run: the sharded drivers with their per-step all-gather and all-reduces, the
+row-block Gram matvec (16 384 rows: 8 column splits that coincide with the 8 shards), the row-block gradient sweep, the fused
+reduction of the estimate.  Prints one JSON line: the 8-rank result, the single-rank result of the same probes, their
+differences.  Timings of the 8-rank leg mean nothing (eight ranks share one GPU, collectives go through host rendezvous).
+
+    python tools/rehearse_eight_ranks.py [--ranks 8] [--n 131072] [--precision f16x3]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "experiments-lanczos-adjoints_amd"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from matfree_extensions.distributed import LocalWorld, slq_value_and_grad  # noqa: E402
+from matfree_extensions.util import gp_util  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--ranks", type=int, default=8)
+ap.add_argument("--n", type=int, default=131072)
+ap.add_argument("--d", type=int, default=8)
+ap.add_argument("--k", type=int, default=40)
+ap.add_argument("--probes", type=int, default=64)
+ap.add_argument("--precision", default="f16x3")
+args = ap.parse_args()
+
+dev = torch.device("cuda:0")
+inv = lambda v: float(np.log(np.expm1(v)))  # noqa: E731
+gen = torch.Generator().manual_seed(4)
+X = torch.randn((args.n, args.d), generator=gen, dtype=torch.float32).to(dev)  # bench.py's inputs
+raw = [inv(2.0), inv(1.0), inv(0.1)]
+op = gp_util.gram_operator(X, precision=args.precision)
+
+
+def estimate(group=None, rows=1):
+    params = [torch.tensor(v, dtype=torch.float32, device=dev, requires_grad=True) for v in raw]
+    mean, std, grads = slq_value_and_grad(op, torch.log, args.k, params, n=args.n, seed=0, num_probes=args.probes, row_group_size=rows,
+                                          group=group, dtype=torch.float32, device=dev)
+    return float(mean), float(std), [float(g) for g in grads]
+
+
+t0 = time.perf_counter()
+single = estimate()
+torch.cuda.synchronize()
+t1 = time.perf_counter()
+many = LocalWorld(args.ranks).run(lambda h: estimate(h, h.world))
+t2 = time.perf_counter()
+same = all(r == many[0] for r in many)
+rel = lambda a, b: abs(a - b) / abs(b)  # noqa: E731
+print(json.dumps({
+    "what": f"config 4 (N={args.n}, d={args.d}, k={args.k}, {args.probes} probes, {args.precision}) as {args.ranks} row shards on one GPU "
+            "(logical ranks = threads, host-rendezvous collectives) against the single-rank run of the same probes",
+    "rows_per_rank": -(-args.n // args.ranks),
+    "result_ranks": {"logdet_mean": many[0][0], "probe_std": many[0][1], "grad": many[0][2]},
+    "result_single": {"logdet_mean": single[0], "probe_std": single[1], "grad": single[2]},
+    "identical_on_every_rank": same,
+    "rel_diff": {"logdet_mean": rel(many[0][0], single[0]), "grad": [rel(a, b) for a, b in zip(many[0][2], single[2])]},
+    "seconds": {"single_rank_incl_first_call": t1 - t0, "logical_ranks_leg_not_a_timing": t2 - t1},
+}))
