@@ -63,6 +63,8 @@ def parse(argv=None):
     ap.add_argument("--stub", default="", help="(tests) run the launcher / collection logic on this backend without any GPU work")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the N > 1 run (nccl = RCCL; gloo only to rehearse "
                                                       "the multi-rank path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--gather", default="", choices=["", "grouped", "packed"],
+                    help="native RCCL row group: how the iterate is all-gathered per Krylov step (include/mfx.h MFX_GATHER_*; default grouped)")
     ap.add_argument("--share-gpus", action="store_true", help="(rehearsal) ranks beyond the visible GPUs share them (needs --backend gloo)")
     args = ap.parse_args(argv)
     if args.probes_per_gpu is not None:
@@ -245,6 +247,8 @@ def main(argv=None):
         else:
             dist.init_process_group(args.backend, timeout=limit, **how)
 
+    if args.gather:
+        os.environ["MFX_GATHER"] = args.gather
     from matfree_extensions import _lib, hutchinson, lanczos
     from matfree_extensions.distributed import Layout, reduce_estimate, shard_probes
     from matfree_extensions.operators import RowShardedOp
@@ -363,7 +367,7 @@ def main(argv=None):
                 "N": n, "d": d, "krylov_depth": k, "probes_total": p_total, "probes_on_this_rank": count,
                 "rows_on_this_rank": rows_local,
                 "parallelism": f"{layout.describe()}; world size seen by rank 0 = {dist.get_world_size() if world > 1 else 1}; "
-                               f"row-group collectives: {'libmfx -> RCCL (native)' if layout.native else ('host callbacks' if layout.comm is not None else 'none')}",
+                               f"row-group collectives: {('libmfx -> RCCL (native, ' + layout.comm.gather + ' gather)') if layout.native else ('host callbacks' if layout.comm is not None else 'none')}",
                 "gram_precision": args.precision, "kernel": args.kernel,
             },
             "modes": {"ms_per_step": modes,

@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <stdio.h>
 #include <string.h>
 
 #include <mutex>
@@ -33,6 +34,8 @@ struct RcclApi {
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
 
+char g_rccl_why[256] = "unknown";  // why rccl() is null: written once, inside the call_once below
+
 RcclApi* rccl() {
   static RcclApi api;
   static std::once_flag once;
@@ -41,6 +44,8 @@ RcclApi* rccl() {
     for (const char* nm : names) {
       api.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
       if (api.lib) break;
+      const char* e = dlerror();  // (null unless the failure was the most recent dl* call: read it right here)
+      snprintf(g_rccl_why, sizeof(g_rccl_why), "librccl.so.1 could not be loaded: %s", e ? e : "unknown");
     }
     if (!api.lib) return;
 #define MFX_SYM(field, name) api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.lib, name))
@@ -53,8 +58,11 @@ RcclApi* rccl() {
     MFX_SYM(GroupEnd, "ncclGroupEnd");
     MFX_SYM(GetErrorString, "ncclGetErrorString");
 #undef MFX_SYM
-    if (!(api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce && api.AllGather && api.GroupStart && api.GroupEnd))
+    if (!(api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce && api.AllGather && api.GroupStart && api.GroupEnd)) {
+      snprintf(g_rccl_why, sizeof(g_rccl_why), "librccl was loaded but lacks one of the entry points used here (ncclGetUniqueId ... ncclGroupEnd)");
+      dlclose(api.lib);
       api.lib = nullptr;
+    }
   });
   return api.lib ? &api : nullptr;
 }
@@ -118,7 +126,7 @@ int mfx_rccl_unique_id(void* id, int64_t bytes) {
   MFX_REQUIRE(id && bytes >= (int64_t)sizeof(ncclUniqueId), MFX_ERR_INVALID, "unique-id buffer of %lld bytes, need %zu", (long long)bytes,
               sizeof(ncclUniqueId));
   RcclApi* a = rccl();
-  MFX_REQUIRE(a, MFX_ERR_UNSUPPORTED, "librccl.so.1 could not be loaded: %s", dlerror());
+  MFX_REQUIRE(a, MFX_ERR_UNSUPPORTED, "%s", g_rccl_why);
   ncclUniqueId uid;
   MFX_NCCL(a->GetUniqueId(&uid));
   memcpy(id, &uid, sizeof(uid));
@@ -130,7 +138,7 @@ int mfx_comm_create_rccl(const void* id, int64_t bytes, int32_t rank, int32_t wo
   MFX_REQUIRE(id && out && bytes >= (int64_t)sizeof(ncclUniqueId), MFX_ERR_INVALID, "null argument or short unique id");
   MFX_REQUIRE(world >= 1 && rank >= 0 && rank < world && nloc >= 1, MFX_ERR_INVALID, "rank %d of %d, nloc %lld", rank, world, (long long)nloc);
   RcclApi* a = rccl();
-  MFX_REQUIRE(a, MFX_ERR_UNSUPPORTED, "librccl.so.1 could not be loaded: %s", dlerror());
+  MFX_REQUIRE(a, MFX_ERR_UNSUPPORTED, "%s", g_rccl_why);
   ncclUniqueId uid;
   memcpy(&uid, id, sizeof(uid));
   NativeComm* nc = new NativeComm();
@@ -148,6 +156,15 @@ int mfx_comm_create_rccl(const void* id, int64_t bytes, int32_t rank, int32_t wo
   out->ctx = nc;
   out->exchange = nullptr;
   out->allgather_rows = native_allgather_rows;
+  return MFX_OK;
+}
+
+int mfx_comm_rccl_gather_mode(mfx_comm* comm, int mode) {
+  using namespace mfx;
+  MFX_REQUIRE(comm && comm->ctx && comm->allreduce_sum == native_allreduce, MFX_ERR_INVALID, "not a communicator of mfx_comm_create_rccl");
+  MFX_REQUIRE(mode == MFX_GATHER_GROUPED || mode == MFX_GATHER_PACKED, MFX_ERR_INVALID, "gather mode %d", mode);
+  // packed: the drivers take their generic path -- k_pack_shard, ONE ncclAllGather of the (p, nloc) shard (native_allgather), k_unshard
+  comm->allgather_rows = mode == MFX_GATHER_GROUPED ? native_allgather_rows : nullptr;
   return MFX_OK;
 }
 

@@ -383,9 +383,17 @@ class NativeRowComm(RowComm):
     CURRENT device (``torch.cuda.set_device(local_rank)`` first).  The host-side helpers (``all_reduce_`` of the parameter
     gradients, ``gather_rows``) and a sparse operator's neighbour exchange stay on torch.distributed."""
 
-    def __init__(self, n: int, group=None):
+    GATHER = {"grouped": 0, "packed": 1}
+
+    def __init__(self, n: int, group=None, gather: str | None = None):
+        """gather: "grouped" (p all-gathers of nloc elements in one group launch, straight into the operator input; the default) or
+        "packed" (pack, ONE all-gather of p nloc elements, unpack) -- `include/mfx.h`, MFX_GATHER_*; default from $MFX_GATHER."""
         super().__init__(n, group)
         lib = _lib.get()
+        gather = gather or os.environ.get("MFX_GATHER", "grouped")
+        if gather not in self.GATHER:
+            raise ValueError(f"gather mode {gather!r}: expected one of {sorted(self.GATHER)}")
+        self.gather = gather
         uid = torch.zeros(128, dtype=torch.uint8)
         # rank 0 ALWAYS takes part in the broadcast, also when it could not make the id: (ok, message, id) travels, and every rank
         # raises -- or goes on -- after the same collective (a rank 0 that raised before the broadcast would leave its peers inside it)
@@ -405,6 +413,7 @@ class NativeRowComm(RowComm):
             raise RuntimeError(f"the first rank of the row group could not make an RCCL unique id: {why}")
         self._cm = _lib.Comm()
         _lib.check(lib.mfx_comm_create_rccl(uid.data_ptr(), uid.numel(), self.rank, self.world, self.nloc, C.byref(self._cm)))
+        _lib.check(lib.mfx_comm_rccl_gather_mode(C.byref(self._cm), self.GATHER[gather]))
 
     def struct(self, ws, tensors=(), plans=None):
         if plans is not None:  # neighbour exchange: callbacks (the exchange plan lives on the host side)
@@ -419,8 +428,12 @@ class NativeRowComm(RowComm):
         rc = self._cm.allreduce_sum(self._cm.ctx, ones.data_ptr(), ones.numel(), _lib.MFX_F64, stream)
         local = torch.full((2, 4), float(self.rank + 1), dtype=torch.float32, device=dev)
         full = torch.zeros((2, 4 * self.world), dtype=torch.float32, device=dev)
-        rc |= self._cm.allgather_rows(self._cm.ctx, local.data_ptr(), 4, full.data_ptr(), 4 * self.world, 2, 4, _lib.MFX_F32, stream)
-        want = torch.arange(1, self.world + 1, dtype=torch.float32, device=dev).repeat_interleave(4).expand(2, -1)
+        if self.gather == "grouped":
+            rc |= self._cm.allgather_rows(self._cm.ctx, local.data_ptr(), 4, full.data_ptr(), 4 * self.world, 2, 4, _lib.MFX_F32, stream)
+            want = torch.arange(1, self.world + 1, dtype=torch.float32, device=dev).repeat_interleave(4).expand(2, -1)
+        else:  # the packed leg: one all-gather of the whole (2, 4) shard, rank-major blocks
+            rc |= self._cm.allgather(self._cm.ctx, local.data_ptr(), full.data_ptr(), 8, _lib.MFX_F32, stream)
+            want = torch.arange(1, self.world + 1, dtype=torch.float32, device=dev).repeat_interleave(8).reshape(2, -1)
         return rc == 0 and bool((ones == self.world).all()) and bool((full == want).all())
 
     def close(self):

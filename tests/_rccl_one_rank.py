@@ -73,6 +73,14 @@ def main():
     print("native communicator, three-term + CG: bit-identical to the callback path:", same2)
     ok = ok and same2
     ncomm.close()
+    # the second gather leg: pack, ONE ncclAllGather of the whole (p, nloc) shard, unpack -- same numbers again
+    pcomm = NativeRowComm(n, gather="packed")
+    v3, g3 = run(RowShardedOp(op, pcomm))
+    torch.cuda.synchronize()
+    same3 = torch.equal(v1, v3) and all(torch.equal(a, b) for a, b in zip(g1, g3)) and pcomm.self_test()
+    print("native communicator, packed gather: bit-identical to the callback path:", same3)
+    ok = ok and same3
+    pcomm.close()
     # what Layout does by default on an RCCL group: native communicator after an agreed availability check and self-test; when the
     # self-test (here: made to) fails on a rank, ALL ranks take the torch.distributed callbacks, with a warning
     import warnings

@@ -42,34 +42,40 @@ def _slq(X, raw, k, probes, precision):
 # ------------------------------------------------------------------------------------------------------------------------
 # C4 accuracy gate
 # ------------------------------------------------------------------------------------------------------------------------
-@pytest.fixture(scope="module")
-def c4_fp64():
-    # the stated config: ALL 64 probes (32 s for the fp64 leg).  With 8 probes the comparison is dominated by the rounding noise of
-    # the fp32 Krylov recurrences, which averages out over the probes: the same build measured 1.4e-4 on dl with 8 probes and
-    # 3.8e-6 with 64 (profiles/r02a_accuracy).
+@pytest.fixture(scope="module", params=[0, 3], ids=["probe-seed-0", "probe-seed-3"])
+def c4_fp64(request):
+    # the stated config: ALL 64 probes (32 s for the fp64 leg of a probe set).  With 8 probes the comparison is dominated by the
+    # rounding noise of the fp32 Krylov recurrences, which averages out over the probes: the same build measured 1.4e-4 on dl with 8
+    # probes and 3.8e-6 with 64 (profiles/r02a_accuracy).
+    # TWO probe sets: seed 0 (the committed tables) and seed 3 -- the WORST of the four sets measured so far (worst gradient component
+    # 6.1e-5 f16x3 / 7.2e-5 f16x3-matvec, profiles/r04a_*/accuracy_seeds_1_2_3.log; seed 0: 1.2e-5 / 5.0e-5).
     n, d, k, p = 131072, 8, 40, 64
     gen = torch.Generator().manual_seed(4)
     X64 = torch.randn((n, d), generator=gen, dtype=torch.float32).double().to(DEV)
     raw = (INV(2.0), INV(1.0), INV(0.1))
-    probes = hutchinson.sampler_rademacher(X64[:, 0], num=p)(0)
+    probes = hutchinson.sampler_rademacher(X64[:, 0], num=p)(request.param)
     val, grad = _slq(X64, raw, k, probes, "fp32")  # fp64 operators ignore the mode: VALU fp64 kernels
     torch.cuda.empty_cache()
-    return X64, raw, k, probes, val, grad
+    return X64, raw, k, probes, val, grad, request.param
 
 
-# Measured (profiles/r02a_accuracy/table_end_of_round.log, 64 probes): value / worst gradient component
-#   f16x3 5.4e-6 / 1.2e-5, f16x3-matvec 5.4e-6 / 5.0e-5, fp32 (exact fp32 MFMA, the arithmetic closest to the reference's fp32) 7.6e-5 / 1.8e-3;
-#   three other probe sets: 1.8e-5 ... 7.2e-5 (table_other_probe_sets.log).
+# Measured (profiles/r04a_grad_gemm_16x16x32/accuracy_*.log, 64 probes): value / worst gradient component
+#   seed 0: f16x3 5.4e-6 / 1.2e-5, f16x3-matvec 5.4e-6 / 5.0e-5, fp32 (exact fp32 MFMA, the arithmetic closest to the reference's fp32) 7.6e-5 / 1.8e-3;
+#   seed 3: f16x3 4.1e-6 / 6.1e-5, f16x3-matvec 4.1e-6 / 7.2e-5;  seeds 1, 2: 1.9e-5 ... 5.9e-5.
 @pytest.mark.parametrize("precision,vtol,gtol", [("f16x3", 1e-4, 1e-4), ("f16x3-matvec", 1e-4, 1e-4), ("fp32", 2e-4, 5e-3)])
 def test_c4_full_size_accuracy_gate(c4_fp64, precision, vtol, gtol):
     """north_star: "matching [...] to rtol 1e-4" on the C4 log-det value and gradient.  The two modes that run the Gram
-    contraction on the f16 matrix pipe meet it against fp64; plain fp32 MFMA accumulation over 131072 columns does not (stated
-    bound 5e-3) -- which is also why agreement with ANOTHER fp32 implementation cannot be better than ~1e-3 at this size."""
-    X64, raw, k, probes, val64, grad64 = c4_fp64
+    contraction on the f16 matrix pipe meet it against fp64 on both probe sets; plain fp32 MFMA accumulation over 131072 columns does
+    not (stated bound 5e-3, held on the first probe set only) -- which is also why agreement with ANOTHER fp32 implementation cannot
+    be better than ~1e-3 at this size.  (Reference tolerance for its own fp32 comparison: sqrt(eps),
+    tests/test_lanczos/test_integrand_spd_value_and_grad.py:36-38.)"""
+    X64, raw, k, probes, val64, grad64, seed = c4_fp64
+    if precision == "fp32" and seed != 0:
+        pytest.skip("the exact-fp32 mode is a stated NON-gate (5e-3): one probe set is enough")
     val, grad = _slq(X64.float(), raw, k, probes, precision)
     assert abs(val - val64) <= vtol * abs(val64), (val, val64)
     rel = np.abs(grad - grad64) / np.abs(grad64)
-    assert np.all(rel <= gtol), (precision, rel)
+    assert np.all(rel <= gtol), (precision, seed, rel)
 
 
 # ------------------------------------------------------------------------------------------------------------------------
@@ -289,3 +295,29 @@ def test_c5_full_size_expm_arnoldi_against_the_taylor_series():
         both, _ = expm(op, dt, 2.0 * y0 - 3.0 * y1, vals)
         out1, _ = expm(op, dt, y1, vals)
         assert float((both - (2.0 * out - 3.0 * out1)).norm() / both.norm()) < 1e-12
+
+
+def test_c5_full_size_expm_arnoldi_adjoint_identity():
+    """BASELINE config 5 is "exp(tA)b + adjoint" at N = 1e6 grid points (state 2e6): the gradient of the Arnoldi matrix exponential
+    w.r.t. the 1e6 entries of the coefficient field (util/pde_util.py:257-268 differentiated through arnoldi.hessenberg's custom adjoint,
+    arnoldi.py:104-220, with the CSR operator's gradient w.r.t. all 6e6 stored values) at the STATED size, k = 30, fp64.
+    Adjoint identity <J delta, w> = <delta, J^T w>: J^T w by the adjoint pass, J delta by a central difference of the forward map along one random
+    direction (relative step 1e-4: truncation ~1e-8, rounding ~1e-11 of the directional derivative)."""
+    res, k, dt = 1000, 30, 1e-3
+    op, values_fn = pde_util.wave_operator(res, 1.0 / res, boundary="neumann", device=DEV)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    scale = ((0.01 * torch.randn((res, res), dtype=torch.float64, device=DEV, generator=g)) ** 2 + 1e-6).requires_grad_(True)
+    y0 = torch.randn(2 * res * res, dtype=torch.float64, device=DEV, generator=g)
+    w = torch.randn(2 * res * res, dtype=torch.float64, device=DEV, generator=g)
+    delta = scale.detach() * torch.randn((res, res), dtype=torch.float64, device=DEV, generator=g)
+    expm = pde_util.expm_arnoldi(k)
+    out, _ = expm(op, dt, y0, values_fn(scale))
+    (jtw,) = torch.autograd.grad((out * w).sum(), [scale])
+    lhs = float((jtw * delta).sum())
+    h = 1e-4
+    with torch.no_grad():
+        up, _ = expm(op, dt, y0, values_fn(scale.detach() + h * delta))
+        dn, _ = expm(op, dt, y0, values_fn(scale.detach() - h * delta))
+        rhs = float(((up - dn) * w).sum()) / (2 * h)
+    assert np.isfinite(lhs) and abs(rhs) > 0
+    assert abs(lhs - rhs) <= 1e-6 * abs(rhs), (lhs, rhs)

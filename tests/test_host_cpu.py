@@ -120,3 +120,57 @@ def test_key_splitting_and_probe_sharding():
         covered += list(range(first, first + count))
     assert covered == list(range(64))
     assert [shard_probes(10, r, 4) for r in range(4)] == [(0, 3), (3, 3), (6, 2), (8, 2)]
+
+
+def _kernel_metadata():
+    """{demangled-ish kernel name: (vgpr_count, vgpr_spill_count, private_segment_fixed_size)} of every gfx950 kernel in the BUILT
+    libmfx.so (the AMDGPU metadata notes of its code objects)."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    objdump, readelf = "/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(objdump) and os.path.exists(readelf) and os.path.exists(_lib.LIB_PATH)):
+        pytest.skip("needs the ROCm llvm tools and a built libmfx.so")
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        so = shutil.copy(_lib.LIB_PATH, os.path.join(tmp, "libmfx.so"))
+        subprocess.run([objdump, "--offloading", so], cwd=tmp, check=True, capture_output=True)  # extracts the bundles next to the copy
+        for f in sorted(os.listdir(tmp)):
+            if "gfx950" not in f:
+                continue
+            notes = subprocess.run([readelf, "--notes", os.path.join(tmp, f)], check=True, capture_output=True, text=True).stdout
+            for block in re.split(r"\n\s+- \.agpr_count:", notes)[1:]:
+                name = re.search(r"\.name:\s+(\S+)", block)
+                if not name:
+                    continue
+                num = lambda key: int(re.search(r"\." + key + r":\s+(\d+)", block).group(1))  # noqa: E731
+                out[name.group(1)] = (num("vgpr_count"), num("vgpr_spill_count"), num("private_segment_fixed_size"))
+    return out
+
+
+def test_hot_kernels_scratch_budget_from_the_code_object():
+    """DESIGN.md states what scratch the matrix-core kernels use; this reads it from the code object so the statement cannot rot
+    (round 3's "zero scratch" had become untrue when a kernel was re-templated).  What is allowed, and where it executes:
+    * k_rbf_fat_apply<*, *, 2>: 68 B -- one 8-byte spill pair around the CHAIN FOLD (once per 128 tiles) and one around the sweep;
+      nothing per tile.  The <*, *, 1> forms: none.
+    * k_rbf_mfma_grad_h (256 x 256 tile): <= 128 B -- row constants of the epilogue, reloaded once per TILE (160 stages); nothing in
+      the stage loop.  The 256 x 128 forms: none.
+    * every other kernel of the library: none."""
+    meta = _kernel_metadata()
+    assert len(meta) > 300, len(meta)
+    hot = 0
+    for name, (vgpr, spill, scratch) in meta.items():
+        if "k_rbf_fat_apply" in name:
+            hot += 1
+            two_blocks = re.search(r"Lb[01]ELi2E", name) is not None
+            assert scratch <= (68 if two_blocks else 0), (name, scratch)
+            assert vgpr > 256  # one wave per SIMD
+        elif "k_rbf_mfma_grad_h" in name:
+            hot += 1
+            big_tile = re.search(r"k_rbf_mfma_grad_hILi\d+ELi4E", name) is not None
+            assert scratch <= (128 if big_tile else 0), (name, scratch)
+            assert vgpr <= 256  # two waves per SIMD
+        else:
+            assert scratch == 0 and spill == 0, (name, spill, scratch)
+    assert hot >= 12, hot
