@@ -1419,9 +1419,11 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
     if constexpr (REGEPI) {
       // Everything below that depends only on the workgroup's rows is invariant over the tile loop; hoisted out of it, it
       // would sit in registers through the K-loop, which has none to spare (measured: 380 B of spills, one reload per stage,
-      // +14 % run time).  `z` is a zero the compiler cannot see through, renewed per tile.
-      int z;
-      asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+      // +14 % run time; adding an opaque zero does not help -- the compiler hoists the rest of the sum).  The row index itself goes
+      // through opaque per-tile copies of the two lane coordinates: nothing that depends on them can leave the tile loop, and
+      // only the coordinates themselves (which the K-loop needs anyway) stay live across it.
+      int l15_t = l15, lq4_t = 4 * lq;
+      asm volatile("" : "+v"(l15_t), "+v"(lq4_t));
       // ---- register epilogue (one lengthscale): the kernel entries are formed IN THE ACCUMULATOR LAYOUT -- the distance block
       //      D = A' B'^T with A' = [-2 x_i, |x_i|^2, 1], B' = [x_j, 1, |x_j|^2] on the fp32 MFMA (v_mfma_f32_16x16x4_f32: lane =
       //      column j, register r <-> row 4 (lane >> 4) + r, exactly like acc) -- so S o dK is 4 elementwise products per block:
@@ -1455,10 +1457,10 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
         constexpr bool DIAG = decltype(diag_c)::value;
         int dj[NB16];  // column of block b's lane, relative to the first row of the workgroup's tile
 #pragma unroll
-        for (int b = 0; b < NB16; ++b) dj[b] = (int)(j0 + wn * (NBW * 32) + b * 16 + l15 - (row0 + i0));
+        for (int b = 0; b < NB16; ++b) dj[b] = (int)(j0 - (row0 + i0)) + wn * (NBW * 32) + b * 16 + l15_t;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-          const int il = wm * 64 + a * 16 + l15 + z;
+          const int il = wm * 64 + a * 16 + l15_t;
           float ai[KQ];
 #pragma unroll
           for (int sI = 0; sI < KQ; ++sI) {
@@ -1467,8 +1469,9 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
             ai[sI] = kNegHalfLog2e * v;
           }
           uint32_t sgm[4];  // sigma of the row of register r as a sign-bit mask
+          const int row_r0 = (int)i0 + wm * 64 + a * 16 + lq4_t;  // (local rows: < 2^31)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sgm[r] = grad_col_sign(i0 + z + wm * 64 + a * 16 + 4 * lq + r, salt_l) ? 0x80000000u : 0u;
+          for (int r = 0; r < 4; ++r) sgm[r] = grad_col_sign(row_r0 + r, salt_l) ? 0x80000000u : 0u;
 #pragma unroll
           for (int b = 0; b < NB16; ++b) {
             floatx4 D = {0.f, 0.f, 0.f, 0.f};
@@ -1485,7 +1488,7 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
               // sigma_i tau_j S_ij -> S_ij: flip the sign bit
               const float s_ij = __uint_as_float(__float_as_uint(acc[a][b][r]) ^ sgm[r] ^ taub[b]);
               if constexpr (DIAG) {
-                const bool on = dj[b] == wm * 64 + a * 16 + 4 * lq + r;
+                const bool on = dj[b] == wm * 64 + a * 16 + lq4_t + r;
                 t = on ? 0.f : t;
                 gn += on ? s_ij : 0.f;
               }
@@ -1529,7 +1532,11 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
         sm.sgj[tid] = grad_col_sign(jp + tid, salt_r) ? -1.f : 1.f;
       }
       __syncthreads();
-      const int il = tid & (kHM - 1), jh = (tid >> 8) * 64;
+      // (an opaque copy of the thread index per pass: the row quantities below are invariant over the tile loop, and hoisted out of
+      //  it they spill around the K-loop, which has no register to spare)
+      int tid_t = tid;
+      asm volatile("" : "+v"(tid_t));
+      const int il = tid_t & (kHM - 1), jh = (tid_t >> 8) * 64;
       const int64_t i = row0 + i0 + il;  // the point; L / the packs are indexed by the local row i0 + il
       const float sgi = grad_col_sign(i0 + il, salt_l) ? -1.f : 1.f;  // sigma_i: the accumulators hold sigma_i tau_j S_ij
       float xiv[DPAD];

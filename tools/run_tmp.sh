@@ -1,5 +1,3 @@
 set -o pipefail
-timeout -k 10 240 python -m pytest tests/test_gpu_sharded.py -x -v -m gpu -k "eight_logical" > gpurun_out/t_b.log 2>&1; rc=$?; echo "pytest rc=$rc"
-tail -8 gpurun_out/t_b.log
-[ $rc -eq 0 ] || exit 1
-timeout -k 10 300 python tools/rehearse_eight_ranks.py > gpurun_out/r04/rehearse8.json 2> gpurun_out/r04/rehearse8.err; echo "rehearse rc=$?"; tail -3 gpurun_out/r04/rehearse8.err; cat gpurun_out/r04/rehearse8.json
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "rbf or slq" > gpurun_out/t_c.log 2>&1; echo "pytest rc=$?"; tail -2 gpurun_out/t_c.log
+for i in 1 2 3; do timeout -k 10 120 python tools/bench_grad.py 131072 2560 3 2>&1 | tail -1; done
