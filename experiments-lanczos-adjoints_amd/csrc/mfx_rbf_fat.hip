@@ -10,6 +10,7 @@
 //   * no instruction follows its producer within one gap (exp -> cvt hi -> fma_mix -> cvt lo, one gap apart each),
 // against 532 for the "pair by pair" order of the h3 kernel.  That placement is the table kSplit below.
 //
+// Shapes: RBF, d <= 12 (two distance MFMAs per block for d <= 8, three for d = 9 .. 12: BASELINE config 2 has d = 9), any number of vectors.
 // Geometry: 256-thread workgroups = 4 waves x 128 rows (four 32-row blocks mi) x 64 probes; 512 registers per lane: 128
 // accumulators + 128 chain masters (kChainTiles) live in the accumulation registers, the rest in VGPRs.  A 64-column tile is
 // 8 blocks (jb, mi); per block 12 contraction MFMAs, 2 distance MFMAs (for the block after next) and 48 VALU instructions.
@@ -40,28 +41,52 @@ namespace mfx {
 struct FatSplit {
   int e[16], h[8], m[16];
 };
-template <int NB>
+// The chain tables by chunk width; the slot ORDER by chunk width and by the number NKD of distance MFMAs of a block
+// (NKD = 2: d <= 8; NKD = 3: d = 9 .. 12 -- BASELINE config 2 has d = 9).  With a third distance MFMA a block has one more slot and the
+// tables stay as they are: an entry >= kSlots still means "in the next block", one slot later than before -- every consumer
+// (the contraction MFMAs of k-step 1) still comes later.
+constexpr FatSplit kFatSplit2 = {{0, 1, 2, 3, 4, 5, 5, 6, 7, 8, 9, 10, 10, 11, 12, 13},
+                                 {2, 4, 6, 7, 9, 11, 12, 14},
+                                 {3, 4, 5, 6, 7, 8, 8, 9, 10, 11, 12, 13, 13, 14, 15, 16}};
+constexpr FatSplit kFatSplit1 = {{0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7},
+                                 {1, 2, 3, 4, 5, 6, 7, 8},
+                                 {2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10}};
+template <int NB, int NKD>
 struct FatPlan;
 template <>
-struct FatPlan<2> {
+struct FatPlan<2, 2> {
   static constexpr int kSlots = 14;
-  static constexpr FatSplit kSplit = {{0, 1, 2, 3, 4, 5, 5, 6, 7, 8, 9, 10, 10, 11, 12, 13},
-                                      {2, 4, 6, 7, 9, 11, 12, 14},
-                                      {3, 4, 5, 6, 7, 8, 8, 9, 10, 11, 12, 13, 13, 14, 15, 16}};
+  static constexpr FatSplit kSplit = kFatSplit2;
   // slot -> distance step q (or -1), slot -> contraction MFMA m (or -1), contraction MFMA -> slot
   static constexpr int dist_q(int slot) { return slot == 10 ? 0 : (slot == 12 ? 1 : -1); }
   static constexpr int contr_m(int slot) { return slot < 10 ? slot : (slot == 11 ? 10 : (slot == 13 ? 11 : -1)); }
   static constexpr int slot_of(int m) { return m < 10 ? m : (m == 10 ? 11 : 13); }
 };
 template <>
-struct FatPlan<1> {
+struct FatPlan<1, 2> {
   static constexpr int kSlots = 8;
-  static constexpr FatSplit kSplit = {{0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7},
-                                      {1, 2, 3, 4, 5, 6, 7, 8},
-                                      {2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10}};
+  static constexpr FatSplit kSplit = kFatSplit1;
   static constexpr int dist_q(int slot) { return slot == 3 ? 0 : (slot == 5 ? 1 : -1); }
   static constexpr int contr_m(int slot) { return slot < 3 ? slot : (slot == 4 ? 3 : (slot >= 6 ? slot - 2 : -1)); }
   static constexpr int slot_of(int m) { return m < 3 ? m : (m == 3 ? 4 : m + 2); }
+};
+// NKD = 3, 64 vectors: 15 slots -- c0-c8, d0, c9, d1, c10, d2, c11 (the last distance MFMA again two MFMAs before the first v_exp on its block)
+template <>
+struct FatPlan<2, 3> {
+  static constexpr int kSlots = 15;
+  static constexpr FatSplit kSplit = kFatSplit2;
+  static constexpr int dist_q(int slot) { return slot == 9 ? 0 : (slot == 11 ? 1 : (slot == 13 ? 2 : -1)); }
+  static constexpr int contr_m(int slot) { return slot < 9 ? slot : (slot == 10 ? 9 : (slot == 12 ? 10 : (slot == 14 ? 11 : -1))); }
+  static constexpr int slot_of(int m) { return m < 9 ? m : (m == 9 ? 10 : (m == 10 ? 12 : 14)); }
+};
+// NKD = 3, <= 32 vectors: 9 slots -- c0 c1 d0 c2 d1 c3 d2 c4 c5
+template <>
+struct FatPlan<1, 3> {
+  static constexpr int kSlots = 9;
+  static constexpr FatSplit kSplit = kFatSplit1;
+  static constexpr int dist_q(int slot) { return slot == 2 ? 0 : (slot == 4 ? 1 : (slot == 6 ? 2 : -1)); }
+  static constexpr int contr_m(int slot) { return slot < 2 ? slot : (slot == 3 ? 2 : (slot == 5 ? 3 : (slot >= 7 ? slot - 3 : -1))); }
+  static constexpr int slot_of(int m) { return m < 2 ? m : (m == 2 ? 3 : (m == 3 ? 5 : m + 3)); }
 };
 
 template <int DPAD, int NB>
@@ -87,9 +112,10 @@ __global__ __launch_bounds__(256, 1) void k_rbf_fat_apply(const float* __restric
                                                           int64_t ldpart, int64_t row0, int64_t rend) {
   if (rangeflag && *rangeflag != 0) return;  // f16 range guard: the fp32-distance launch queued behind this one does the work
   using S = FatSmem<DPAD, NB>;
-  using Plan = FatPlan<NB>;
-  constexpr int KD = S::KD, NKD = S::NKD, AROW = S::AROW, kSlots = Plan::kSlots;
-  static_assert(NKD == 2, "two distance MFMAs per block (d <= 8)");
+  constexpr int KD = S::KD, NKD = S::NKD, AROW = S::AROW;
+  static_assert(NKD == 2 || NKD == 3, "two or three distance MFMAs per block (d <= 12)");
+  using Plan = FatPlan<NB, NKD>;
+  constexpr int kSlots = Plan::kSlots;
   extern __shared__ __attribute__((aligned(16))) char fat_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -393,8 +419,10 @@ int rbf_fat_launch(int dpad, int nb, bool vec4, dim3 grid, hipStream_t stream, c
   if (dpad == 4 && nb == 2) return fat_launch_dn<4, 2>(MFX_FAT_ARGS);
   if (dpad == 8 && nb == 1) return fat_launch_dn<8, 1>(MFX_FAT_ARGS);
   if (dpad == 8 && nb == 2) return fat_launch_dn<8, 2>(MFX_FAT_ARGS);
+  if (dpad == 12 && nb == 1) return fat_launch_dn<12, 1>(MFX_FAT_ARGS);
+  if (dpad == 12 && nb == 2) return fat_launch_dn<12, 2>(MFX_FAT_ARGS);
 #undef MFX_FAT_ARGS
-  set_error("fat-wave Gram matvec supports d <= 8 and chunks of 32 or 64 vectors");
+  set_error("fat-wave Gram matvec supports d <= 12 and chunks of 32 or 64 vectors");
   return MFX_ERR_UNSUPPORTED;
 }
 
