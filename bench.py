@@ -359,7 +359,7 @@ def main(argv=None):
             "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32" if not split else "f32 (Gram contraction emulated with 3 f16 MFMA products, fp32 accumulate; accuracy vs "
-                                             "fp64 at this size: profiles/r03a_accuracy)",
+                                             "fp64 at this size: profiles/r04a_grad_gemm_16x16x32/accuracy_*.log)",
             "data": "synthetic",
             "config": {
                 "workload": f"matrix-free RBF GP kernel N={n} d={d}, SLQ log-det value+grad, {k} Lanczos steps (full reortho) x "
