@@ -5,8 +5,8 @@ set -e
 cd "$(dirname "$0")/../experiments-lanczos-adjoints_amd/csrc"
 NAME=$1; SRC=$2; FLAGS=$3
 mkdir -p ../../tools/ab
-OBJ=/tmp/mfx_${NAME}_${SRC%.hip}.o
+OBJ=${TMPDIR:-/tmp}/mfx_${NAME}_${SRC%.hip}.o
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -Wall -Wno-unused-function $FLAGS -c $SRC -o $OBJ
 OTHERS=$(ls *.o | grep -v "^${SRC%.hip}.o$")
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OTHERS $OBJ -o ../../tools/ab/libmfx_${NAME}.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OTHERS $OBJ -ldl -o ../../tools/ab/libmfx_${NAME}.so
 echo built tools/ab/libmfx_${NAME}.so

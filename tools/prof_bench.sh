@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 kernel-trace summary of the default bench command (copied into profiles/ by hand afterwards)
 set -e
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/prof_bench
 rm -rf $OUT && mkdir -p $OUT

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 kernel stats of the C2-shaped run of tools/bench_configs.py (n = 45730, d = 9 ARD, k = 30, 8 probes)
 set -e
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/prof_c2
 rm -rf $OUT && mkdir -p $OUT

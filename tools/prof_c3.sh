@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 kernel stats of BASELINE config 3 (CSR n = 102400, k = 50, fp64, one vector): kernel durations vs wall time
 set -e
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/prof_c3${1:+_$1}
 rm -rf $OUT && mkdir -p $OUT

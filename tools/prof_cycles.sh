@@ -1,8 +1,8 @@
 #!/bin/bash
 # one PMC pass over the Gram matvec (C4 shape, 64 vectors): shader cycles, clock and matrix-pipe share of the kernel whose name
 # contains $1 (default pc_apply).  MFX_* environment selects the kernel / the build, P the number of vectors (default 64).   usage: [P=32] tools/prof_cycles.sh [filter] [tag]
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 FILTER=${1:-pc_apply}
 OUT=/tmp/prof_cycles_$$
 rm -rf $OUT && mkdir -p $OUT

@@ -1,8 +1,8 @@
 #!/bin/bash
 # PMC passes over the gradient GEMM alone (separate runs per counter group)
 set -e
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_grad
 rm -rf $OUT && mkdir -p $OUT
 python3 $R/tools/bench_grad.py 131072 2560 3

@@ -1,8 +1,8 @@
 #!/bin/bash
 # PMC passes over the pipelined Gram matvec alone (C4 shape, 64 probes)
 set -e
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_matvec
 rm -rf $OUT && mkdir -p $OUT
 python3 $R/tools/bench_matvec_one.py 64 10

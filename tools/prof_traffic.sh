@@ -2,7 +2,7 @@
 # HBM-side bytes per launch of the dominant kernels: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes over
 # `bench.py --steps 1 --warmup 0 --k 3`; writes gpurun_out/traffic.json (copy to profiles/traffic.json, which bench.py reads)
 set -e
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/prof_traffic
 rm -rf $OUT && mkdir -p $OUT

@@ -1,7 +1,7 @@
 #!/bin/bash
 set -e
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_train
 rm -rf $OUT && mkdir -p $OUT
 cd $R
