@@ -1204,16 +1204,100 @@ __host__ __device__ __forceinline__ bool grad_col_sign(int64_t i, uint32_t salt)
 }
 constexpr uint32_t kSaltL = 0x51ED270Bu, kSaltR = 0xB5297A4Du;
 
-// hi/lo packs: out[(kb * npad + i) * 8 + q] = piece of (+-) scale * x[8 kb + q][i], sign per column i = grad_col_sign(i, salt)
-// inner > 1: the source rows come as (batch / inner) groups of `inner` rows -- (probe, Krylov step) -- and are packed
-// TRANSPOSED, (step, probe): the 16 rows that meet in one MFMA then belong to the same step of different probes and have
-// similar magnitudes.  Why it matters: the f16 MFMA aligns the 16 products of an output element to the largest of them and
-// truncates the others TOWARDS ZERO (tools/mfma_f16_trunc.hip), and the adjoint states of different steps differ by orders of
-// magnitude -- with (probe, step) order every small product lost bits, always in the direction that shrinks its contribution,
-// a sign-symmetric bias that no sign alternation can cancel (1.6e-4 / 4.3e-4 gradient error at n = 65536).
+// ONE product instead of three for the rows that cannot matter, and the rows ORDERED BY SIZE.
+// S = sum_b L_b^T R_b does not care in which order the batch rows are summed, and the adjoint states of the last Krylov steps are
+// orders of magnitude smaller than those of the first (config 4: row maxima 8.8e3 at step 0, ~2e2 at steps 1-13, < 8 from step 30 on,
+// 2e-3 at step 39; the basis rows are unit vectors).  The pre-pass therefore sorts the rows by the bound m_b = |L_b|max |R_b|max,
+// largest first (a bitonic sort of <= 8192 keys in LDS, ties by the (step, probe) index: deterministic), and packs them in that order:
+//   * the 32 rows that meet in one K = 32 MFMA step have similar magnitudes (what the (step, probe) order of round 2 was for: the
+//     f16 MFMA aligns its products to the largest of them and truncates the rest);
+//   * the cross products hi lo + lo hi of a row are 2^-11 of its hi hi product.  The TAIL of the sorted order -- the longest run of
+//     the smallest rows whose bounds add up to at most 2^-MFX_GRAD_ONE_PRODUCT_LOG2 (default 2^-10) of the sum of ALL bounds -- is
+//     multiplied hi hi only: what that drops from any S_ij is at most 2^-(11 + 10) = 2^-21 of sum_b m_b even if it all had one sign,
+//     the size of what the three-product sum itself drops (lo lo, the MFMA's truncation).  Those stages (from stage n3 on) stage and
+//     multiply their hi images only: a third of the MFMAs, half of the L2 -> LDS bytes.  (A per-row cut relative to the largest row
+//     would let MANY small rows through that together carry the gradient; measured at config 4: per-row cut 2^-6 -> 4e-4 off.)
+// Decided on the device per launch; no row qualifies when the rows are of similar size, and then nothing changes but the order.
+#ifndef MFX_GRAD_ONE_PRODUCT_LOG2
+#define MFX_GRAD_ONE_PRODUCT_LOG2 10
+#endif
+constexpr int kSortMax = 8192;  // rows the LDS sort takes (64 KB of 64-bit keys); larger batches keep the (step, probe) order, three products
+// perm[bt] = source row of packed row bt (-1: a zero row of the padding); tail[0] = n3, the first one-product stage
+__global__ __launch_bounds__(1024) void k_order_rows(const float* __restrict__ amaxL, const float* __restrict__ amaxR, int64_t batch,
+                                                     int64_t inner, int64_t bpad, int npow2, int* __restrict__ perm,
+                                                     int* __restrict__ tail) {
+  extern __shared__ unsigned long long keys[];  // (bound bits << 32) | (0xFFFFFFFF - default position): sorted DESCENDING
+  const int64_t outer = batch / inner;
+  for (int i = threadIdx.x; i < npow2; i += 1024) {
+    unsigned long long kv = 0;  // padding: after every real row
+    if (i < batch) {
+      const int64_t src = inner > 1 ? ((int64_t)i % outer) * inner + (int64_t)i / outer : i;  // default order: (step, probe)
+      float m = amaxL[src] * amaxR[src];
+      if (!(m >= 0.f) || m > 3.0e38f) m = 3.0e38f;  // NaN / inf rows first: never in the one-product tail
+      kv = ((unsigned long long)__float_as_uint(m) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+    }
+    keys[i] = kv;
+  }
+  __syncthreads();
+  for (int size = 2; size <= npow2; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < npow2 / 2; t += 1024) {
+        const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+        const bool desc = (lo & size) == 0;
+        const unsigned long long a = keys[lo], b = keys[hi];
+        if (desc ? a < b : a > b) {
+          keys[lo] = b;
+          keys[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  for (int64_t bt = threadIdx.x; bt < bpad; bt += 1024) {
+    int src = -1;
+    if (bt < batch) {
+      const int64_t i = 0xFFFFFFFFu - (unsigned)(keys[bt] & 0xFFFFFFFFull);
+      src = (int)(inner > 1 ? (i % outer) * inner + i / outer : i);
+    }
+    perm[bt] = src;
+  }
+  if (threadIdx.x == 0) {
+    // the one-product tail: the longest run of the SMALLEST rows whose bounds add up to at most 2^-LOG2 of the sum of all bounds
+    // (a row with a NaN / inf bound makes the sum infinite: no tail)
+    const int nstage = (int)(bpad / 32);
+    int n3 = nstage;
+    if (MFX_GRAD_ONE_PRODUCT_LOG2 > 0) {
+      double total = 0.0;
+      for (int64_t bt = 0; bt < batch; ++bt) total += (double)__uint_as_float((unsigned)(keys[bt] >> 32));
+      const double cut = total < 1.0e38 ? ldexp(total, -MFX_GRAD_ONE_PRODUCT_LOG2) : -1.0;
+      double mass = 0.0;
+      int64_t first = batch;  // first row of the tail
+      while (first > 0) {
+        const double m = (double)__uint_as_float((unsigned)(keys[first - 1] >> 32));
+        if (mass + m > cut) break;
+        mass += m;
+        --first;
+      }
+      n3 = (int)((first + 31) / 32);  // whole stages only
+    }
+    tail[0] = n3;
+  }
+}
+__global__ void k_order_default(int64_t batch, int64_t inner, int64_t bpad, int* __restrict__ perm, int* __restrict__ tail) {
+  const int64_t bt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t outer = batch / inner;
+  if (bt < bpad) perm[bt] = bt < batch ? (int)(inner > 1 ? (bt % outer) * inner + bt / outer : bt) : -1;
+  if (bt == 0) tail[0] = (int)(bpad / 32);
+}
+
+// hi/lo packs: out[(kb * npad + i) * 8 + q] = piece of (+-) scale * x[perm[8 kb + q]][i], sign per column i = grad_col_sign(i, salt).
+// The packed row order is k_order_rows' (by decreasing size).  Why the order matters beyond the one-product tail: the f16 MFMA aligns
+// the products of an output element to the largest of them and truncates the others TOWARDS ZERO (tools/mfma_f16_trunc.hip), and the
+// adjoint states of different Krylov steps differ by orders of magnitude -- with the caller's (probe, step) order every small product
+// lost bits, always in the direction that shrinks its contribution, a sign-symmetric bias that no sign alternation can cancel
+// (1.6e-4 / 4.3e-4 gradient error at n = 65536; round 2 packed (step, probe) for that reason, round 4 sorts outright).
 __global__ __launch_bounds__(256) void k_pack_f16(const float* __restrict__ x, int64_t ldx, int64_t batch, int64_t n,
-                                                  int64_t npad, const float* __restrict__ scale, uint32_t salt, int64_t inner,
-                                                  _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
+                                                  int64_t npad, const float* __restrict__ scale, uint32_t salt,
+                                                  const int* __restrict__ perm, _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t kb = blockIdx.y;
   if (i >= npad) return;
@@ -1222,10 +1306,8 @@ __global__ __launch_bounds__(256) void k_pack_f16(const float* __restrict__ x, i
   half8 h, l;
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
-    const int64_t bt = kb * 8 + q;
-    const int64_t outer = batch / inner;
-    const int64_t src = inner > 1 ? (bt % outer) * inner + bt / outer : bt;
-    const float v = (bt < batch && i < n) ? x[src * ldx + i] * s : 0.f;
+    const int64_t src = perm[kb * 8 + q];  // k_order_rows: rows by decreasing size; -1 = a zero row of the padding
+    const float v = (src >= 0 && i < n) ? x[src * ldx + i] * s : 0.f;
     float fh, fl;
     split_hi_lo(v, fh, fl);
     h[q] = (_Float16)fh;
@@ -1288,7 +1370,7 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
                                                             const _Float16* __restrict__ Rh, const _Float16* __restrict__ Rl,
                                                             int64_t nkb /* batch_pad / 8 */, int tiles_per_block,
                                                             uint32_t salt_l, uint32_t salt_r, double* __restrict__ partial,
-                                                            int64_t row0, int64_t nrow) {
+                                                            int64_t row0, int64_t nrow, const int* __restrict__ one_product) {
   // rows: the nrow points row0 .. of X that the L operand covers (a row shard, or all n); columns: all n points
   using Smem = GradSmemH<DPAD, NBW, REGEPI>;
   constexpr int TN = Smem::TN;
@@ -1336,18 +1418,22 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
   const char* Llb = reinterpret_cast<const char*>(Ll);
   const char* Rhb = reinterpret_cast<const char*>(Rh);
   const char* Rlb = reinterpret_cast<const char*>(Rl);
-  auto issue_stage = [&](uint32_t l_off, uint32_t r_off, int slot) {
+  auto issue_stage = [&](uint32_t l_off, uint32_t r_off, int slot, int hi_only) {  // hi_only: a one-product stage (k_stage_flags)
     glds16(Lhb + l_off, &sm.u.st.a_hi[slot][lkb][lcol][0]);
-    glds16(Llb + l_off, &sm.u.st.a_lo[slot][lkb][lcol][0]);
     glds16(Lhb + l_off + kb2_l, &sm.u.st.a_hi[slot][lkb + 2][lcol][0]);
-    glds16(Llb + l_off + kb2_l, &sm.u.st.a_lo[slot][lkb + 2][lcol][0]);
     glds16(Rhb + r_off, &sm.u.st.b_hi[slot][rkb][rcol][0]);
-    glds16(Rlb + r_off, &sm.u.st.b_lo[slot][rkb][rcol][0]);
-    if constexpr (TN == 256) {
-      glds16(Rhb + r_off + kb2_r, &sm.u.st.b_hi[slot][rkb + 2][rcol][0]);
-      glds16(Rlb + r_off + kb2_r, &sm.u.st.b_lo[slot][rkb + 2][rcol][0]);
+    if constexpr (TN == 256) glds16(Rhb + r_off + kb2_r, &sm.u.st.b_hi[slot][rkb + 2][rcol][0]);
+    if (!hi_only) {
+      glds16(Llb + l_off, &sm.u.st.a_lo[slot][lkb][lcol][0]);
+      glds16(Llb + l_off + kb2_l, &sm.u.st.a_lo[slot][lkb + 2][lcol][0]);
+      glds16(Rlb + r_off, &sm.u.st.b_lo[slot][rkb][rcol][0]);
+      if constexpr (TN == 256) glds16(Rlb + r_off + kb2_r, &sm.u.st.b_lo[slot][rkb + 2][rcol][0]);
     }
   };
+  // stages from n3 on are one-product stages (a scalar of the pre-pass, k_order_rows; the same for every workgroup)
+  int n3 = one_product[0];
+  n3 = n3 < 0 ? 0 : (n3 > nstage ? nstage : n3);
+  const int one_first = n3 == 0 ? 1 : 0;
 
   for (int64_t tj = tj_begin; tj < tj_end; ++tj) {
     const int64_t j0 = tj * TN;
@@ -1365,7 +1451,7 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
     asm volatile("" : "+v"(ol));
     if (!REGEPI || tj == tj_begin) {
       __syncthreads();  // previous tile's epilogue reads of the overlaid S^T tile are done
-      issue_stage(ol, orr, 0);
+      issue_stage(ol, orr, 0, one_first);
     }  // (REGEPI: stage 0 of this tile was requested before the previous tile's epilogue)
     ol += stage_bytes_l;
     orr += stage_bytes_r;
@@ -1383,38 +1469,47 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
     //     flight) before it ARRIVES there -- A before its B1(st + 1), B before its B2(st);  stage 0 before the first barrier.
     __builtin_amdgcn_s_waitcnt(0x0F70);
     if (wid >= 4) __builtin_amdgcn_s_barrier();  // the half-stage offset of the upper half
-    for (int st = 0; st < nstage; ++st) {
-      const int slot = st & 1;
-      if (wid < 4) __builtin_amdgcn_s_waitcnt(0x0F70);  // (A) my pieces of this stage, requested a stage ago
-      __builtin_amdgcn_s_barrier();  // B1
-      if (st + 1 < nstage) issue_stage(ol, orr, slot ^ 1);
-      ol += stage_bytes_l;
-      orr += stage_bytes_r;
-      half8 ah[4], al[4], bh[NB16], bl[NB16];
+    // stages [0, n3): three products; stages [n3, nstage): hi hi only (k_stage_flags).  TWO loops, each with its own straight-line
+    // body: with the choice as a branch inside one loop the allocator spilled 140-190 registers around the joins
+    auto run_stages = [&](auto one_c, int st_begin, int st_end) {
+      constexpr bool ONE = decltype(one_c)::value;
+      for (int st = st_begin; st < st_end; ++st) {
+        const int slot = st & 1;
+        if (wid < 4) __builtin_amdgcn_s_waitcnt(0x0F70);  // (A) my pieces of this stage, requested a stage ago
+        __builtin_amdgcn_s_barrier();  // B1
+        if (st + 1 < nstage) issue_stage(ol, orr, slot ^ 1, ONE ? 1 : (st + 1 >= n3 ? 1 : 0));
+        ol += stage_bytes_l;
+        orr += stage_bytes_r;
+        half8 ah[4], al[ONE ? 1 : 4], bh[NB16], bl[ONE ? 1 : NB16];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        ah[a] = *reinterpret_cast<const half8*>(&sm.u.st.a_hi[slot][lq][wm * 64 + a * 16 + l15][0]);
-        al[a] = *reinterpret_cast<const half8*>(&sm.u.st.a_lo[slot][lq][wm * 64 + a * 16 + l15][0]);
-      }
-#pragma unroll
-      for (int b = 0; b < NB16; ++b) {
-        bh[b] = *reinterpret_cast<const half8*>(&sm.u.st.b_hi[slot][lq][wn * (NBW * 32) + b * 16 + l15][0]);
-        bl[b] = *reinterpret_cast<const half8*>(&sm.u.st.b_lo[slot][lq][wn * (NBW * 32) + b * 16 + l15][0]);
-      }
-      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the fragments are in registers
-      if (wid >= 4) __builtin_amdgcn_s_waitcnt(0x0F70);  // (B) my pieces of stage st + 1
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();  // B2  (no s_setprio around the MFMA cluster: measured 0.5 % faster without, tools/gradk_bench.hip)
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a) {
+          ah[a] = *reinterpret_cast<const half8*>(&sm.u.st.a_hi[slot][lq][wm * 64 + a * 16 + l15][0]);
+          if constexpr (!ONE) al[a] = *reinterpret_cast<const half8*>(&sm.u.st.a_lo[slot][lq][wm * 64 + a * 16 + l15][0]);
+        }
 #pragma unroll
         for (int b = 0; b < NB16; ++b) {
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
+          bh[b] = *reinterpret_cast<const half8*>(&sm.u.st.b_hi[slot][lq][wn * (NBW * 32) + b * 16 + l15][0]);
+          if constexpr (!ONE) bl[b] = *reinterpret_cast<const half8*>(&sm.u.st.b_lo[slot][lq][wn * (NBW * 32) + b * 16 + l15][0]);
         }
-      __builtin_amdgcn_sched_barrier(0);
-    }
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the fragments are in registers
+        if (wid >= 4) __builtin_amdgcn_s_waitcnt(0x0F70);  // (B) my pieces of stage st + 1
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();  // B2  (no s_setprio around the MFMA cluster: measured 0.5 % faster without, tools/gradk_bench.hip)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < NB16; ++b) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+            if constexpr (!ONE) {
+              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
+            }
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    run_stages(std::false_type{}, 0, n3);
+    run_stages(std::true_type{}, n3, nstage);
     if (wid < 4) __builtin_amdgcn_s_barrier();  // the lower half catches up: both halves have taken 2 nstage + 1 barriers
     if constexpr (REGEPI) {
       // Everything below that depends only on the workgroup's rows is invariant over the tile loop; hoisted out of it, it
@@ -1444,7 +1539,7 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
       }
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): my bq writes have landed (the DMA counter is left alone)
       __builtin_amdgcn_s_barrier();        // every wave is done reading the last stage of this tile, and bq is complete
-      if (tj + 1 < tj_end) issue_stage(ol - (uint32_t)(nstage + 1) * stage_bytes_l, offR0 + (uint32_t)((j0 + TN) * 16), 0);
+      if (tj + 1 < tj_end) issue_stage(ol - (uint32_t)(nstage + 1) * stage_bytes_l, offR0 + (uint32_t)((j0 + TN) * 16), 0, one_first);
       const bool diag_tile = (row0 + i0 < j0 + TN) && (j0 < row0 + i0 + kHM);
       float gl = 0.f, gs = 0.f, gn = 0.f;
       // one straight-line copy of the body per (tile meets the diagonal or not): with the diagonal test as a run-time branch inside
@@ -1609,13 +1704,14 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
 
 int64_t rbf_grad_h_ws_bytes(int64_t n, int64_t batch) {
   const int64_t npad = (n + kHM - 1) / kHM * kHM, bpad = (batch + 31) / 32 * 32;
-  return 4 * bpad * npad * (int64_t)sizeof(_Float16) + 2 * bpad * (int64_t)sizeof(float) + 1024;
+  return 4 * bpad * npad * (int64_t)sizeof(_Float16) + 3 * bpad * (int64_t)sizeof(float) + 1536;
 }
 
 template <int DPAD, int NBW>
 static int launch_grad_h_t(const mfx_operator* op, const float* xs, const float* sq, int64_t n, int64_t npad_l, int64_t npad,
                            const _Float16* Lh, const _Float16* Ll, const _Float16* Rh, const _Float16* Rl, int64_t bpad,
-                           uint32_t salt_l, uint32_t salt_r, double* partial, int64_t* nblocks_out, hipStream_t stream) {
+                           uint32_t salt_l, uint32_t salt_r, double* partial, int64_t* nblocks_out, const int* one_product,
+                           hipStream_t stream) {
   constexpr int TN = GradSmemH<DPAD, NBW>::TN;
   const int64_t row0 = op_row0(op), nrow = op_nrows(op);
   const int64_t nti = (nrow + kHM - 1) / kHM, ntj = (n + TN - 1) / TN;
@@ -1629,7 +1725,7 @@ static int launch_grad_h_t(const mfx_operator* op, const float* xs, const float*
       MFX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rbf_mfma_grad_h<DPAD, NBW, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
       k_rbf_mfma_grad_h<DPAD, NBW, true><<<grid, 512, sh, stream>>>(xs, sq, n, npad_l, npad, op->ard, op->kernel_fn, Lh, Ll, Rh, Rl,
-                                                                    bpad / 8, tiles_per_block, salt_l, salt_r, partial, row0, nrow);
+                                                                    bpad / 8, tiles_per_block, salt_l, salt_r, partial, row0, nrow, one_product);
       launched = true;
     }
   }
@@ -1638,7 +1734,7 @@ static int launch_grad_h_t(const mfx_operator* op, const float* xs, const float*
     MFX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rbf_mfma_grad_h<DPAD, NBW, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     k_rbf_mfma_grad_h<DPAD, NBW, false><<<grid, 512, sh, stream>>>(xs, sq, n, npad_l, npad, op->ard, op->kernel_fn, Lh, Ll, Rh, Rl,
-                                                                   bpad / 8, tiles_per_block, salt_l, salt_r, partial, row0, nrow);
+                                                                   bpad / 8, tiles_per_block, salt_l, salt_r, partial, row0, nrow, one_product);
   }
   MFX_CHECK_LAUNCH();
   *nblocks_out = nti * kGSub * kGSplit;
@@ -1656,7 +1752,9 @@ static int launch_grad_h(const mfx_operator* op, const float* xs, const float* s
   float* amaxL = reinterpret_cast<float*>(base);
   float* amaxR = amaxL + bpad;
   float* scl = amaxR + bpad;  // [sL, 1/sL, sR, 1/sR]
-  _Float16* Lh = reinterpret_cast<_Float16*>(base + align_up(2 * bpad * 4 + 64, 256));
+  int* tail = reinterpret_cast<int*>(base + 2 * bpad * 4 + 64);  // n3: the first one-product stage (k_order_rows)
+  int* perm = tail + 16;                                          // packed row -> source row
+  _Float16* Lh = reinterpret_cast<_Float16*>(base + align_up(2 * bpad * 4 + 128 + bpad * 4, 256));
   _Float16* Ll = Lh + bpad * npad_l;
   _Float16* Rh = Ll + bpad * npad_l;
   _Float16* Rl = Rh + bpad * npad;
@@ -1664,17 +1762,26 @@ static int launch_grad_h(const mfx_operator* op, const float* xs, const float* s
   k_row_amax<<<(unsigned)batch, 256, 0, stream>>>(R, ldr, n, amaxR);
   k_global_scale<<<1, 256, 0, stream>>>(amaxL, batch, scl);
   k_global_scale<<<1, 256, 0, stream>>>(amaxR, batch, scl + 2);
+  if (bpad <= kSortMax) {
+    int npow2 = 64;
+    while (npow2 < bpad) npow2 <<= 1;
+    if (npow2 * 8 > 48 * 1024)
+      MFX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_order_rows), hipFuncAttributeMaxDynamicSharedMemorySize, kSortMax * 8));
+    k_order_rows<<<1, 1024, (size_t)npow2 * 8, stream>>>(amaxL, amaxR, batch, inner, bpad, npow2, perm, tail);
+  } else {
+    k_order_default<<<(unsigned)((bpad + 255) / 256), 256, 0, stream>>>(batch, inner, bpad, perm, tail);
+  }
   const dim3 pgrid((unsigned)((npad + 255) / 256), (unsigned)(bpad / 8));
   const dim3 pgrid_l((unsigned)((npad_l + 255) / 256), (unsigned)(bpad / 8));
   const uint32_t salt_l = kSaltL, salt_r = kSaltR;
-  k_pack_f16<<<pgrid_l, 256, 0, stream>>>(L, ldl, batch, nrow, npad_l, scl, salt_l, inner, Lh, Ll);
-  k_pack_f16<<<pgrid, 256, 0, stream>>>(R, ldr, batch, n, npad, scl + 2, salt_r, inner, Rh, Rl);
+  k_pack_f16<<<pgrid_l, 256, 0, stream>>>(L, ldl, batch, nrow, npad_l, scl, salt_l, perm, Lh, Ll);
+  k_pack_f16<<<pgrid, 256, 0, stream>>>(R, ldr, batch, n, npad, scl + 2, salt_r, perm, Rh, Rl);
   MFX_CHECK_LAUNCH();
   // 256 x 256 workgroup tile (NBW = 4) for d <= 8; d = 9..16 keeps the 256 x 128 tile (the epilogue registers on top of 128
   // accumulators spill there)
   if constexpr (DPAD <= 8)
-    return launch_grad_h_t<DPAD, 4>(op, xs, sq, n, npad_l, npad, Lh, Ll, Rh, Rl, bpad, salt_l, salt_r, partial, nblocks_out, stream);
-  return launch_grad_h_t<DPAD, 2>(op, xs, sq, n, npad_l, npad, Lh, Ll, Rh, Rl, bpad, salt_l, salt_r, partial, nblocks_out, stream);
+    return launch_grad_h_t<DPAD, 4>(op, xs, sq, n, npad_l, npad, Lh, Ll, Rh, Rl, bpad, salt_l, salt_r, partial, nblocks_out, tail, stream);
+  return launch_grad_h_t<DPAD, 2>(op, xs, sq, n, npad_l, npad, Lh, Ll, Rh, Rl, bpad, salt_l, salt_r, partial, nblocks_out, tail, stream);
 }
 
 // returns the device pointer holding [sL, 1/sL, sR, 1/sR] through scales_out

@@ -137,6 +137,36 @@ def test_rbf_op_apply_and_param_sweep(dtype, tol, precision, ard, n, d, p, kerne
         assert close(g.reshape(np.shape(rr)), rr, gtol, atol_rel=gtol * np.sqrt(n))
 
 
+@pytest.mark.parametrize("decay,batch", [(0.0, 96), (9.0, 96), (9.0, 200), (30.0, 77)])
+def test_split_param_sweep_with_rows_of_very_different_size(decay, batch):
+    """The split gradient GEMM packs the batch rows by decreasing size and multiplies the tail -- the smallest rows whose bounds add
+    up to <= 2^-10 of the sum of all bounds -- hi hi only (csrc/mfx_rbf_mfma.hip, k_order_rows).  Rows decaying over 9 and 30 orders of
+    magnitude (the adjoint states of a long Krylov recursion), in scrambled order, ragged batch sizes, against the fp64 oracle: the
+    parameter gradients must be as accurate as with rows of equal size (decay 0: no tail, only the ordering).  The sweep being summed:
+    arnoldi.py:207-209 over all (probe, step) pairs."""
+    n, d = 2304, 8
+    rng = np.random.default_rng(11)
+    X = rng.standard_normal((n, d))
+    raw = (np.array(0.7), np.array(0.4), np.array(-1.0))
+    scale = 10.0 ** (-decay * rng.permutation(batch) / batch)
+    L = rng.standard_normal((batch, n)) * scale[:, None]
+    R = rng.standard_normal((batch, n))
+    o = orc.RbfGramOp(X, noise_minval=1e-4)
+    ref = o.param_vjp(R, L, *raw)  # d/dtheta sum_b L_b^T A(theta) R_b
+
+    def sweep(precision):
+        op = RbfGramOp(T(X, torch.float32), noise_minval=1e-4, precision=precision)
+        params = [T(r, torch.float32, True) for r in raw]
+        y = op(T(R, torch.float32), *params)
+        return [float(g) for g in torch.autograd.grad(y, params, T(L, torch.float32))]
+
+    split, exact = sweep("f16x3"), sweep("f16x3-matvec")  # the latter: the exact-fp32 MFMA gradient GEMM, no ordering, no tail
+    for gs, ge, rr in zip(split, exact, ref):
+        rr = float(rr)
+        # as accurate as the exact-fp32 GEMM up to a small factor, with a floor at 2e-5 of the value (both sums cancel heavily)
+        assert abs(gs - rr) <= 3.0 * abs(ge - rr) + 2e-5 * abs(rr), (decay, batch, gs, ge, rr)
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-11), (torch.float32, 5e-5)])
 @pytest.mark.parametrize("kernel", ["rbf", "matern32"])
 @pytest.mark.parametrize("n,d,p", [(2100, 14, 2), (2050, 16, 33), (600, 20, 6), (4097, 3, 1), (2304, 12, 65)])

@@ -22,6 +22,9 @@ cparams = op.constrain(*params)
 desc = op.descriptor(cparams, torch.float32, n)
 L = torch.randn(batch, n, device=dev, generator=g)
 R = torch.randn(batch, n, device=dev, generator=g)
+DECAY = float(os.environ.get("DECAY", "0"))  # > 0: row b scaled by 10^(-DECAY b / batch): the decay of the adjoint states over the Krylov steps
+if DECAY > 0:      # (the public entry packs the rows in the order given, 32 consecutive rows = one stage)
+    L.mul_(torch.pow(10.0, -DECAY * torch.arange(batch, device=dev) / batch)[:, None])
 lib = _lib.get()
 ws = _lib.scratch(int(lib.mfx_workspace_bytes(C.byref(desc), n, batch - 1, 1)), dev)
 
