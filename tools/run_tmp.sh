@@ -1,2 +1,3 @@
 set -o pipefail
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "very_different_size" > gpurun_out/t_h.log 2>&1; echo "pytest rc=$?"; tail -12 gpurun_out/t_h.log
+mkdir -p gpurun_out/r04
+timeout -k 10 1100 python -m pytest tests -x -q -m gpu > gpurun_out/t_full2.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/t_full2.log
