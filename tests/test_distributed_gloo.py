@@ -147,6 +147,44 @@ def test_rows_x_probes_grid_2x2_equals_single_process(tmp_path):
     _run_grid(tmp_path, 4, 2)
 
 
+def test_eight_logical_ranks_in_one_process_equal_single_process():
+    """The 8-way row shard that `bench.py --gpus 8` runs, with the ranks as eight THREADS (`distributed.LocalWorld`: the rehearsal
+    transport of tests/test_gpu_sharded.py and tools/rehearse_eight_ranks.py -- a GPU box admits at most six processes on its card):
+    RowComm / reduce_estimate on a LocalWorld handle and the sharded restatement of the oracle reproduce the single-process oracle.
+    n = 8 x 64 - 30: seven full shards and a ragged last one."""
+    _setup_paths()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _sharded_oracle as so
+    from matfree_extensions.distributed import Layout, LocalWorld, RowComm, reduce_estimate
+    from oracle import slq_oracle as orc
+
+    n, d, k, p, world = 8 * 64 - 30, 3, 6, 3, 8
+    X = np.random.default_rng(0).standard_normal((n, d))
+    raw = (np.array(0.4), np.array(0.2), np.array(-1.0))
+    probes = orc.rademacher(3, p, n)
+
+    def rank_body(handle):
+        comm = RowComm(n, handle)
+        assert (comm.world, comm.nloc, comm.rank) == (world, 64, handle.rank)
+        lay = Layout(n, world, handle)  # pure row sharding over the logical ranks
+        assert lay.comm.nrows == comm.nrows and lay.probe_groups == 1 and not lay.native
+        assert np.array_equal(comm.gather_rows(comm.rows(torch.as_tensor(probes))).numpy(), probes)
+        op = so.ShardedRbf(X, comm, noise_minval=1e-4)
+        vals, grads = [], np.zeros(3)
+        for v in probes:
+            val, g = so.integrand_value_and_grad(op, k, v[comm.row0 : comm.row0 + comm.nrows], raw)
+            vals.append(val)
+            grads += np.array([float(x) for x in g])
+        mean, std, (g,) = reduce_estimate(torch.tensor(vals), (torch.tensor(grads),), p, group=handle, replicas=world)
+        return mean.item(), std.item(), g.numpy()
+
+    results = LocalWorld(world).run(rank_body)
+    val, grads, vals = orc.hutchinson_value_and_grad(orc.RbfGramOp(X, noise_minval=1e-4), k, probes, raw)
+    for mean, std, g in results:
+        assert np.isclose(mean, val, rtol=1e-11) and np.isclose(std, np.std(vals), rtol=1e-8)
+        assert np.allclose(g, np.array([float(x) for x in grads]), rtol=1e-9, atol=1e-12)
+
+
 # ---- the other row-sharded drivers: three-term recurrence + adjoint, (P)CG -- decomposition under gloo -----------------------------
 def _lz_cg_worker(rank, world, port, out):
     _setup_paths()
