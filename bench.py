@@ -64,7 +64,7 @@ def parse(argv=None):
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the N > 1 run (nccl = RCCL; gloo only to rehearse "
                                                       "the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--gather", default="", choices=["", "grouped", "packed"],
-                    help="native RCCL row group: how the iterate is all-gathered per Krylov step (include/mfx.h MFX_GATHER_*; default grouped)")
+                    help="native RCCL row group: how the iterate is all-gathered per Krylov step (include/mfx.h MFX_GATHER_*; default packed)")
     ap.add_argument("--share-gpus", action="store_true", help="(rehearsal) ranks beyond the visible GPUs share them (needs --backend gloo)")
     args = ap.parse_args(argv)
     if args.probes_per_gpu is not None:

@@ -386,11 +386,12 @@ class NativeRowComm(RowComm):
     GATHER = {"grouped": 0, "packed": 1}
 
     def __init__(self, n: int, group=None, gather: str | None = None):
-        """gather: "grouped" (p all-gathers of nloc elements in one group launch, straight into the operator input; the default) or
-        "packed" (pack, ONE all-gather of p nloc elements, unpack) -- `include/mfx.h`, MFX_GATHER_*; default from $MFX_GATHER."""
+        """gather: "packed" (pack, ONE all-gather of p nloc elements, unpack; the default: one large message is the pattern RCCL's
+        bandwidth figures are quoted for) or "grouped" (p all-gathers of nloc elements in one group launch, straight into the operator
+        input: no copies, but p small operations) -- `include/mfx.h`, MFX_GATHER_*; default from $MFX_GATHER."""
         super().__init__(n, group)
         lib = _lib.get()
-        gather = gather or os.environ.get("MFX_GATHER", "grouped")
+        gather = gather or os.environ.get("MFX_GATHER", "packed")
         if gather not in self.GATHER:
             raise ValueError(f"gather mode {gather!r}: expected one of {sorted(self.GATHER)}")
         self.gather = gather

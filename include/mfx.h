@@ -271,10 +271,11 @@ int mfx_rccl_unique_id(void* id, int64_t bytes);
 int mfx_comm_create_rccl(const void* id, int64_t bytes, int32_t rank, int32_t world, int64_t nloc, mfx_comm* out);
 int mfx_comm_destroy_rccl(mfx_comm* comm);
 /* How a native communicator moves the (p, nloc) iterate of a Krylov step into the (p, n) operator input -- two legs to measure on
- * an 8-GPU node (same results):
- *   MFX_GATHER_GROUPED (default): ONE grouped launch of p ncclAllGather of nloc elements each, straight from the row shards
- *                                 into the operator input (no pack / unpack copies; at config 4: 64 operations of 64 KB per rank);
- *   MFX_GATHER_PACKED           : k_pack_shard, ONE ncclAllGather of p nloc elements (config 4: 4 MB per rank), k_unshard. */
+ * an 8-GPU node (same results).  mfx_comm_create_rccl leaves the communicator in MFX_GATHER_GROUPED; the Python layer selects
+ * MFX_GATHER_PACKED unless told otherwise (matfree_extensions/distributed.py, $MFX_GATHER):
+ *   MFX_GATHER_GROUPED: ONE grouped launch of p ncclAllGather of nloc elements each, straight from the row shards into the
+ *                       operator input (no pack / unpack copies; at config 4: 64 operations of 64 KB per rank);
+ *   MFX_GATHER_PACKED : k_pack_shard, ONE ncclAllGather of p nloc elements (config 4: 4 MB per rank), k_unshard. */
 #define MFX_GATHER_GROUPED 0
 #define MFX_GATHER_PACKED 1
 int mfx_comm_rccl_gather_mode(mfx_comm* comm, int mode);

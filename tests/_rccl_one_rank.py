@@ -51,7 +51,7 @@ def main():
     # grouped per-vector all-gather straight into the operator input); same arithmetic -> the same numbers as the callback path
     from matfree_extensions.distributed import NativeRowComm
 
-    ncomm = NativeRowComm(n)
+    ncomm = NativeRowComm(n, gather="grouped")
     v2, g2 = run(RowShardedOp(op, ncomm))
     torch.cuda.synchronize()
     same = torch.equal(v1, v2) and all(torch.equal(a, b) for a, b in zip(g1, g2))
@@ -73,8 +73,9 @@ def main():
     print("native communicator, three-term + CG: bit-identical to the callback path:", same2)
     ok = ok and same2
     ncomm.close()
-    # the second gather leg: pack, ONE ncclAllGather of the whole (p, nloc) shard, unpack -- same numbers again
-    pcomm = NativeRowComm(n, gather="packed")
+    # the other gather leg (the default): pack, ONE ncclAllGather of the whole (p, nloc) shard, unpack -- same numbers again
+    pcomm = NativeRowComm(n)
+    assert pcomm.gather == "packed"
     v3, g3 = run(RowShardedOp(op, pcomm))
     torch.cuda.synchronize()
     same3 = torch.equal(v1, v3) and all(torch.equal(a, b) for a, b in zip(g1, g3)) and pcomm.self_test()
