@@ -401,6 +401,10 @@ def main(argv=None):
                 "achieved_TFLOPs": 2.0 * rows_local * n * batch / max(grad_ms / max(grad_cnt, 1) * 1e-3, 1e-12) / 1e12,
                 "peak_TFLOPs": MFMA_F16_PEAK_TFLOPS if args.precision == "f16x3" else MFMA_F32_PEAK_TFLOPS,
                 "executed_mfma_flops_factor": 3.0 if args.precision == "f16x3" else 1.0,
+                "note": "f16x3: the batch rows are packed by decreasing size and the tail that holds <= 2^-10 of the summed row bounds "
+                        "|L_b|max |R_b|max is multiplied hi*hi only (what that drops is bounded by 2^-21 of the summed bounds, the size of what "
+                        "the three-product sum drops anyway; decided on the device per launch, DESIGN.md section 3.3) -- the executed factor is 3 "
+                        "for the other rows" if args.precision == "f16x3" else "",
             },
             "krylov_vector_hbm": {
                 # B_fwd + B_bwd = p n s [2k(k+1)+3k] + p n s [3k^2+9k] algorithmic bytes (this rank's rows)
