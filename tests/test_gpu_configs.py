@@ -224,6 +224,31 @@ def test_c3_bloweybq_tridiag_and_adjoint(reortho, ftol, gtol):
     assert np.allclose(dvals.cpu().numpy(), ref_vals, rtol=gtol, atol=gtol * np.abs(ref_vals).max())
 
 
+@pytest.mark.parametrize("k", [2, 3])
+def test_c3_bloweybq_three_term_adjoint_at_short_depth(k):
+    """The numeric check of the three-term adjoint (lanczos.py:288-335) that the chaotic 6-step recurrence above cannot give: on the
+    same SuiteSparse matrix at depth 2 and 3 the amplification is small enough for NumPy's and the GPU's summation orders to agree, and
+    forward coefficients, dv and the gradient w.r.t. ALL stored values are held to the oracle (computed here, fp64)."""
+    g = np.load(os.path.join(GOLD, "csr_bloweybq.npz"))
+    n = g["v"].shape[0]
+    row, col = g["row"].astype(np.int64), g["col"].astype(np.int64)
+    o = orc.CooOp(row, col, n)
+    rng = np.random.default_rng(k)
+    (Qr, (dr_, er)), (qr, br) = orc.tridiag(o, k, g["v"], g["vals"], reortho="none")
+    cot = ((rng.standard_normal(Qr.shape), (rng.standard_normal(k), rng.standard_normal(k - 1))), (rng.standard_normal(n), rng.standard_normal()))
+    dv_ref, (dvals_ref,) = orc.tridiag_none_vjp(o, k, g["v"], (g["vals"],), cot)
+    op, vals, order = CsrOp.from_coo(row, col, g["vals"], n, DEV)
+    vals = vals.double().requires_grad_(True)
+    v = torch.tensor(g["v"], dtype=torch.float64, device=DEV, requires_grad=True)
+    (Q, (d, e)), (q, b) = lanczos.tridiag(op, k, reortho="none")(v, vals)
+    assert np.allclose(d.detach().cpu().numpy(), dr_, rtol=1e-9) and np.allclose(e.detach().cpu().numpy(), er, rtol=1e-9)
+    tc = [torch.tensor(np.asarray(t), dtype=torch.float64, device=DEV) for t in (cot[0][0], cot[0][1][0], cot[0][1][1], cot[1][0], cot[1][1])]
+    dv, dvals = torch.autograd.grad((Q, d, e, q, b), (v, vals), tc)
+    ref_vals = dvals_ref[order.numpy()]
+    assert np.allclose(dv.cpu().numpy(), dv_ref, rtol=1e-6, atol=1e-6 * np.abs(dv_ref).max())
+    assert np.allclose(dvals.cpu().numpy(), ref_vals, rtol=1e-6, atol=1e-6 * np.abs(ref_vals).max())
+
+
 # ------------------------------------------------------------------------------------------------------------------------
 # (f)-2: the reference's own pde_wave numbers
 # ------------------------------------------------------------------------------------------------------------------------
