@@ -10,7 +10,8 @@
 //   * no instruction follows its producer within one gap (exp -> cvt hi -> fma_mix -> cvt lo, one gap apart each),
 // against 532 for the "pair by pair" order of the h3 kernel.  That placement is the table kSplit below.
 //
-// Shapes: RBF, d <= 12 (two distance MFMAs per block for d <= 8, three for d = 9 .. 12: BASELINE config 2 has d = 9), any number of vectors.
+// Shapes: RBF, d <= 16 (two distance MFMAs per block for d <= 8, three for d = 9 .. 12 -- BASELINE config 2 has d = 9 --, four for d = 13 .. 16),
+// any number of vectors.
 // Geometry: 256-thread workgroups = 4 waves x 128 rows (four 32-row blocks mi) x 64 probes; 512 registers per lane: 128
 // accumulators + 128 chain masters (kChainTiles) live in the accumulation registers, the rest in VGPRs.  A 64-column tile is
 // 8 blocks (jb, mi); per block 12 contraction MFMAs, 2 distance MFMAs (for the block after next) and 48 VALU instructions.
@@ -42,7 +43,7 @@ struct FatSplit {
   int e[16], h[8], m[16];
 };
 // The chain tables by chunk width; the slot ORDER by chunk width and by the number NKD of distance MFMAs of a block
-// (NKD = 2: d <= 8; NKD = 3: d = 9 .. 12 -- BASELINE config 2 has d = 9).  With a third distance MFMA a block has one more slot and the
+// (NKD = 2: d <= 8; NKD = 3: d = 9 .. 12 -- BASELINE config 2 has d = 9; NKD = 4: d = 13 .. 16).  With every further distance MFMA a block has one more slot and the
 // tables stay as they are: an entry >= kSlots still means "in the next block", one slot later than before -- every consumer
 // (the contraction MFMAs of k-step 1) still comes later.
 constexpr FatSplit kFatSplit2 = {{0, 1, 2, 3, 4, 5, 5, 6, 7, 8, 9, 10, 10, 11, 12, 13},
@@ -89,6 +90,24 @@ struct FatPlan<1, 3> {
   static constexpr int slot_of(int m) { return m < 2 ? m : (m == 2 ? 3 : (m == 3 ? 5 : m + 3)); }
 };
 
+// NKD = 4 (d = 13 .. 16), 64 vectors: 16 slots -- c0-c7, d0, c8, d1, c9, d2, c10, d3, c11;  <= 32 vectors: 10 slots -- c0 d0 c1 d1 c2 d2 c3 d3 c4 c5
+template <>
+struct FatPlan<2, 4> {
+  static constexpr int kSlots = 16;
+  static constexpr FatSplit kSplit = kFatSplit2;
+  static constexpr int dist_q(int slot) { return (slot >= 8 && slot <= 14 && (slot & 1) == 0) ? (slot - 8) / 2 : -1; }
+  static constexpr int contr_m(int slot) { return slot < 8 ? slot : ((slot & 1) ? 8 + (slot - 9) / 2 : -1); }
+  static constexpr int slot_of(int m) { return m < 8 ? m : 9 + 2 * (m - 8); }
+};
+template <>
+struct FatPlan<1, 4> {
+  static constexpr int kSlots = 10;
+  static constexpr FatSplit kSplit = kFatSplit1;
+  static constexpr int dist_q(int slot) { return (slot >= 1 && slot <= 7 && (slot & 1) == 1) ? (slot - 1) / 2 : -1; }
+  static constexpr int contr_m(int slot) { return slot == 0 ? 0 : (slot <= 6 && (slot & 1) == 0 ? slot / 2 : (slot >= 8 ? slot - 4 : -1)); }
+  static constexpr int slot_of(int m) { return m == 0 ? 0 : (m <= 3 ? 2 * m : m + 4); }
+};
+
 template <int DPAD, int NB>
 struct FatSmem {
   static constexpr int KD = DPAD + 2;
@@ -113,7 +132,7 @@ __global__ __launch_bounds__(256, 1) void k_rbf_fat_apply(const float* __restric
   if (rangeflag && *rangeflag != 0) return;  // f16 range guard: the fp32-distance launch queued behind this one does the work
   using S = FatSmem<DPAD, NB>;
   constexpr int KD = S::KD, NKD = S::NKD, AROW = S::AROW;
-  static_assert(NKD == 2 || NKD == 3, "two or three distance MFMAs per block (d <= 12)");
+  static_assert(NKD >= 2 && NKD <= 4, "two to four distance MFMAs per block (d <= 16)");
   using Plan = FatPlan<NB, NKD>;
   constexpr int kSlots = Plan::kSlots;
   extern __shared__ __attribute__((aligned(16))) char fat_smem[];
@@ -421,8 +440,10 @@ int rbf_fat_launch(int dpad, int nb, bool vec4, dim3 grid, hipStream_t stream, c
   if (dpad == 8 && nb == 2) return fat_launch_dn<8, 2>(MFX_FAT_ARGS);
   if (dpad == 12 && nb == 1) return fat_launch_dn<12, 1>(MFX_FAT_ARGS);
   if (dpad == 12 && nb == 2) return fat_launch_dn<12, 2>(MFX_FAT_ARGS);
+  if (dpad == 16 && nb == 1) return fat_launch_dn<16, 1>(MFX_FAT_ARGS);
+  if (dpad == 16 && nb == 2) return fat_launch_dn<16, 2>(MFX_FAT_ARGS);
 #undef MFX_FAT_ARGS
-  set_error("fat-wave Gram matvec supports d <= 12 and chunks of 32 or 64 vectors");
+  set_error("fat-wave Gram matvec supports d <= 16 and chunks of 32 or 64 vectors");
   return MFX_ERR_UNSUPPORTED;
 }
 

@@ -1092,7 +1092,7 @@ static int launch_apply_h3k(const mfx_operator* op, const float* xs, const float
   }
   if (pack) {
     bool done = false;
-    if constexpr (KIND == MFX_KERNEL_RBF && DPAD <= 12) {
+    if constexpr (KIND == MFX_KERNEL_RBF) {
       if (rbf_fat()) {  // fat waves (mfx_rbf_fat.hip): four waves of 128 rows, one per SIMD
         MFX_TRY(rbf_fat_launch(DPAD, NB, vec4, grid_pk, stream, xs, sq, n, (const float*)op->outputscale, (const float*)op->noise, vscale,
                                x, ldx, y, ldy, p, pkv, pka, part, rangeflag, ldpart, row0, rend));

@@ -1,5 +1,5 @@
 """The matrix-core Gram matvec kernels against the fp64 NumPy oracle: the fat-wave kernel (`k_rbf_fat_apply`,
-csrc/mfx_rbf_fat.hip: the default for RBF with d <= 12 -- BASELINE config 4's matvec and config 2's -- in its two forms, chunks of 64 vectors and,
+csrc/mfx_rbf_fat.hip: the default for RBF with d <= 16 -- BASELINE config 4's matvec and config 2's -- in its two forms, chunks of 64 vectors and,
 for at most 32 vectors, one 32-probe block) and the same-program kernel `k_rbf_mfma_apply_h3` (every other shape, and
 MFX_RBF_FAT=0).
 
@@ -92,7 +92,7 @@ sys.path.insert(0, {root!r})
 sys.path.insert(0, {pkg!r})
 import test_gpu_matvec_kernels as t
 n = 20000                   # 313 tiles in ONE sweep: two chain folds
-for kernel, p, d in (("rbf", 64, 8), ("matern32", 64, 8), ("rbf", 24, 8), ("rbf", 64, 9), ("rbf", 24, 12)):
+for kernel, p, d in (("rbf", 64, 8), ("matern32", 64, 8), ("rbf", 24, 8), ("rbf", 64, 9), ("rbf", 24, 12), ("rbf", 64, 16), ("rbf", 9, 13)):
     o, op, raw, params, V = t._setup(n, d, p, kernel, True, seed=11)
     # smooth positive vectors: the accumulators grow monotonically, which is what the chain folds are for
     V[:8] = np.abs(V[:8])
@@ -119,7 +119,7 @@ def _run_child(tmp_path, tag, **env_over):
 def test_unsplit_sweep_with_chain_folds_and_bit_identity_of_the_two_kernels(tmp_path):
     fat = _run_child(tmp_path, "fat", MFX_RBF_SPLIT="1", MFX_RBF_FAT="1")
     h3 = _run_child(tmp_path, "h3", MFX_RBF_SPLIT="1", MFX_RBF_FAT="0")
-    for kernel in ("rbf64_d8", "matern3264_d8", "rbf24_d8", "rbf64_d9", "rbf24_d12"):
+    for kernel in ("rbf64_d8", "matern3264_d8", "rbf24_d8", "rbf64_d9", "rbf24_d12", "rbf64_d16", "rbf9_d13"):
         # the fat-wave kernel keeps the order of every sum of the same-program kernel (blocks, k-steps, products, chain folds):
         # bit-identical, so the accuracy tables of profiles/r02a_accuracy carry over (Matern: the child runs h3 both times)
         assert np.array_equal(np.load(fat + "_" + kernel + ".npy"), np.load(h3 + "_" + kernel + ".npy")), kernel
@@ -133,13 +133,13 @@ def test_every_parity_case_on_the_same_program_kernel():
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]
 
 
-@pytest.mark.parametrize("d", [8, 9])
+@pytest.mark.parametrize("d", [8, 9, 14])
 @pytest.mark.parametrize("p", [64, 32])
 def test_every_block_position_of_a_tile(p, d):
     """Unit vectors: K[i][j] itself, for the columns of one tile at a time -- every (column block, row block) position of the fat
     kernel's block pipeline (the blocks whose distances are computed across the mid-tile barrier included), first, middle and last
     tile; with 32 vectors (the one-probe-block form) one column block of the tile at a time."""
-    n = 1536  # d = 9: three distance MFMAs per block (config 2's shape), another slot order
+    n = 1536  # d = 9: three distance MFMAs per block (config 2's shape), d = 14: four -- other slot orders
     o, op, raw, params, _ = _setup(n, d, p, "rbf", False, seed=3)
     for tile, half in [(t, h) for t in (0, 1, 11, n // 64 - 1) for h in range(64 // p)]:
         E = np.zeros((p, n))
