@@ -275,7 +275,16 @@ __global__ __launch_bounds__(256, 1) void k_rbf_fat_apply(const float* __restric
   asm volatile("" ::: "memory");
 
   // ---- pipeline state.  Blocks are numbered along the sweep: block = 8 tile + 4 jb + mi. --------------------------------------
-  floatx16 wc, wn, wd;          // distance blocks: current (its last pairs still being split), next (being split), next but one
+  // distance blocks: current (its last pairs still being split), next (being split), next but one.  Three roles, eight blocks per tile:
+  // with three buffers that change roles by moves, the tile loop's back edge carries a rotation by 8 mod 3 = 2 positions (~6 v_mov per
+  // block, 12 % of the VALU instructions of the VALU-bound <= 32-vector form).  There (registers to spare: 304 of 512) the buffers are a ring
+  // of FOUR indexed by the block number -- 4 divides 8, every index is static, no move; with 64 vectors (all 512 registers in use, VALU
+  // hidden behind the MFMAs) the three buffers stay.
+  constexpr bool kRing4 = NB == 1;
+  floatx16 wr[kRing4 ? 4 : 3];
+#define MFX_WC(blk) wr[kRing4 ? ((blk) & 3) : 0]
+#define MFX_WN(blk) wr[kRing4 ? (((blk) + 1) & 3) : 1]
+#define MFX_WD(blk) wr[kRing4 ? (((blk) + 2) & 3) : 2]
   half8 ahc[2], alc[2], ahn[2], aln[2];   // A fragments (hi, lo) x k-step of the current and of the next block
   unsigned lpc[8], lpn[8];                 // packed lo pairs in the making (between the mixlo and the mixhi step)
   half8 vf[2][NB][2];           // probe fragments of the current column block [k-step][probe block][hi / lo]
@@ -289,13 +298,13 @@ __global__ __launch_bounds__(256, 1) void k_rbf_fat_apply(const float* __restric
 #pragma unroll
       for (int hl = 0; hl < 2; ++hl) read_v1(vf[s][nb][hl], 0, 0, s, nb, hl);
 #pragma unroll
-  for (int q = 0; q < NKD; ++q) dist_step(wc, ajs[0][q], bih[0][q], q == 0);
+  for (int q = 0; q < NKD; ++q) dist_step(MFX_WC(0), ajs[0][q], bih[0][q], q == 0);
 #pragma unroll
-  for (int q = 0; q < NKD; ++q) dist_step(wn, ajs[0][q], bih[1][q], q == 0);
-  asm volatile("" : "+v"(wc));  // ties the first reader of wc behind the last of these MFMAs (two MFMAs after the one that wrote wc)
+  for (int q = 0; q < NKD; ++q) dist_step(MFX_WN(0), ajs[0][q], bih[1][q], q == 0);
+  asm volatile("" : "+v"(MFX_WC(0)));  // ties the first reader of wc behind the last of these MFMAs (two MFMAs after the one that wrote wc)
   // block 0's split as far as the table places it before a block boundary (its lag-1 steps run in the loop, like every block's)
 #pragma unroll
-  for (int slot = 0; slot < kSlots; ++slot) split_slot(slot, 0, wc, ahc, alc, lpc, false);
+  for (int slot = 0; slot < kSlots; ++slot) split_slot(slot, 0, MFX_WC(0), ahc, alc, lpc, false);
 
   const float sc = outputscale[0];
   int tl = 0;
@@ -328,7 +337,7 @@ __global__ __launch_bounds__(256, 1) void k_rbf_fat_apply(const float* __restric
         __builtin_amdgcn_sched_barrier(0);
         if (Plan::dist_q(slot) >= 0) {
           const int q = Plan::dist_q(slot);
-          dist_step(wd, ajs[jb2 & 1][q], bih[mi2][q], q == 0);
+          dist_step(MFX_WD(blk), ajs[jb2 & 1][q], bih[mi2][q], q == 0);
         } else {
           const int m = Plan::contr_m(slot);
           const int s = m / (3 * NB), nb = (m / 3) % NB, w = m % 3;
@@ -336,8 +345,8 @@ __global__ __launch_bounds__(256, 1) void k_rbf_fat_apply(const float* __restric
                                                                acc[mi][nb], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        split_slot(slot, 1, wc, ahc, alc, lpc, neg_c);  // this block's late pairs first (their consumers are a few slots away)
-        split_slot(slot, 0, wn, ahn, aln, lpn, neg_n);
+        split_slot(slot, 1, MFX_WC(blk), ahc, alc, lpc, neg_c);  // this block's late pairs first (their consumers are a few slots away)
+        split_slot(slot, 0, MFX_WN(blk), ahn, aln, lpn, neg_n);
         // fragment reads, one per gap: the probe fragments of the NEXT column block during this one (blocks mi = 1, 2: sixteen
         // reads... eight per block), the column operand of the column block after that in block mi = 1
         if (mi == 1 && slot < NKD) {
@@ -370,8 +379,10 @@ __global__ __launch_bounds__(256, 1) void k_rbf_fat_apply(const float* __restric
       // rotate: next -> current, next-but-one -> next
       ahc[0] = ahn[0]; ahc[1] = ahn[1];
       alc[0] = aln[0]; alc[1] = aln[1];
-      wc = wn;
-      wn = wd;
+      if constexpr (!kRing4) {
+        wr[0] = wr[1];
+        wr[1] = wr[2];
+      }
 #pragma unroll
       for (int q = 0; q < 8; ++q) lpc[q] = lpn[q];
     }
@@ -412,6 +423,10 @@ __global__ __launch_bounds__(256, 1) void k_rbf_fat_apply(const float* __restric
       }
     }
 }
+
+#undef MFX_WC
+#undef MFX_WN
+#undef MFX_WD
 
 template <int DPAD, int NB>
 static int fat_launch_dn(bool vec4, dim3 grid, hipStream_t stream, const float* xs, const float* sq, int64_t n,
