@@ -266,15 +266,15 @@ def main(argv=None):
               for v in (inv_softplus(2.0), inv_softplus(1.0), inv_softplus(0.1))]
     sampler = hutchinson.sampler_rademacher(X[:, 0], num=count)
 
-    def make_step(precision):
+    def make_step(precision, comm=layout.comm):
         op = gp_util.gram_operator(X, precision=precision, kernel=args.kernel)
-        matvec = RowShardedOp(op, layout.comm) if layout.comm is not None else op
+        matvec = RowShardedOp(op, comm) if comm is not None else op
         integrand = lanczos.integrand_spd(torch.log, k, matvec)
 
         def step(seed):
             probes = sampler((seed, first))  # this probe group's slice of ONE global +-1 probe matrix
-            if layout.comm is not None:
-                probes = layout.comm.rows(probes)
+            if comm is not None:
+                probes = comm.rows(probes)
             values = integrand(probes, *params)
             grads = torch.autograd.grad(values.sum(), params)
             return reduce_estimate(values.detach(), grads, p_total, replicas=layout.replicas)
@@ -319,6 +319,36 @@ def main(argv=None):
     comm_ms, comm_cnt = _lib.timing_read(3)
     _lib.timing_reset()
 
+    # Every gather leg of the row group in the SAME process group, so that one `bench.py --gpus N` line carries all of them (the
+    # driver runs one command per N): the native communicator's packed and grouped all-gather (include/mfx.h MFX_GATHER_*) and the
+    # torch.distributed callbacks (what MFX_NATIVE_COMM=0 selects).  Per leg: 1 warm-up + 2 timed steps without kernel timers, then
+    # one step with them for the all-gather's own time.  The headline above is the leg named in `config.parallelism`.
+    gather_legs = None
+    rccl_view = None
+    if world > 1 and layout.comm is not None:
+        from matfree_extensions.distributed import RowComm
+
+        def leg(comm_obj):
+            st = make_step(args.precision, comm_obj)
+            t, _ = timed(st, 2, 1)
+            _lib.timing_reset()
+            _lib.timing_enable(True)
+            timed(st, 1, 0)
+            _lib.timing_enable(False)
+            g_ms, _ = _lib.timing_read(3)
+            _lib.timing_reset()
+            return {"ms_per_step": 1e3 * t / 2, "allgather_incl_pack_unpack": g_ms}
+
+        gather_legs = {}
+        if layout.native:
+            rccl_view = layout.comm.rccl_count()  # (ranks, rank) from ncclCommCount / ncclCommUserRank: RCCL's own view of the row group
+            headline = layout.comm.gather
+            for mode_name in ("packed", "grouped"):
+                layout.comm.set_gather(mode_name)
+                gather_legs["native_" + mode_name] = leg(layout.comm)
+            layout.comm.set_gather(headline)
+        gather_legs["torch_distributed_callbacks"] = leg(RowComm(n, layout.comm.group))
+
     modes = {args.precision: 1e3 * elapsed / args.steps}
     if not args.no_modes:
         for mode in MODES:
@@ -339,11 +369,14 @@ def main(argv=None):
         peak = MFMA_F16_PEAK_TFLOPS if split else MFMA_F32_PEAK_TFLOPS
         kernel = ("k_rbf_fat_apply (Gram matvec, one wave per SIMD; fp32 emulated by 3 f16 MFMA products, distances included; "
                   "pre-pass and split reduction inside the timed span)" if split else "k_rbf_mfma_apply (Gram matvec, exact fp32 MFMA)")
-        traffic = None
+        # HBM-side bytes per launch: NOT measured in this run (PMC counters need rocprofv3 around the process) -- read from the file
+        # tools/prof_traffic.sh wrote, which names the commit and the command it was collected on (`traffic_source`)
+        traffic, traffic_source = None, None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile) and world == 1:
-            traffic = json.load(open(tfile)).get("k_rbf_fat_apply_hbm_bytes_per_launch" if split
-                                                 else "k_rbf_mfma_apply_hbm_bytes_per_launch")
+            tj = json.load(open(tfile))
+            traffic = tj.get("k_rbf_fat_apply_hbm_bytes_per_launch" if split else "k_rbf_mfma_apply_hbm_bytes_per_launch")
+            traffic_source = f"profiles/traffic.json @ {tj.get('commit', 'unknown commit')} ({tj.get('command', 'command not recorded')}); read from the file, not measured in this run"
         mean, std, grads = out
         batch = count * k
         line = {
@@ -366,8 +399,9 @@ def main(argv=None):
                             f"{p_total} probes, fp32 (BASELINE config 4)",
                 "N": n, "d": d, "krylov_depth": k, "probes_total": p_total, "probes_on_this_rank": count,
                 "rows_on_this_rank": rows_local,
-                "parallelism": f"{layout.describe()}; world size seen by rank 0 = {dist.get_world_size() if world > 1 else 1}; "
-                               f"row-group collectives: {('libmfx -> RCCL (native, ' + layout.comm.gather + ' gather)') if layout.native else ('host callbacks' if layout.comm is not None else 'none')}",
+                "parallelism": f"{layout.describe()}; world size seen by rank 0 (torch.distributed) = {dist.get_world_size() if world > 1 else 1}; "
+                               f"row-group collectives: {('libmfx -> RCCL (native, ' + layout.comm.gather + ' gather); ranks in libmfx's own communicator (ncclCommCount) = ' + str(rccl_view[0])) if layout.native else ('host callbacks' if layout.comm is not None else 'none')}",
+                "rccl_comm_ranks": rccl_view[0] if rccl_view else None,
                 "gram_precision": args.precision, "kernel": args.kernel,
             },
             "modes": {"ms_per_step": modes,
@@ -380,6 +414,7 @@ def main(argv=None):
                 "unit": "TFLOP/s",
                 "frac": achieved / peak,
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 "avg_launch_ms": avg_ms,
                 "launches": apply_cnt,
                 "measured_in": "the instrumented repeat of the timed steps (same seeds, hipEvents around every launch of the class on the "
@@ -389,6 +424,7 @@ def main(argv=None):
                 "executed_mfma_flops_factor": 3.0 if split else 1.0,
                 "frac_of_fp32_mfma_peak": achieved / MFMA_F32_PEAK_TFLOPS,
             },
+            "gather_legs_ms_per_step": gather_legs,
             "breakdown_ms_per_step": {
                 "gram_matvec": apply_ms / args.steps,
                 "param_grad_sweep": grad_ms / args.steps,
@@ -402,7 +438,7 @@ def main(argv=None):
                 "peak_TFLOPs": MFMA_F16_PEAK_TFLOPS if args.precision == "f16x3" else MFMA_F32_PEAK_TFLOPS,
                 "executed_mfma_flops_factor": 3.0 if args.precision == "f16x3" else 1.0,
                 "note": "f16x3: the batch rows are packed by decreasing size and the tail that holds <= 2^-10 of the summed row bounds "
-                        "|L_b|max |R_b|max is multiplied hi*hi only (what that drops is bounded by 2^-21 of the summed bounds, the size of what "
+                        "|L_b|max |R_b|max is multiplied hi*hi only (what that drops is bounded by 2^-20 of the summed bounds, the size of what "
                         "the three-product sum drops anyway; decided on the device per launch, DESIGN.md section 3.3) -- the executed factor is 3 "
                         "for the other rows" if args.precision == "f16x3" else "",
             },

@@ -32,6 +32,8 @@ struct RcclApi {
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;        // optional (mfx_comm_rccl_count)
+  decltype(&ncclCommUserRank) CommUserRank = nullptr;  // optional
 };
 
 char g_rccl_why[256] = "unknown";  // why rccl() is null: written once, inside the call_once below
@@ -57,6 +59,8 @@ RcclApi* rccl() {
     MFX_SYM(GroupStart, "ncclGroupStart");
     MFX_SYM(GroupEnd, "ncclGroupEnd");
     MFX_SYM(GetErrorString, "ncclGetErrorString");
+    MFX_SYM(CommCount, "ncclCommCount");
+    MFX_SYM(CommUserRank, "ncclCommUserRank");
 #undef MFX_SYM
     if (!(api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce && api.AllGather && api.GroupStart && api.GroupEnd)) {
       snprintf(g_rccl_why, sizeof(g_rccl_why), "librccl was loaded but lacks one of the entry points used here (ncclGetUniqueId ... ncclGroupEnd)");
@@ -165,6 +169,20 @@ int mfx_comm_rccl_gather_mode(mfx_comm* comm, int mode) {
   MFX_REQUIRE(mode == MFX_GATHER_GROUPED || mode == MFX_GATHER_PACKED, MFX_ERR_INVALID, "gather mode %d", mode);
   // packed: the drivers take their generic path -- k_pack_shard, ONE ncclAllGather of the (p, nloc) shard (native_allgather), k_unshard
   comm->allgather_rows = mode == MFX_GATHER_GROUPED ? native_allgather_rows : nullptr;
+  return MFX_OK;
+}
+
+int mfx_comm_rccl_count(const mfx_comm* comm, int32_t* ranks, int32_t* rank) {
+  using namespace mfx;
+  MFX_REQUIRE(comm && comm->ctx && comm->allreduce_sum == native_allreduce, MFX_ERR_INVALID, "not a communicator of mfx_comm_create_rccl");
+  MFX_REQUIRE(ranks && rank, MFX_ERR_INVALID, "null output");
+  RcclApi* a = rccl();
+  MFX_REQUIRE(a && a->CommCount && a->CommUserRank, MFX_ERR_UNSUPPORTED, "librccl lacks ncclCommCount / ncclCommUserRank");
+  int cnt = -1, me = -1;
+  MFX_NCCL(a->CommCount(static_cast<NativeComm*>(comm->ctx)->comm, &cnt));
+  MFX_NCCL(a->CommUserRank(static_cast<NativeComm*>(comm->ctx)->comm, &me));
+  *ranks = cnt;
+  *rank = me;
   return MFX_OK;
 }
 

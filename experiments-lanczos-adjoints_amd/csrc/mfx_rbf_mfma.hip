@@ -1054,6 +1054,8 @@ static int launch_apply_h3k(const mfx_operator* op, const float* xs, const float
   int64_t gx = (n + 8191) / 8192;
   if (gx > 64) gx = 64;
   while (gx > 1 && 3 * p + 64 + p * gx > (int64_t)65536 * 3) --gx;
+  // (one slice per vector must fit behind the scales and the flag: p <= 49136 -- far beyond any probe count; unguarded before round 5)
+  MFX_REQUIRE(3 * p + 64 + p * gx <= (int64_t)65536 * 3, MFX_ERR_UNSUPPORTED, "matrix-core Gram matvec: %lld vectors exceed the scale / slice-maximum region of the workspace (at most 49136)", (long long)p);
   if (pack) {
     k_row_amax_part<<<dim3((unsigned)gx, (unsigned)p), 256, 0, stream>>>(x, ldx, n, amax_part, rangeflag);
     MFX_CHECK_LAUNCH();
@@ -1213,18 +1215,32 @@ constexpr uint32_t kSaltL = 0x51ED270Bu, kSaltR = 0xB5297A4Du;
 //     f16 MFMA aligns its products to the largest of them and truncates the rest);
 //   * the cross products hi lo + lo hi of a row are 2^-11 of its hi hi product.  The TAIL of the sorted order -- the longest run of
 //     the smallest rows whose bounds add up to at most 2^-MFX_GRAD_ONE_PRODUCT_LOG2 (default 2^-10) of the sum of ALL bounds -- is
-//     multiplied hi hi only: what that drops from any S_ij is at most 2^-(11 + 10) = 2^-21 of sum_b m_b even if it all had one sign,
-//     the size of what the three-product sum itself drops (lo lo, the MFMA's truncation).  Those stages (from stage n3 on) stage and
+//     multiplied hi hi only: with |lo| <= 2^-11 |x| the two cross terms of a row are at most 2 x 2^-11 m_b = 2^-10 m_b, so what that drops from
+//     any S_ij is at most 2^-(10 + 10) = 2^-20 of sum_b m_b even if it all had one sign -- a bound relative to the summed row bounds
+//     sum_b |L_b|max |R_b|max, NOT to |S_ij|; what protects the gradient (which cancels to 1e-4 .. 1e-5 of its terms) is measured: the
+//     16-probe-set table of profiles/r05b_*.  The three-product sum itself drops terms of that size (lo lo, the MFMA's truncation).  Those stages (from stage n3 on) stage and
 //     multiply their hi images only: a third of the MFMAs, half of the L2 -> LDS bytes.  (A per-row cut relative to the largest row
 //     would let MANY small rows through that together carry the gradient; measured at config 4: per-row cut 2^-6 -> 4e-4 off.)
 // Decided on the device per launch; no row qualifies when the rows are of similar size, and then nothing changes but the order.
+// On row shards every rank picks its n3 from the maxima of ITS rows of L: the ranks may run different arithmetic on their tails
+// (harmless: each rank's partial sums obey the bound above; the ranks' results are added in fp64 by the estimator's all-reduce).
+// Knob: MFX_GRAD_ONE_PRODUCT_LOG2 at build time sets the default (10); the environment variable of the same name, read once per process,
+// overrides it at run time -- 0 switches the tail off (every stage three products): the A/B without a rebuild.
 #ifndef MFX_GRAD_ONE_PRODUCT_LOG2
 #define MFX_GRAD_ONE_PRODUCT_LOG2 10
 #endif
+static int grad_one_product_log2() {
+  static const int v = [] {
+    const char* e = getenv("MFX_GRAD_ONE_PRODUCT_LOG2");
+    const int x = e ? atoi(e) : MFX_GRAD_ONE_PRODUCT_LOG2;
+    return x < 0 ? 0 : (x > 60 ? 60 : x);
+  }();
+  return v;
+}
 constexpr int kSortMax = 8192;  // rows the LDS sort takes (64 KB of 64-bit keys); larger batches keep the (step, probe) order, three products
 // perm[bt] = source row of packed row bt (-1: a zero row of the padding); tail[0] = n3, the first one-product stage
 __global__ __launch_bounds__(1024) void k_order_rows(const float* __restrict__ amaxL, const float* __restrict__ amaxR, int64_t batch,
-                                                     int64_t inner, int64_t bpad, int npow2, int* __restrict__ perm,
+                                                     int64_t inner, int64_t bpad, int npow2, int one_log2, int* __restrict__ perm,
                                                      int* __restrict__ tail) {
   extern __shared__ unsigned long long keys[];  // (bound bits << 32) | (0xFFFFFFFF - default position): sorted DESCENDING
   const int64_t outer = batch / inner;
@@ -1260,27 +1276,51 @@ __global__ __launch_bounds__(1024) void k_order_rows(const float* __restrict__ a
     }
     perm[bt] = src;
   }
-  if (threadIdx.x == 0) {
-    // the one-product tail: the longest run of the SMALLEST rows whose bounds add up to at most 2^-LOG2 of the sum of all bounds
-    // (a row with a NaN / inf bound makes the sum infinite: no tail)
-    const int nstage = (int)(bpad / 32);
-    int n3 = nstage;
-    if (MFX_GRAD_ONE_PRODUCT_LOG2 > 0) {
-      double total = 0.0;
-      for (int64_t bt = 0; bt < batch; ++bt) total += (double)__uint_as_float((unsigned)(keys[bt] >> 32));
-      const double cut = total < 1.0e38 ? ldexp(total, -MFX_GRAD_ONE_PRODUCT_LOG2) : -1.0;
-      double mass = 0.0;
-      int64_t first = batch;  // first row of the tail
-      while (first > 0) {
-        const double m = (double)__uint_as_float((unsigned)(keys[first - 1] >> 32));
-        if (mass + m > cut) break;
-        mass += m;
-        --first;
-      }
-      n3 = (int)((first + 31) / 32);  // whole stages only
-    }
-    tail[0] = n3;
+  // the one-product tail: the longest run of the SMALLEST rows whose bounds add up to at most 2^-one_log2 of the sum of all bounds
+  // (a row with a NaN / inf bound makes the sum infinite: no tail).  Block-wide: thread t owns `per` consecutive sorted rows; a suffix
+  // scan over the threads' partial sums (wave shuffles + 16 wave totals in LDS) gives every thread the mass of the rows behind its
+  // own, and the smallest row index whose suffix mass stays within the cut is found with one LDS atomicMin.  (Round 4 had thread 0 sum
+  // and scan all <= 8192 keys alone, in front of both pack launches of every sweep.)
+  __shared__ double wave_sum[16];
+  __shared__ int first_row;
+  const int nstage = (int)(bpad / 32);
+  if (one_log2 <= 0) {
+    if (threadIdx.x == 0) tail[0] = nstage;
+    return;
   }
+  const int per = npow2 >= 1024 ? npow2 / 1024 : 1;
+  const int64_t r0 = (int64_t)threadIdx.x * per, r1 = r0 + per < batch ? r0 + per : batch;
+  double mine = 0.0;
+  for (int64_t bt = r1 - 1; bt >= r0; --bt) mine += (double)__uint_as_float((unsigned)(keys[bt] >> 32));
+  // inclusive suffix sum over the lanes of a wave, then over the waves
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double suf = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const double o = __shfl_down(suf, off, 64);
+    if (lane + off < 64) suf += o;
+  }
+  if (lane == 0) wave_sum[wv] = suf;
+  if (threadIdx.x == 0) first_row = (int)batch;
+  __syncthreads();
+  double behind = 0.0, total = 0.0;  // mass of the waves behind mine; mass of all rows
+  for (int w = 0; w < 16; ++w) {
+    total += wave_sum[w];
+    if (w > wv) behind += wave_sum[w];
+  }
+  const double cut = total < 1.0e38 ? ldexp(total, -one_log2) : -1.0;
+  double mass = behind + (suf - mine);  // everything behind this thread's rows
+  int64_t first = r1;
+  for (int64_t bt = r1 - 1; bt >= r0; --bt) {
+    const double m = (double)__uint_as_float((unsigned)(keys[bt] >> 32));
+    if (mass + m > cut) break;
+    mass += m;
+    first = bt;
+  }
+  // rows are sorted by decreasing bound, so "suffix mass <= cut" holds from some row on: the smallest such row over all threads
+  if (first < r1) atomicMin(&first_row, (int)first);
+  __syncthreads();
+  if (threadIdx.x == 0) tail[0] = (int)(((int64_t)first_row + 31) / 32);  // whole stages only
 }
 __global__ void k_order_default(int64_t batch, int64_t inner, int64_t bpad, int* __restrict__ perm, int* __restrict__ tail) {
   const int64_t bt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1767,7 +1807,7 @@ static int launch_grad_h(const mfx_operator* op, const float* xs, const float* s
     while (npow2 < bpad) npow2 <<= 1;
     if (npow2 * 8 > 48 * 1024)
       MFX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_order_rows), hipFuncAttributeMaxDynamicSharedMemorySize, kSortMax * 8));
-    k_order_rows<<<1, 1024, (size_t)npow2 * 8, stream>>>(amaxL, amaxR, batch, inner, bpad, npow2, perm, tail);
+    k_order_rows<<<1, 1024, (size_t)npow2 * 8, stream>>>(amaxL, amaxR, batch, inner, bpad, npow2, grad_one_product_log2(), perm, tail);
   } else {
     k_order_default<<<(unsigned)((bpad + 255) / 256), 256, 0, stream>>>(batch, inner, bpad, perm, tail);
   }

@@ -131,6 +131,7 @@ SYMBOLS = {
     "mfx_comm_create_rccl": (_I, [_P, _I64, C.c_int32, C.c_int32, _I64, _CMP]),
     "mfx_comm_destroy_rccl": (_I, [_CMP]),
     "mfx_comm_rccl_gather_mode": (_I, [_CMP, _I]),
+    "mfx_comm_rccl_count": (_I, [_CMP, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "mfx_sharded_workspace_bytes": (_I64, [_OPP, _CMP, _I64, _I64, _I64]),
     "mfx_arnoldi_forward_sharded": (_I, [_OPP, _CMP, _P, _I64, _I64, _I64, _I, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "mfx_arnoldi_adjoint_sharded": (

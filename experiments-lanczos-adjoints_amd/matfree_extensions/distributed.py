@@ -28,120 +28,44 @@ import torch.distributed as dist
 from . import _lib
 
 
-class LocalWorld:
-    """R logical ranks as R THREADS of one process sharing one GPU: the rehearsal stand-in for a process group on a box with fewer
-    GPUs than ranks (a GPU box admits few processes on its card; eight threads are one process).  ``LocalWorld(8).ranks()`` gives
-    the eight group handles; pass one as ``group=`` to `RowComm`, `Layout`, `reduce_estimate` in the thread that plays that rank.
-    Collectives are host rendezvous (a barrier, device copies in rank order -- sums are deterministic) -- every kernel launch, every
-    workspace layout and every callback of the row-sharded drivers is the real one; only the transport is not RCCL.  Timings
-    mean nothing.  ``run(fn)`` starts the threads, passes each its handle and returns the results in rank order (first exception re-raised)."""
+class TorchGroup:
+    """A torch.distributed process group (None = the default group; no process group at all = one rank) behind the four calls the
+    helpers of this module make on a group: ``world``, ``rank``, ``all_reduce_sum``, ``all_gather``.  Anything else that offers these
+    four -- a transport of the caller's own -- can be passed as ``group=`` in its place (`as_group`); the helpers below have ONE path,
+    through this interface.  (tests/_local_world.py plays eight ranks as threads of one process that way.)"""
 
-    def __init__(self, world: int, timeout: float = 120.0):
-        import threading
+    torch_backed = True
 
-        self.world = int(world)
-        self._barrier = threading.Barrier(self.world, timeout=timeout)
-        self._slots = [None] * self.world
+    def __init__(self, pg=None):
+        self.pg = pg
 
-    def ranks(self):
-        return [LocalRank(self, r) for r in range(self.world)]
+    @property
+    def _on(self):
+        return dist.is_available() and dist.is_initialized()
 
-    def run(self, fn):
-        import threading
+    @property
+    def world(self):
+        return dist.get_world_size(self.pg) if self._on else 1
 
-        out, err = [None] * self.world, [None] * self.world
+    @property
+    def rank(self):
+        return dist.get_rank(self.pg) if self._on else 0
 
-        def body(handle):
-            try:
-                # a stream of its own per logical rank: the scratch cache of the host layer is keyed by (device, stream), so the ranks
-                # get separate workspaces exactly as separate processes would
-                own = torch.cuda.stream(torch.cuda.Stream()) if torch.cuda.is_available() else contextlib.nullcontext()
-                # backward passes in THIS thread: the autograd engine otherwise runs every rank's backward nodes on the one worker
-                # thread of the device, one after the other -- the first rank's adjoint driver then waits in its first collective
-                # for ranks whose backward is queued behind it
-                with own, torch.autograd.set_multithreading_enabled(False):
-                    out[handle.rank] = fn(handle)
-                    if torch.cuda.is_available():
-                        torch.cuda.synchronize()
-            except BaseException as exc:  # noqa: BLE001 -- a rank that dies must not leave the others in a rendezvous
-                err[handle.rank] = exc
-                self._barrier.abort()
-
-        threads = [threading.Thread(target=body, args=(h,), name=f"mfx-rank-{h.rank}") for h in self.ranks()]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-        first = next((e for e in err if e is not None and not isinstance(e, __import__("threading").BrokenBarrierError)), None)
-        if first is None:
-            first = next((e for e in err if e is not None), None)
-        if first is not None:
-            raise first
-        return out
-
-
-class LocalRank:
-    """One logical rank of a `LocalWorld` (the ``group=`` argument of this module's classes in the thread that plays it)."""
-
-    def __init__(self, shared: LocalWorld, rank: int):
-        self.shared, self.rank, self.world = shared, int(rank), shared.world
-
-    def _publish(self, t):
-        if t.is_cuda:
-            torch.cuda.synchronize(t.device)
-        self.shared._slots[self.rank] = t
-        self.shared._barrier.wait()
-
-    def all_reduce(self, t, op="sum"):
-        self._publish(t)
-        acc = self.shared._slots[0].clone()
-        for r in range(1, self.world):
-            other = self.shared._slots[r]
-            acc = acc + other if op == "sum" else (torch.minimum(acc, other) if op == "min" else torch.maximum(acc, other))
-        if t.is_cuda:
-            torch.cuda.synchronize(t.device)
-        self.shared._barrier.wait()  # everybody has read everybody's input
-        t.copy_(acc)
+    def all_reduce_sum(self, t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
         return t
 
-    def all_gather_into_tensor(self, out, inp):
-        self._publish(inp)
-        blocks = out.view(self.world, -1)
-        for r in range(self.world):
-            blocks[r].copy_(self.shared._slots[r].reshape(-1))
-        if out.is_cuda:
-            torch.cuda.synchronize(out.device)
-        self.shared._barrier.wait()
+    def all_gather(self, out, inp):
+        dist.all_gather_into_tensor(out, inp, group=self.pg)
         return out
 
-    def barrier(self):
-        self.shared._barrier.wait()
 
-
-def _group_size(group):
-    if isinstance(group, LocalRank):
-        return group.world
-    return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-
-
-def _group_rank(group):
-    if isinstance(group, LocalRank):
-        return group.rank
-    return dist.get_rank(group) if (dist.is_available() and dist.is_initialized()) else 0
-
-
-def _all_reduce_sum(t, group):
-    if isinstance(group, LocalRank):
-        return group.all_reduce(t)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    return t
-
-
-def _all_gather(out, inp, group):
-    if isinstance(group, LocalRank):
-        return group.all_gather_into_tensor(out, inp)
-    dist.all_gather_into_tensor(out, inp, group=group)
-    return out
+def as_group(group):
+    """``group=`` of this module's classes and functions -> an object with world / rank / all_reduce_sum / all_gather: a
+    torch.distributed process group (or None) is wrapped, an object that already offers the four calls is taken as it is."""
+    if all(hasattr(group, a) for a in ("world", "rank", "all_reduce_sum", "all_gather")):
+        return group
+    return TorchGroup(group)
 
 
 def shard_probes(num_total: int, rank: int, world_size: int):
@@ -163,9 +87,7 @@ def rows_per_rank(n: int, world_size: int) -> int:
 
 
 def _active(group=None):
-    if isinstance(group, LocalRank):
-        return group.world > 1
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    return as_group(group).world > 1
 
 
 def reduce_estimate(local_values, local_grads, num_total: int, group=None, replicas: int = 1):
@@ -182,7 +104,7 @@ def reduce_estimate(local_values, local_grads, num_total: int, group=None, repli
     flat += [g.reshape(-1).double() for g in local_grads]
     buf = torch.cat(flat).contiguous()
     if _active(group):
-        _all_reduce_sum(buf, group)
+        as_group(group).all_reduce_sum(buf)
     buf = buf / replicas
     mean = buf[0] / num_total
     var = torch.clamp_min(buf[1] / num_total - mean**2, 0.0)
@@ -221,9 +143,10 @@ class RowComm:
     """
 
     def __init__(self, n: int, group=None):
-        self.group = group
-        self.world = _group_size(group)
-        self.rank = _group_rank(group)
+        self.transport = as_group(group)
+        self.group = getattr(self.transport, "pg", None)  # the torch.distributed process group, where there is one
+        self.world = self.transport.world
+        self.rank = self.transport.rank
         self.n = int(n)
         self.nloc = rows_per_rank(self.n, self.world)
         self.row0 = self.rank * self.nloc
@@ -239,7 +162,7 @@ class RowComm:
 
     def all_reduce_(self, t):
         if self.world > 1 or (self.force_collectives and dist.is_available() and dist.is_initialized()):
-            _all_reduce_sum(t, self.group)
+            self.transport.all_reduce_sum(t)
         return t
 
     def gather_rows(self, t_local):
@@ -250,7 +173,7 @@ class RowComm:
         send[:, : self.nrows] = flat
         out = torch.empty((self.world * flat.shape[0], self.nloc), dtype=t_local.dtype, device=t_local.device)
         if self.world > 1:
-            _all_gather(out, send, self.group)  # rank-major blocks along axis 0
+            self.transport.all_gather(out, send)  # rank-major blocks along axis 0
         else:
             out.copy_(send)
         out = out.reshape(self.world, flat.shape[0], self.nloc).movedim(0, 1).reshape(flat.shape[0], self.world * self.nloc)
@@ -261,8 +184,9 @@ class RowComm:
         """Which entries of the iterate do this rank's rows of a CSR matrix (crow, col: device int32) read from other ranks?
         -> (recv, send): lists of (peer, lo, hi) column ranges -- one bounding range per owner, which is tight for banded / block
         structures (stencils) -- to receive from / send to each peer.  Collective over the row group (one all_gather_object)."""
-        if isinstance(self.group, LocalRank):
-            raise NotImplementedError("the neighbour exchange needs a torch.distributed process group (LocalWorld rehearses the all-gather layout)")
+        if not getattr(self.transport, "torch_backed", False):
+            raise NotImplementedError("the neighbour exchange is point-to-point over a torch.distributed process group; a transport of "
+                                      "the caller's own offers the all-gather layout only")
         c = col[int(crow[self.row0]) : int(crow[self.row0 + self.nrows])].to(torch.int64)
         owner = torch.div(c, self.nloc, rounding_mode="floor")
         recv = []
@@ -306,7 +230,7 @@ class RowComm:
         ``plans``: (forward, transpose) exchange plans of a sparse operator, or None for the all-gather."""
         base, nbytes = ws.data_ptr(), ws.numel()
         failure = []
-        world, group = self.world, self.group
+        world, transport = self.world, self.transport
         collective = world > 1 or (self.force_collectives and dist.is_available() and dist.is_initialized())
         regs = [(ws.data_ptr(), ws.numel(), ws)] + [(t.data_ptr(), t.numel() * t.element_size(), t.view(-1).view(torch.uint8))
                                                    for t in tensors if t is not None]
@@ -348,7 +272,7 @@ class RowComm:
             try:
                 if collective:
                     with on(stream):
-                        _all_reduce_sum(view(buf, count, dtype_code), group)
+                        transport.all_reduce_sum(view(buf, count, dtype_code))
                 return 0
             except Exception as exc:  # never let an exception cross the C boundary
                 failure.append(exc)
@@ -359,7 +283,7 @@ class RowComm:
                 tin, tout = view(inp, count, dtype_code), view(out, count * world, dtype_code)
                 with on(stream):
                     if collective:
-                        _all_gather(tout, tin, group)
+                        transport.all_gather(tout, tin)
                     else:
                         tout.copy_(tin)
                 return 0
@@ -436,6 +360,20 @@ class NativeRowComm(RowComm):
             rc |= self._cm.allgather(self._cm.ctx, local.data_ptr(), full.data_ptr(), 8, _lib.MFX_F32, stream)
             want = torch.arange(1, self.world + 1, dtype=torch.float32, device=dev).repeat_interleave(8).reshape(2, -1)
         return rc == 0 and bool((ones == self.world).all()) and bool((full == want).all())
+
+    def rccl_count(self):
+        """(ranks, rank) as RCCL itself reports them for this communicator (``ncclCommCount`` / ``ncclCommUserRank``) -- libmfx's own
+        view of the row group, as opposed to torch.distributed's world size."""
+        ranks, rank = C.c_int32(-1), C.c_int32(-1)
+        _lib.check(_lib.get().mfx_comm_rccl_count(C.byref(self._cm), C.byref(ranks), C.byref(rank)))
+        return int(ranks.value), int(rank.value)
+
+    def set_gather(self, gather: str):
+        """switch the gather leg of this communicator ("packed" / "grouped"): same results, two message patterns to time"""
+        if gather not in self.GATHER:
+            raise ValueError(f"gather mode {gather!r}: expected one of {sorted(self.GATHER)}")
+        _lib.check(_lib.get().mfx_comm_rccl_gather_mode(C.byref(self._cm), self.GATHER[gather]))
+        self.gather = gather
 
     def close(self):
         if getattr(self, "_cm", None) is not None:
@@ -560,24 +498,26 @@ class Layout:
     def __init__(self, n: int, row_group_size: int = 1, group=None, native: bool | None = None):
         """native: the row group's collectives as libmfx's own RCCL calls (NativeRowComm); default: whenever the process
         group's backend is "nccl" (= RCCL), i.e. one GPU per rank -- gloo rehearsals keep the callback path."""
-        on = isinstance(group, LocalRank) or (dist.is_available() and dist.is_initialized())
+        on = dist.is_available() and dist.is_initialized()
+        transport = as_group(group)
         self.group = group
-        self.world = _group_size(group)
-        rank = _group_rank(group)
+        self.world = transport.world
+        rank = transport.rank
         self.n = int(n)
         self.replicas = int(row_group_size)
         if self.replicas > 1:
-            if isinstance(group, LocalRank):  # in-process rehearsal: pure row sharding over the logical ranks, host-rendezvous collectives
+            if not getattr(transport, "torch_backed", False):  # a transport of the caller's own: its ranks are ONE row group
                 if self.world != self.replicas:
-                    raise ValueError("a LocalWorld rehearses pure row sharding: row_group_size must equal its number of ranks")
+                    raise ValueError("a group that is not a torch.distributed process group cannot be split: row_group_size must equal its number of ranks")
                 self.probe_index, self.probe_groups = 0, 1
                 self.comm = RowComm(n, group)
                 self.native = False
                 return
+            pg = transport.pg
             if self.world > self.replicas:
-                row_group, self.probe_index, self.probe_groups = make_grid(self.replicas, group)
+                row_group, self.probe_index, self.probe_groups = make_grid(self.replicas, pg)
             elif self.world == self.replicas:
-                row_group, self.probe_index, self.probe_groups = group, 0, 1
+                row_group, self.probe_index, self.probe_groups = pg, 0, 1
             else:
                 raise ValueError(f"row group size {row_group_size} exceeds the world size {self.world}")
             if native is None:

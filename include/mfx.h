@@ -279,6 +279,10 @@ int mfx_comm_destroy_rccl(mfx_comm* comm);
 #define MFX_GATHER_GROUPED 0
 #define MFX_GATHER_PACKED 1
 int mfx_comm_rccl_gather_mode(mfx_comm* comm, int mode);
+/* What RCCL itself says about a native communicator: ncclCommCount -> *ranks, ncclCommUserRank -> *rank (the row group the drivers'
+ * collectives really span -- reported by bench.py next to torch.distributed's world size, which is a different library's view).
+ * MFX_ERR_INVALID for an mfx_comm the caller filled in itself.  No counterpart in the reference (no collective there). */
+int mfx_comm_rccl_count(const mfx_comm* comm, int32_t* ranks, int32_t* rank);
 
 int64_t mfx_sharded_workspace_bytes(const mfx_operator* op, const mfx_comm* comm, int64_t n, int64_t k, int64_t p);
 

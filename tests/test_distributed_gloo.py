@@ -148,14 +148,15 @@ def test_rows_x_probes_grid_2x2_equals_single_process(tmp_path):
 
 
 def test_eight_logical_ranks_in_one_process_equal_single_process():
-    """The 8-way row shard that `bench.py --gpus 8` runs, with the ranks as eight THREADS (`distributed.LocalWorld`: the rehearsal
+    """The 8-way row shard that `bench.py --gpus 8` runs, with the ranks as eight THREADS (`tests/_local_world.LocalWorld`: the rehearsal
     transport of tests/test_gpu_sharded.py and tools/rehearse_eight_ranks.py -- a GPU box admits at most six processes on its card):
     RowComm / reduce_estimate on a LocalWorld handle and the sharded restatement of the oracle reproduce the single-process oracle.
     n = 8 x 64 - 30: seven full shards and a ragged last one."""
     _setup_paths()
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _sharded_oracle as so
-    from matfree_extensions.distributed import Layout, LocalWorld, RowComm, reduce_estimate
+    from _local_world import LocalWorld
+    from matfree_extensions.distributed import Layout, RowComm, reduce_estimate
     from oracle import slq_oracle as orc
 
     n, d, k, p, world = 8 * 64 - 30, 3, 6, 3, 8

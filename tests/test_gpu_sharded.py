@@ -571,10 +571,11 @@ def test_rccl_one_rank_group_runs_the_collective_callbacks():
 @pytest.mark.parametrize("n", [8 * 2048, 8 * 2048 - 700])
 def test_eight_logical_ranks_in_one_process_reproduce_the_single_rank_estimate(dtype_name, precision, vtol, gtol, n):
     """`bench.py --gpus 8` shards the rows of config 4 eight ways.  A GPU box admits at most six processes on its card, so the
-    eight ranks are eight THREADS here (`distributed.LocalWorld`: host-rendezvous collectives, everything else -- the sharded
+    eight ranks are eight THREADS here (`tests/_local_world.LocalWorld`: host-rendezvous collectives, everything else -- the sharded
     drivers, their workspaces and callbacks, the row-block matvec with its column splits, the row-block gradient sweep, the fused
     reduction of the estimate -- is the code the eight processes run).  Even shards (8 x 2048 rows) and a ragged last shard."""
-    from matfree_extensions.distributed import LocalWorld, slq_value_and_grad
+    from _local_world import LocalWorld
+    from matfree_extensions.distributed import slq_value_and_grad
 
     dtype = getattr(torch, dtype_name)
     d, k, p = 8, 10, 16

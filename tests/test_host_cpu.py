@@ -178,3 +178,36 @@ def test_hot_kernels_scratch_budget_from_the_code_object():
         else:
             assert scratch == 0 and spill == 0, (name, spill, scratch)
     assert hot >= 12, hot
+
+
+def test_host_side_of_the_c_abi_under_address_and_ub_sanitizers():
+    """"`-fsanitize=address` host build of the C-ABI shim".  `make asan` compiles the HOST code of every
+    csrc/*.hip under AddressSanitizer + UndefinedBehaviorSanitizer (device code unchanged; GPU sanitizers are not available on
+    this pool) and tests/cabi/cabi_host_checks.cpp with the same flags.  Run here, without a GPU: (1) that program -- every workspace
+    query on every operator kind and padding, the argument checks of the drivers, timing / graph counters; (2) this file's
+    symbol-export, struct-layout, argument-error and no-fallback tests in a child interpreter that loads asan/libmfx_asan.so.
+    Any invalid access or undefined behaviour aborts the child (`-fno-sanitize-recover`)."""
+    import shutil
+    import subprocess
+    import sys
+
+    csrc = os.path.join(ROOT, "experiments-lanczos-adjoints_amd", "csrc")
+    clang = "/opt/rocm/lib/llvm/bin/clang++"
+    if not (shutil.which("make") and os.path.exists("/opt/rocm/bin/hipcc") and os.path.exists(clang)):
+        pytest.skip("needs make, hipcc and the ROCm clang")
+    rt = subprocess.run([clang, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(rt) or not os.path.exists(rt):
+        pytest.skip("the sanitizer runtime is not installed")
+    build = subprocess.run(["make", "-C", csrc, "asan", "-j4"], capture_output=True, text=True, timeout=900)
+    assert build.returncode == 0, build.stdout[-2000:] + build.stderr[-2000:]
+    lib = os.path.join(csrc, "asan", "libmfx_asan.so")
+    chk = subprocess.run([os.path.join(csrc, "asan", "cabi_host_checks")], capture_output=True, text=True, timeout=300)
+    assert chk.returncode == 0 and "cabi_host_checks ok" in chk.stdout, chk.stdout[-2000:] + chk.stderr[-3000:]
+    # CPython itself is not leak-clean: leak detection off for the interpreter child (on for the C++ program above)
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1",
+               MFX_LIBRARY_PATH=lib)
+    child = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-p", "no:cacheprovider", "-k",
+                            "exports_every or struct_layout or argument_errors or no_cpu_fallback"],
+                           cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert child.returncode == 0 and "4 passed" in child.stdout, child.stdout[-2000:] + child.stderr[-3000:]
+    assert "ERROR: AddressSanitizer" not in child.stderr and "runtime error:" not in child.stderr, child.stderr[-3000:]

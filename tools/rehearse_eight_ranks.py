@@ -1,6 +1,6 @@
 """BASELINE config 4 in the layout `bench.py --gpus 8` runs -- the rows of the kernel matrix and of every Krylov vector sharded
 eight ways, all 64 probes on every rank -- rehearsed on ONE GPU: the eight ranks are eight threads of this process
-(`matfree_extensions.distributed.LocalWorld`; a GPU box admits at most six processes on its card).  Everything but the transport
+(`tests/_local_world.LocalWorld`, handed to the package as a `group=` transport; a GPU box admits at most six processes on its card).  Everything but the transport
 of the collectives is the code the eight processes run: the sharded drivers with their per-step all-gather and all-reduces, the
 row-block Gram matvec (16 384 rows: 8 column splits that coincide with the 8 shards), the row-block gradient sweep, the fused
 reduction of the estimate.  Prints one JSON line: the 8-rank result, the single-rank result of the same probes, their
@@ -16,10 +16,13 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "experiments-lanczos-adjoints_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from matfree_extensions.distributed import LocalWorld, slq_value_and_grad  # noqa: E402
+from _local_world import LocalWorld  # noqa: E402
+
+from matfree_extensions.distributed import slq_value_and_grad  # noqa: E402
 from matfree_extensions.util import gp_util  # noqa: E402
 
 ap = argparse.ArgumentParser()
