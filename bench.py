@@ -379,6 +379,11 @@ def main(argv=None):
             traffic_source = f"profiles/traffic.json @ {tj.get('commit', 'unknown commit')} ({tj.get('command', 'command not recorded')}); read from the file, not measured in this run"
         mean, std, grads = out
         batch = count * k
+        if layout.native:
+            collectives = (f"libmfx -> RCCL (native, {layout.comm.gather} gather); ranks in the communicator libmfx itself holds "
+                           f"(ncclCommCount) = {rccl_view[0]}")
+        else:
+            collectives = "host callbacks" if layout.comm is not None else "none"
         line = {
             "metric": "slq_logdet_value_and_grad_throughput",
             "value": value,
@@ -400,7 +405,7 @@ def main(argv=None):
                 "N": n, "d": d, "krylov_depth": k, "probes_total": p_total, "probes_on_this_rank": count,
                 "rows_on_this_rank": rows_local,
                 "parallelism": f"{layout.describe()}; world size seen by rank 0 (torch.distributed) = {dist.get_world_size() if world > 1 else 1}; "
-                               f"row-group collectives: {('libmfx -> RCCL (native, ' + layout.comm.gather + ' gather); ranks in libmfx's own communicator (ncclCommCount) = ' + str(rccl_view[0])) if layout.native else ('host callbacks' if layout.comm is not None else 'none')}",
+                               f"row-group collectives: {collectives}",
                 "rccl_comm_ranks": rccl_view[0] if rccl_view else None,
                 "gram_precision": args.precision, "kernel": args.kernel,
             },

@@ -81,6 +81,17 @@ def main():
     same3 = torch.equal(v1, v3) and all(torch.equal(a, b) for a, b in zip(g1, g3)) and pcomm.self_test()
     print("native communicator, packed gather: bit-identical to the callback path:", same3)
     ok = ok and same3
+    # what RCCL itself reports for libmfx's communicator (ncclCommCount / ncclCommUserRank: the figure bench.py prints next to
+    # torch.distributed's world size), and the switch between the gather legs on a live communicator (bench.py times both legs of one group)
+    counted = pcomm.rccl_count() == (1, 0)
+    pcomm.set_gather("grouped")
+    v4, g4 = run(RowShardedOp(op, pcomm))
+    pcomm.set_gather("packed")
+    v5, g5 = run(RowShardedOp(op, pcomm))
+    torch.cuda.synchronize()
+    switched = torch.equal(v1, v4) and torch.equal(v1, v5) and all(torch.equal(a, b) for a, b in zip(g1, g4)) and pcomm.gather == "packed"
+    print("native communicator: ranks / rank as RCCL reports them:", pcomm.rccl_count(), "; gather legs switched on the live communicator:", switched)
+    ok = ok and counted and switched
     pcomm.close()
     # what Layout does by default on an RCCL group: native communicator after an agreed availability check and self-test; when the
     # self-test (here: made to) fails on a rank, ALL ranks take the torch.distributed callbacks, with a warning
