@@ -211,3 +211,26 @@ def test_host_side_of_the_c_abi_under_address_and_ub_sanitizers():
                            cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert child.returncode == 0 and "4 passed" in child.stdout, child.stdout[-2000:] + child.stderr[-3000:]
     assert "ERROR: AddressSanitizer" not in child.stderr and "runtime error:" not in child.stderr, child.stderr[-3000:]
+
+
+def test_traffic_file_is_not_older_than_the_kernels_it_describes():
+    """profiles/traffic.json feeds `roofline.traffic` of the bench line (read from the file, not measured in the run): it must name
+    the commit and the command it was collected on, at the config-4 batch, and that commit must contain the last change to the
+    kernels it describes -- round 4 shipped a file collected at --k 3 on an intermediate build that still spilled (658 MB of writes)."""
+    import json
+    import shutil
+    import subprocess
+
+    tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    assert tj.get("krylov_depth") == 40 and "--k 40" in tj.get("command", ""), "collect with tools/prof_traffic.sh (K = 40)"
+    assert tj["k_rbf_mfma_grad_h_WRITE_SIZE_KB"] < 16 * 1024, "the gradient GEMM writes its partial sums only: a spilling build?"
+    assert tj["k_rbf_mfma_grad_h_launches_FETCH_SIZE"] >= 1 and tj["k_rbf_fat_apply_launches_FETCH_SIZE"] >= 80
+    if not (shutil.which("git") and os.path.isdir(os.path.join(ROOT, ".git"))):
+        pytest.skip("no git history here (the GPU box): the commit check runs in the development container")
+    git = lambda *a: subprocess.run(["git", "-C", ROOT, *a], capture_output=True, text=True)  # noqa: E731
+    csrc = "experiments-lanczos-adjoints_amd/csrc/"
+    last = git("log", "-1", "--format=%H", "--", csrc + "mfx_rbf_fat.hip", csrc + "mfx_rbf_mfma.hip", csrc + "mfx_rbf_common.h").stdout.strip()
+    assert last, "no history for the kernels"
+    assert git("cat-file", "-e", tj["commit"] + "^{commit}").returncode == 0, f"traffic.json names an unknown commit {tj['commit']!r}"
+    assert git("merge-base", "--is-ancestor", last, tj["commit"]).returncode == 0, (
+        f"profiles/traffic.json was collected at {tj['commit']}, before the last change to the Gram kernels ({last[:7]}): re-run tools/prof_traffic.sh")
