@@ -217,7 +217,9 @@ __device__ __forceinline__ double block_sum16(const floatx4& c, int rowlabel0, i
   return (double)t * (double)(wblk(rowlabel0 >> 5) * wblk(collabel0 >> 5) * wlow(l15));
 }
 // VAR: 0 as built into the product; 1 column blocks outer; 2 no s_setprio; 3 products grouped (all hh, all hl, all lh);
-//      timing diagnostics with WRONG sums: 4 no LDS-DMA in the loop, 5 no fragment reads in the loop, 6 neither, 7 neither and no barriers
+//      timing diagnostics with WRONG sums: 4 no LDS-DMA in the loop, 5 no fragment reads in the loop, 6 neither, 7 neither and no barriers;
+//      8 / 9 (round 5, on VAR 2's loop): only 6 / 7 of a wave's 8 LDS-DMA pieces per stage -- the L2 -> LDS bytes per flop of a 3-byte operand
+//      (f16 hi + 8-bit lo: 3/4) and, bracketing it from above, of a 256 x 384 workgroup tile (5/6 of the 256 x 256 tile's; 7/8 here)
 template <int VAR, int AUX = 0>
 __global__ __launch_bounds__(512, 1) void k_v3(Args g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -248,6 +250,8 @@ __global__ __launch_bounds__(512, 1) void k_v3(Args g) {
   auto issue_stage = [&](uint32_t l_off, uint32_t r_off, int slot) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
+      if (VAR == 8 && (i == 3 || i == 7)) continue;  // 3/4 of the stream (the lo images at half size)
+      if (VAR == 9 && i == 7) continue;              // 7/8 of the stream
       const int arr = i >> 1, hi2 = i & 1;
       const uint32_t so = arr < 2 ? l_off + (hi2 ? kb2L : 0u) : r_off + (hi2 ? kb2R : 0u);
       glds16<AUX>(gbase[arr] + (so + lane16), smem + slot * kSlot3 + ((arr * 4 + 2 * hi2 + kb0) * 256 + chunk * 64) * 16);
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(512, 1) void k_v3(Args g) {
       if (wid >= 4) __builtin_amdgcn_s_waitcnt(0x0F70);  // upper half: my pieces of stage st + 1 before the barrier the lower half reads it behind
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (VAR != 7) __builtin_amdgcn_s_barrier();  // B2
-      if constexpr (VAR != 2) __builtin_amdgcn_s_setprio(1);
+      if constexpr (VAR != 2 && VAR < 8) __builtin_amdgcn_s_setprio(1);
       if constexpr (VAR == 1) {
 #pragma unroll
         for (int b = 0; b < 8; ++b)
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(512, 1) void k_v3(Args g) {
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
           }
       }
-      if constexpr (VAR != 2) __builtin_amdgcn_s_setprio(0);
+      if constexpr (VAR != 2 && VAR < 8) __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (wid < 4) __builtin_amdgcn_s_barrier();
@@ -565,9 +569,9 @@ int main(int argc, char** argv) {
   const int tiles_per_block = (int)(ntj / (kSplit * kSub));
   const dim3 grid(kSplit, (unsigned)(nti * kSub));
   const int64_t nwg = (int64_t)grid.x * grid.y;
-  double* out[17];
+  double* out[19];
   long long* stamps;
-  for (int v = 0; v < 17; ++v) CK(hipMalloc(&out[v], nwg * 8 * tiles_per_block));
+  for (int v = 0; v < 19; ++v) CK(hipMalloc(&out[v], nwg * 8 * tiles_per_block));
   CK(hipMalloc(&stamps, nwg * 16 * tiles_per_block));
   Args a{Lh, Ll, Rh, Rl, rows, cols, nkb, tiles_per_block, 0, nullptr, stamps};
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_v0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmemV0)));
@@ -576,19 +580,20 @@ int main(int argc, char** argv) {
 #define V3ATTR(V) CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_v3<V>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kSlot3))
 #define V3ATTRA(V, A) CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_v3<V, A>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kSlot3))
   V3ATTRA(2, 1); V3ATTRA(2, 2); V3ATTRA(2, 16); V3ATTRA(2, 3);
-  V3ATTR(0); V3ATTR(1); V3ATTR(2); V3ATTR(3); V3ATTR(4); V3ATTR(5); V3ATTR(6); V3ATTR(7);
+  V3ATTR(0); V3ATTR(1); V3ATTR(2); V3ATTR(3); V3ATTR(4); V3ATTR(5); V3ATTR(6); V3ATTR(7); V3ATTR(8); V3ATTR(9);
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const double mfma_cycles_per_simd_per_tile = (double)(nkb / 2) * 48.0 * 32.0;  // both layouts: 48 MFMAs per SIMD and 16-row stage
-  const char* names[16] = {"V0 round-3 loop (32x32x16, 8 waves, ping-pong)", "V1 fat waves, LDS-DMA", "V2 fat waves, register staging",
+  const char* names[18] = {"V0 round-3 loop (32x32x16, 8 waves, ping-pong)", "V1 fat waves, LDS-DMA", "V2 fat waves, register staging",
                            "V3 as V0 on 16x16x32 (K = 32 stages)", "V3.1 column blocks outer", "V3.2 no s_setprio", "V3.3 products grouped",
                            "V3.4 [diag] no LDS-DMA", "V3.5 [diag] no fragment reads", "V3.6 [diag] neither", "V3.7 [diag] neither, no barriers",
-                           "V3.2 + sc0 loads", "V3.2 + nt loads", "V3.2 + sc1 loads", "V3.2 + sc0 nt loads", "V3.2 chunk-major, one tile per workgroup"};
+                           "V3.2 + sc0 loads", "V3.2 + nt loads", "V3.2 + sc1 loads", "V3.2 + sc0 nt loads", "V3.2 chunk-major, one tile per workgroup",
+                           "V3.8 [diag] 3/4 of the L2->LDS stream (3-byte operand)", "V3.9 [diag] 7/8 of the stream (~ 256 x 384 tile: 5/6)"};
   const unsigned vmask = argc > 5 ? (unsigned)strtoul(argv[5], nullptr, 0) : 0xFu;
   std::vector<double> ref, cur(nwg);
   std::vector<long long> st(2 * nwg);
   for (int rep = 0; rep < reps; ++rep)
-    for (int v = 0; v < 16; ++v) {
+    for (int v = 0; v < 18; ++v) {
       if (!((vmask >> v) & 1)) continue;
       a.out = out[v];
       const int64_t nwg_v = v == 15 ? nwg * tiles_per_block : nwg;
@@ -609,6 +614,8 @@ int main(int argc, char** argv) {
       else if (v == 12) k_v3<2, 2><<<grid, 512, 2 * kSlot3>>>(a);
       else if (v == 13) k_v3<2, 16><<<grid, 512, 2 * kSlot3>>>(a);
       else if (v == 14) k_v3<2, 3><<<grid, 512, 2 * kSlot3>>>(a);
+      else if (v == 16) k_v3<8><<<grid, 512, 2 * kSlot3>>>(a);
+      else if (v == 17) k_v3<9><<<grid, 512, 2 * kSlot3>>>(a);
       else {
         a.chunk_major = 1;
         k_v3<2><<<dim3(grid.x, grid.y * tiles_per_block), 512, 2 * kSlot3>>>(a);
