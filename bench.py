@@ -339,15 +339,26 @@ def main(argv=None):
             _lib.timing_reset()
             return {"ms_per_step": 1e3 * t / 2, "allgather_incl_pack_unpack": g_ms}
 
+        # (a leg that fails the same way on every rank -- a Python-level error -- is recorded and skipped: the headline above is already
+        #  measured and must survive it; a failure inside a collective cannot be survived by anything)
+        def try_leg(name, comm_obj):
+            try:
+                gather_legs[name] = leg(comm_obj)
+            except Exception as exc:  # noqa: BLE001
+                gather_legs[name] = {"error": f"{type(exc).__name__}: {exc}"}
+
         gather_legs = {}
         if layout.native:
-            rccl_view = layout.comm.rccl_count()  # (ranks, rank) from ncclCommCount / ncclCommUserRank: RCCL's own view of the row group
+            try:
+                rccl_view = layout.comm.rccl_count()  # (ranks, rank) from ncclCommCount / ncclCommUserRank: RCCL's own view of the row group
+            except Exception as exc:  # noqa: BLE001
+                rccl_view = (f"unavailable ({exc})", None)
             headline = layout.comm.gather
             for mode_name in ("packed", "grouped"):
                 layout.comm.set_gather(mode_name)
-                gather_legs["native_" + mode_name] = leg(layout.comm)
+                try_leg("native_" + mode_name, layout.comm)
             layout.comm.set_gather(headline)
-        gather_legs["torch_distributed_callbacks"] = leg(RowComm(n, layout.comm.group))
+        try_leg("torch_distributed_callbacks", RowComm(n, layout.comm.group))
 
     modes = {args.precision: 1e3 * elapsed / args.steps}
     if not args.no_modes:

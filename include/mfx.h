@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MFX_VERSION 200
+#define MFX_VERSION 201 /* 201: + mfx_comm_rccl_count */
 
 enum { MFX_F32 = 0, MFX_F64 = 1 };
 enum { MFX_OP_DENSE = 0, MFX_OP_CSR = 1, MFX_OP_RBF = 2, MFX_OP_CALLBACK = 3 };

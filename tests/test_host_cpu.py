@@ -22,7 +22,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.mfx_version() == 200
+    assert lib.mfx_version() == 201
     assert lib.mfx_last_error() is not None
 
 
