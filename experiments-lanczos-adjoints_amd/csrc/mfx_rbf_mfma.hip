@@ -60,12 +60,11 @@ __device__ __forceinline__ void grad_weights(int kind, float dist, float& kv, fl
 // monotone, so clamping the result equals clamping the argument (the reference clamps the squared
 // distance at 0, util/gp_util.py:173).  fp32 MFMA shares the FP32 lanes with the VALU on gfx950
 // (measured: removing the min/exp shortens the kernel by exactly their issue cycles), so every VALU
-// instruction per kernel entry is paid in full.  s_nop 1 = the VALU-write -> MFMA-operand wait states.
-__device__ __forceinline__ float exp2_clamped(float x) {
-  float r;
-  asm("v_exp_f32_e64 %0, %1 clamp\n\ts_nop 1" : "=v"(r) : "v"(x));
-  return r;
-}
+// instruction per kernel entry is paid in full.  Written so that the COMPILER emits the instruction (fmed3(x, 0, 1) folds into the
+// clamp modifier of v_exp_f32): x is an MFMA result and the result feeds an MFMA operand, and the wait states on both sides are the
+// hazard recogniser's job -- it does not look inside inline asm (rounds 1-4 had asm("v_exp_f32_e64 ... clamp; s_nop 1") here, which
+// covered the second hazard by hand and the first one not at all; see the register epilogue of k_rbf_mfma_grad_h for what that cost).
+__device__ __forceinline__ float exp2_clamped(float x) { return __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(x), 0.f, 1.f); }
 
 template <int DPAD, int NB, int kTJ>
 struct RbfTile {
@@ -1627,8 +1626,13 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
                 t = on ? 0.f : t;
                 gn += on ? s_ij : 0.f;
               }
-              float kv;
-              asm("v_exp_f32_e64 %0, %1 clamp" : "=v"(kv) : "v"(t));
+              // exp2 with the clamp modifier, as an instruction the COMPILER emits (fmed3(x, 0, 1) folds into v_exp_f32 ... clamp): t comes
+              // straight out of an MFMA, and the wait states between an MFMA's write and a VALU read are inserted by the compiler's hazard
+              // recogniser -- which does not look inside inline asm.  Round 4 had this as asm("v_exp_f32_e64 ... clamp"): with the
+              // 2-MFMA distance chain of d <= 4 it read the accumulator before the MFMA had written it (S o dK off by O(1) for every
+              // non-ARD RBF operator with d = 2 .. 4; found by tools/fuzz_matvec.py in round 5), with the 3-MFMA chain of d = 5 .. 8
+              // the same read happened to land late enough.
+              const float kv = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(t), 0.f, 1.f);
               const float u = s_ij * kv;
               gs += u;
               gl = fmaf(u, t, gl);
