@@ -20,6 +20,7 @@ SWEEPS = [
     ("tools/fuzz_small.py", 100, 10),    # on-device eigen-solver + quadrature VJP
     ("tests/fuzz_krylov.py", 100, 2),    # Krylov drivers in fp64 against the oracle
     ("tests/fuzz_gp.py", 60, 6),         # partial Cholesky, preconditioner, (P)CG
+    ("tools/fuzz_pde.py", 25, 11),       # wave operator + expm_arnoldi against scipy expm, adjoint identity; Hutchinson against the trace
 ]
 
 
