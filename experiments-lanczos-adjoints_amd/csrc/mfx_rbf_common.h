@@ -1,4 +1,4 @@
-// Pieces shared by the matrix-core RBF / Matern Gram kernels (mfx_rbf_mfma.hip, mfx_rbf_pc.hip): vector types, the kernel
+// Pieces shared by the matrix-core RBF / Matern Gram kernels (mfx_rbf_mfma.hip, mfx_rbf_fat.hip): vector types, the kernel
 // family's constants, the hi / lo f16 split, the LDS-DMA copy and the layout of the pre-packed tile images.
 #pragma once
 #include "mfx_internal.h"

@@ -2,7 +2,7 @@
 //   W[i][b] = s * sum_j K(x_i, x_j) V[j][b] + noise V[i][b]   (util/gp_util.py:160-176,225-226,536-541 of the reference)
 //
 // Why (round-3 measurements): with two waves per SIMD -- the same-program kernel k_rbf_mfma_apply_h3 as well as
-// the producer / consumer split of mfx_rbf_pc.hip -- the matrix pipe idles a third of the time: a wave's MFMA and another wave's
+// the producer / consumer split (round 3; tools/experiments/pc_matvec/) -- the matrix pipe idles a third of the time: a wave's MFMA and another wave's
 // VALU instruction compete for the SIMD's one vector issue port, and neither wave can see the other's schedule.  ONE wave that
 // owns the SIMD can: tools/valu_mix_bench.hip runs 14 MFMAs plus the whole exp / hi-lo split chain of a 32 x 32 block in 470
 // cycles (452 for the MFMAs alone) when every VALU instruction is placed behind a chosen MFMA so that
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256, 1) void k_rbf_fat_apply(const float* __restric
     //  straight into them, so neither takes part in the VGPR working set)
     // No wait states are inserted for an MFMA the compiler cannot see: the operands must be IN PLACE, not copied there (v_accvgpr_mov)
     // in front of the asm -- measured as wrong K blocks when the allocator kept bih scattered.  bih is pinned as tuples above, the
-    // column operand arrives by ds_read_b128 (s_waitcnt is data-flow, the compiler keeps that); tests/test_gpu_pc_matvec.py
+    // column operand arrives by ds_read_b128 (s_waitcnt is data-flow, the compiler keeps that); tests/test_gpu_matvec_kernels.py
     // checks every block position of a tile against the oracle.
     if (first) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(kd) : "a"(a), "a"(b));
     else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(kd) : "a"(a), "a"(b));

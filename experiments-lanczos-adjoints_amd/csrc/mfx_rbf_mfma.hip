@@ -1457,7 +1457,7 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
   const char* Llb = reinterpret_cast<const char*>(Ll);
   const char* Rhb = reinterpret_cast<const char*>(Rh);
   const char* Rlb = reinterpret_cast<const char*>(Rl);
-  auto issue_stage = [&](uint32_t l_off, uint32_t r_off, int slot, int hi_only) {  // hi_only: a one-product stage (k_stage_flags)
+  auto issue_stage = [&](uint32_t l_off, uint32_t r_off, int slot, int hi_only) {  // hi_only: a one-product stage (from n3 on: k_order_rows)
     glds16(Lhb + l_off, &sm.u.st.a_hi[slot][lkb][lcol][0]);
     glds16(Lhb + l_off + kb2_l, &sm.u.st.a_hi[slot][lkb + 2][lcol][0]);
     glds16(Rhb + r_off, &sm.u.st.b_hi[slot][rkb][rcol][0]);
@@ -1508,7 +1508,7 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
     //     flight) before it ARRIVES there -- A before its B1(st + 1), B before its B2(st);  stage 0 before the first barrier.
     __builtin_amdgcn_s_waitcnt(0x0F70);
     if (wid >= 4) __builtin_amdgcn_s_barrier();  // the half-stage offset of the upper half
-    // stages [0, n3): three products; stages [n3, nstage): hi hi only (k_stage_flags).  TWO loops, each with its own straight-line
+    // stages [0, n3): three products; stages [n3, nstage): hi hi only (n3 from k_order_rows).  TWO loops, each with its own straight-line
     // body: with the choice as a branch inside one loop the allocator spilled 140-190 registers around the joins
     auto run_stages = [&](auto one_c, int st_begin, int st_end) {
       constexpr bool ONE = decltype(one_c)::value;
