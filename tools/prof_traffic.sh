@@ -39,6 +39,10 @@ for tag in ("k_rbf_fat_apply", "k_rbf_mfma_grad_h"):
     if f"{tag}_FETCH_SIZE_KB" in res:
         res[f"{tag}_hbm_bytes_per_launch"] = (2 * res[f"{tag}_FETCH_SIZE_KB"] + res[f"{tag}_WRITE_SIZE_KB"]) * 1024
 res["algorithmic_hbm_bytes_per_launch"] = 131072 * 8 * 4 + 2 * 64 * 131072 * 4 + 131072 * 4 * 9
+res["k_rbf_mfma_grad_h_algorithmic_bytes_per_launch"] = 2 * 2 * (64 * int(k)) * 131072 * 2   # hi + lo f16 images of L and R
+res["k_rbf_mfma_grad_h_note"] = ("batch = 64 probes x k steps (2560 rows at k = 40: the config-4 sweep); memory-side bytes (2 x FETCH + WRITE) are ~90 x the operand "
+                                 "images: every 256 x 256 tile re-reads its operand panels through L2 (hit rate 81 %, profiles/r04g_*), the misses are served by the "
+                                 "Infinity Cache and, the 2.7 GB of images exceeding it, partly by HBM; WRITE_SIZE ~ 3 MB: the partial sums only, no scratch")
 json.dump(res, open(out + "/../traffic.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
