@@ -91,6 +91,12 @@ for case in range(cases):
         vt = T(v, True)
         Q, H, r, c = arnoldi.hessenberg(mv, kk, reortho=reortho)(vt, *tparams)
         Qo, Ho, ro, co = orc.arnoldi_forward(o, kk, v, *oparams, reortho=reortho)
+        sub = np.abs(np.diag(Ho, -1))
+        if sub.size and sub.min() < 1e-7 * np.abs(Ho).max():
+            # (the Krylov space has found an invariant subspace -- a kernel matrix of low numerical rank: what follows a beta ~ 0 is normalised
+            #  round-off in any implementation)
+            print(info + ": near-breakdown (beta ~ 0), skipped", flush=True)
+            continue
         check("hessenberg Q", N(Q), Qo, 5e-8, info + " " + reortho)
         check("hessenberg H", N(H), Ho, 1e-8, info + " " + reortho)
         if kk < n and np.abs(ro).max() > 1e-6 * np.abs(Ho).max():

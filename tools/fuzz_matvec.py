@@ -55,7 +55,7 @@ for case in range(cases):
         y, r, what = op32(V32, *p32).double(), ref, "all rows"
     err = ((y - r).abs().amax(dim=1) / ref.abs().amax(dim=1)).max().item()
     # (Matern: the fp64 operator adds eps of ITS dtype under the square root, util/gp_util.py:99,140 -- K_ii differs by sqrt(eps_fp32) by definition)
-    tol = (6e-4 if kernel == "matern12" else 1e-4 if kernel == "matern32" else 0.0) + (2e-4 if mode == "fp32" else 8e-5)
+    tol = (1e-3 if kernel == "matern12" else 2e-4 if kernel == "matern32" else 0.0) + (2e-4 if mode == "fp32" else 1e-4)
     flag = "" if err < tol else "   <-- FAIL"
     worst = max(worst, err / tol)
     if flag or case % 20 == 0:
