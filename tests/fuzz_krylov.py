@@ -108,6 +108,12 @@ for case in range(cases):
         check("hessenberg adjoint dv", N(grads[0]), dv_o, 1e-6, info + " " + reortho)
         for g, go in zip(grads[1:], dp_o):
             check("hessenberg adjoint dparam", N(g).reshape(np.shape(go)), go, 1e-6, info + " " + reortho)
+        # ---- the same forward pass on the fp32 kernels (other vector widths, other slice geometry): shallow depth, loose bar ----------------
+        if kk <= 8 and kind in ("dense_sym", "dense_nonsym", "csr"):
+            f32 = lambda t: t.detach().to(torch.float32)  # noqa: E731
+            Q32, H32, r32, c32 = arnoldi.hessenberg(mv, kk, reortho=reortho)(f32(vt), *[f32(t) for t in tparams])
+            check("hessenberg Q (fp32 kernels)", N(Q32.double()), Qo, 2e-4 * kk, info + " " + reortho)
+            check("hessenberg H (fp32 kernels)", N(H32.double()), Ho, 2e-4 * kk, info + " " + reortho)
         # ---- lanczos.tridiag on the symmetric operators -----------------------------------------------------------------------------
         if kind != "dense_nonsym":
             reortho = str(rng.choice(["full", "none"]))
