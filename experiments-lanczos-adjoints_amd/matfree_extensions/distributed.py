@@ -314,6 +314,8 @@ class NativeRowComm(RowComm):
         bandwidth figures are quoted for) or "grouped" (p all-gathers of nloc elements in one group launch, straight into the operator
         input: no copies, but p small operations) -- `include/mfx.h`, MFX_GATHER_*; default from $MFX_GATHER."""
         super().__init__(n, group)
+        if not getattr(self.transport, "torch_backed", False):
+            raise TypeError("the native RCCL communicator is created over a torch.distributed process group (its unique id travels through it)")
         lib = _lib.get()
         gather = gather or os.environ.get("MFX_GATHER", "packed")
         if gather not in self.GATHER:
@@ -330,8 +332,9 @@ class NativeRowComm(RowComm):
                 ok, why = False, str(exc)
         if self.world > 1:
             box = [(ok, why, bytes(uid.tolist()))]
-            src = dist.get_process_group_ranks(group)[0] if group is not None else 0
-            dist.broadcast_object_list(box, src=src, group=group)
+            pg = self.group  # (the torch.distributed process group behind `group`, also when a TorchGroup wrapper was passed)
+            src = dist.get_process_group_ranks(pg)[0] if pg is not None else 0
+            dist.broadcast_object_list(box, src=src, group=pg)
             ok, why, raw = box[0]
             uid = torch.tensor(list(raw), dtype=torch.uint8)
         if not ok:
