@@ -31,6 +31,8 @@ def apply_block(op, cparams, V, row0, nrows):
 worst = 0.0
 for case in range(cases):
     n = int(rng.choice([rng.integers(65, 700), rng.integers(700, 6000), rng.integers(6000, 30000)]))
+    if os.environ.get("FUZZ_LARGE"):  # a few cases at the headline's size class: unsplit sweeps with many chain folds, 2048 tiles
+        n = int(rng.integers(60000, 140000))
     d = int(rng.integers(1, 17))
     p = int(rng.choice([1, 2, 3, 7, 8, 16, 31, 32, 33, 47, 64, 65, 96, 100, 128, 130]))
     kernel = str(rng.choice(["rbf", "rbf", "matern32", "matern12"]))

@@ -18,6 +18,8 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 for case in range(cases):
     n = int(rng.choice([rng.integers(300, 2500), rng.integers(2500, 12000), rng.integers(12000, 40000)]))
+    if os.environ.get("FUZZ_LARGE"):  # the headline's size class (the fp64 leg takes ~10-40 s per case)
+        n = int(rng.integers(60000, 140000))
     d = int(rng.integers(1, 17))
     p = int(rng.choice([1, 3, 8, 16, 31, 33, 64, 65, 100, 130]))
     k = int(rng.integers(3, 25))
