@@ -6,6 +6,7 @@ dense RBF Gram matrix, n points in d = 8 dimensions, lengthscale 2, noise scaled
 the log-det mean and of its gradient (lengthscale, outputscale, noise) against the all-fp64 run of the same probes.
 
     python tools/experiments/precision_sources_emulation.py [n] [seeds]
+    python tools/experiments/precision_sources_emulation.py [n] [seeds] per-probe     (only the shipped arithmetic, error of every probe's own share)
 
 Self-contained on purpose (no import of oracle/ or of the package): a measurement script, not a checker.  Result (round 5, n = 8192):
 tools/experiments/precision_sources_emulation.log, DESIGN.md section 3.2.
@@ -110,7 +111,9 @@ def run(probes, R):
     beta_plus = H.copy()
     for b in range(P):
         beta_plus[b] -= np.diag(np.diag(H[b])) + np.diag(np.diag(H[b], -1), -1)
-    g_l = g_s = g_n = 0.0
+    g_l = np.zeros(P)
+    g_s = np.zeros(P)
+    g_n = np.zeros(P)
     for idx in range(k - 1, -1, -1):
         m = ps_mask[idx]
         Pm = Q * m[None, :, None]
@@ -122,9 +125,9 @@ def run(probes, R):
         z = rz(Kl + noise * lam_v)
         # parameter gradients of lam^T A(theta) q  (the deferred sweep): exact arithmetic on the STORED lam and q
         lg, qg = rgemm(lam_v), rgemm(q)
-        g_s += np.einsum("pn,pn->", lg @ K, qg) / sigma
-        g_n += np.einsum("pn,pn->", lam_v, q)
-        g_l += np.einsum("pn,pn->", lg @ G_l, qg)
+        g_s += np.einsum("pn,pn->p", lg @ K, qg) / sigma
+        g_n += np.einsum("pn,pn->p", lam_v, q)
+        g_l += np.einsum("pn,pn->p", lg @ G_l, qg)
         zq = rh(np.einsum("pn,pjn->pj", z, Q))
         Gam[:, idx, :] = rg(lower[idx][None, :] * (Pi_gamma[:, idx, :] - zq))
         Lam[:, idx] = lam_v
@@ -134,7 +137,10 @@ def run(probes, R):
     s2 = scale**2
     # (the scale^2 weights: all probes have the same norm sqrt(n))
     value = np.mean(s2 * vals)
-    grad = np.array([g_l, g_s, g_n]) * s2[0] / P
+    per_probe = np.stack([g_l, g_s, g_n]) * s2[0]  # (3, P): every probe's own gradient
+    grad = per_probe.sum(1) / P
+    if R.get("per_probe"):
+        return value, grad, per_probe
     return value, grad
 
 
@@ -155,6 +161,18 @@ configs = [
     ("shipped: all fp32 + 22-bit operands", dict(w=f32, q=f32, h=f32, len=f32, lam=f32, z=f32, g=f32, opf=True, opa=True, gemm=True)),
     ("proposed: vectors fp32 + 22-bit operands, small quantities fp64", dict(w=f32, q=f32, lam=f32, z=f32, opf=True, opa=True, gemm=True)),
 ]
+if len(sys.argv) > 3 and sys.argv[3] == "per-probe":
+    shipped = dict(configs[-2][1], per_probe=True)
+    print(f"n = {n}, cond ~ {0.2 * n / noise:.2e}, shipped arithmetic (all fp32 + 22-bit operands): error of each probe's OWN gradient, relative to the mean gradient")
+    print(f"{'seed':>4} {'set: d l':>9} {'d s':>9} {'d noise':>9} | per-probe |d l| error: {'median':>9} {'90 %':>9} {'max':>9} {'(probe)':>7} | cond * eps(fp32) = {0.2 * n / noise * 6e-8:.1e}")
+    for seed in seeds:
+        probes = np.where(np.random.default_rng(1000 + seed).random((p, n)) < 0.5, -1.0, 1.0)
+        v0, g0, pp0 = run(probes, dict(per_probe=True))
+        v, g, pp = run(probes, shipped)
+        e = np.abs(g - g0) / np.abs(g0)
+        pe = np.abs(pp[0] - pp0[0]) / np.abs(g0[0])
+        print(f"{seed:>4} {e[0]:9.2e} {e[1]:9.2e} {e[2]:9.2e} | {'':>24} {np.median(pe):9.2e} {np.quantile(pe, 0.9):9.2e} {pe.max():9.2e} {int(pe.argmax()):>7}", flush=True)
+    sys.exit(0)
 print(f"n = {n}, d = {d}, k = {k}, {p} probes, noise = {noise:.5f} (cond ~ {0.2 * n / noise:.2e}); relative errors against the all-fp64 run")
 print(f"{'rounded to fp32':<52} {'seed':>4} {'value':>9} {'d l':>9} {'d s':>9} {'d noise':>9}")
 for seed in seeds:
