@@ -82,7 +82,8 @@ def rows_per_rank(n: int, world_size: int) -> int:
     nloc = -(-n // world_size)
     nloc = -(-nloc // 64) * 64
     if (world_size - 1) * nloc >= n:
-        raise ValueError(f"n = {n} is too small to give each of {world_size} ranks at least one 64-aligned row block")
+        raise ValueError(f"n = {n} cannot be laid out on {world_size} ranks: equal 64-aligned shards are {nloc} rows, which leaves the last "
+                         f"{world_size - -(-n // nloc)} rank(s) without rows -- {-(-n // nloc)} ranks have one")
     return nloc
 
 

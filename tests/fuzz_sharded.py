@@ -12,7 +12,7 @@ for q in (ROOT, os.path.join(ROOT, "experiments-lanczos-adjoints_amd"), os.path.
     if q not in sys.path:
         sys.path.insert(0, q)
 from _local_world import LocalWorld  # noqa: E402
-from matfree_extensions.distributed import slq_value_and_grad  # noqa: E402
+from matfree_extensions.distributed import rows_per_rank, slq_value_and_grad  # noqa: E402
 from matfree_extensions.util import gp_util  # noqa: E402
 
 dev = torch.device("cuda:0")
@@ -22,6 +22,15 @@ bad = 0
 for case in range(cases):
     ranks = int(rng.choice([2, 3, 4, 5, 8]))
     n = int(rng.integers(ranks * 64 + 1, 9000))
+    # (equal 64-aligned shards: some n leave the last rank without rows -- e.g. 858 rows on 8 ranks: shards of 128, 7 * 128 > 858 -- and are
+    #  refused with a ValueError, checked here; the sweep itself runs on a layout that exists)
+    try:
+        rows_per_rank(n, ranks)
+    except ValueError:
+        if (ranks - 1) * (-(-(-(-n // ranks)) // 64) * 64) < n:
+            bad += 1
+            print(f"FAIL rows_per_rank refused a layout that exists: n={n} ranks={ranks}", flush=True)
+        n = ranks * (-(-n // (64 * ranks)) * 64) - int(rng.integers(0, 64))  # the next n whose last shard is not empty
     d = int(rng.integers(1, 17))
     p = int(rng.choice([1, 4, 8, 16, 33, 64, 70]))
     k = int(rng.integers(2, 14))

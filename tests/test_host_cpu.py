@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from matfree_extensions import _lib, arnoldi, hutchinson, lanczos
-from matfree_extensions.distributed import shard_probes
+from matfree_extensions.distributed import rows_per_rank, shard_probes
 from matfree_extensions.operators import CsrOp, DenseOp, RbfGramOp, as_operator
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -147,6 +147,23 @@ def _kernel_metadata():
                 num = lambda key: int(re.search(r"\." + key + r":\s+(\d+)", block).group(1))  # noqa: E731
                 out[name.group(1)] = (num("vgpr_count"), num("vgpr_spill_count"), num("private_segment_fixed_size"))
     return out
+
+
+def test_row_layout_is_equal_64_aligned_shards_or_a_stated_refusal():
+    """rows_per_rank: the same shard length on every rank, a multiple of 64, rows on EVERY rank -- an n that equal shards cannot cover that
+    way (858 rows on 8 ranks: shards of 128 leave the eighth rank empty) is refused with the rank count that has a layout in the message."""
+    assert rows_per_rank(131072, 8) == 16384 and rows_per_rank(45730, 8) == 5760 and rows_per_rank(65, 2) == 64
+    for n in range(65, 3000, 7):
+        for world in (2, 3, 5, 8):
+            try:
+                nloc = rows_per_rank(n, world)
+            except ValueError as exc:
+                fewer = int(re.search(r"(\d+) ranks have one", str(exc)).group(1))
+                assert 1 <= fewer < world and (fewer == 1 or rows_per_rank(n, fewer) > 0)
+                continue
+            assert nloc % 64 == 0 and (world - 1) * nloc < n <= world * nloc
+    with pytest.raises(ValueError, match="leaves the last 1 rank"):
+        rows_per_rank(858, 8)
 
 
 def test_hot_kernels_scratch_budget_from_the_code_object():
