@@ -11,22 +11,32 @@ namespace mfx {
 // Implicit-shift QL on (d, e) with accumulation of the rotations into Z (EISPACK tql2 scheme).
 // The scalar recurrence is evaluated redundantly by all 64 lanes (wave-uniform, LDS broadcast reads);
 // the O(k) row updates of Z per rotation are spread over the lanes (lane = row of Z).
-template <typename T>
+//
+// DEEP (k > 120, fp64 only): k (k | 1) doubles of Z no longer fit the 160 KB of LDS -- the rotations are accumulated in the caller's evecs
+// itself (same layout, Z[row][col], leading dimension k; a lane reads back only what it wrote: program order is enough), d and e stay in LDS.
+// The reference's SuiteSparse sweeps go to depth 150 (benchmark.py:21,83; plot_quadrant.py:22).
+template <typename T, bool DEEP>
 __global__ __launch_bounds__(64) void k_tridiag_eigh(const T* __restrict__ alpha, const T* __restrict__ beta,
                                                      int64_t ldbeta, int k, T* __restrict__ evals,
                                                      T* __restrict__ evecs) {
+  static_assert(!DEEP || sizeof(T) == 8, "the deep variant accumulates in the fp64 output");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* d = reinterpret_cast<double*>(smem_raw);
   double* e = d + k;
-  double* Z = e + k;
-  const int ldz = k | 1;  // odd leading dimension: conflict-free column access
   const int lane = threadIdx.x;
   const int64_t b = blockIdx.x;
+  double* Z = DEEP ? reinterpret_cast<double*>(evecs) + b * k * k : e + k;
+  const int ldz = DEEP ? k : (k | 1);  // LDS: odd leading dimension, conflict-free column access
   for (int i = lane; i < k; i += 64) {
     d[i] = (double)alpha[b * k + i];
     e[i] = (i < k - 1) ? (double)beta[b * ldbeta + i] : 0.0;
   }
-  for (int t = lane; t < k * k; t += 64) Z[(t / k) * ldz + (t % k)] = (t / k == t % k) ? 1.0 : 0.0;
+  if (DEEP) {  // by the lane that will rotate the row
+    for (int row = lane; row < k; row += 64)
+      for (int col = 0; col < k; ++col) Z[row * ldz + col] = row == col ? 1.0 : 0.0;
+  } else {
+    for (int t = lane; t < k * k; t += 64) Z[(t / k) * ldz + (t % k)] = (t / k == t % k) ? 1.0 : 0.0;
+  }
   __syncthreads();
   const double eps = 2.220446049250313e-16;
   bool converged = true;  // wave-uniform
@@ -79,12 +89,15 @@ __global__ __launch_bounds__(64) void k_tridiag_eigh(const T* __restrict__ alpha
   }
   __syncthreads();
   for (int i = lane; i < k; i += 64) evals[b * k + i] = converged ? (T)d[i] : (T)NAN;
-  for (int t = lane; t < k * k; t += 64) evecs[b * k * k + t] = (T)Z[(t / k) * ldz + (t % k)];
+  if (!DEEP)
+    for (int t = lane; t < k * k; t += 64) evecs[b * k * k + t] = (T)Z[(t / k) * ldz + (t % k)];
 }
 
 // G = gout * U (F o u0 u0^T) U^T with F the divided differences of f at the eigenvalues;
 // dalpha_i = G_ii, dbeta_i = 2 G_{i,i+1}.
-template <typename T>
+// DEEP (k > 120): M = F o u0 u0^T is not stored (k^2 doubles of LDS) but evaluated where it is used -- k^3 divided differences per probe
+// instead of k^2, irrelevant next to the Krylov passes at such depths; LDS holds lam, f, f' and u0 (4 k doubles).
+template <typename T, bool DEEP>
 __global__ __launch_bounds__(64) void k_quadform_bwd(const T* __restrict__ evals, const T* __restrict__ evecs,
                                                      const T* __restrict__ fvals, const T* __restrict__ dfvals,
                                                      const T* __restrict__ gout, int k, T* __restrict__ dalpha,
@@ -100,16 +113,24 @@ __global__ __launch_bounds__(64) void k_quadform_bwd(const T* __restrict__ evals
   double lmax = 0.0;
   for (int a = 0; a < k; ++a) lmax = fmax(lmax, fabs((double)lam[a]));
   const double tol = (sizeof(T) == 4 ? 1e-6 : 1e-13) * lmax;
-  for (int t = lane; t < k * k; t += 64) {
-    const int a = t / k, c = t % k;
-    const double dl = (double)lam[a] - (double)lam[c];
-    double F;
-    if (a == c || fabs(dl) <= tol) {
-      F = 0.5 * ((double)df[a] + (double)df[c]);
-    } else {
-      F = ((double)f[a] - (double)f[c]) / dl;
+  auto entry = [&](int a, int c, double la, double lc, double fa, double fc, double dfa, double dfc, double ua, double uc) {
+    const double dl = la - lc;
+    const double F = (a == c || fabs(dl) <= tol) ? 0.5 * (dfa + dfc) : (fa - fc) / dl;
+    return F * ua * uc;  // U[0][a] U[0][c]
+  };
+  double *sl = M, *sf = M + k, *sd = M + 2 * k, *su = M + 3 * k;  // DEEP only
+  if (DEEP) {
+    for (int a = lane; a < k; a += 64) {
+      sl[a] = (double)lam[a];
+      sf[a] = (double)f[a];
+      sd[a] = (double)df[a];
+      su[a] = (double)U[a];
     }
-    M[t] = F * (double)U[a] * (double)U[c];  // U[0][a] U[0][c]
+  } else {
+    for (int t = lane; t < k * k; t += 64) {
+      const int a = t / k, c = t % k;
+      M[t] = entry(a, c, (double)lam[a], (double)lam[c], (double)f[a], (double)f[c], (double)df[a], (double)df[c], (double)U[a], (double)U[c]);
+    }
   }
   __syncthreads();
   const double go = (double)gout[b];
@@ -117,7 +138,11 @@ __global__ __launch_bounds__(64) void k_quadform_bwd(const T* __restrict__ evals
     double gii = 0.0, gi1 = 0.0;
     for (int a = 0; a < k; ++a) {
       double t = 0.0;
-      for (int c = 0; c < k; ++c) t += M[a * k + c] * (double)U[i * k + c];
+      if (DEEP) {
+        for (int c = 0; c < k; ++c) t += entry(a, c, sl[a], sl[c], sf[a], sf[c], sd[a], sd[c], su[a], su[c]) * (double)U[i * k + c];
+      } else {
+        for (int c = 0; c < k; ++c) t += M[a * k + c] * (double)U[i * k + c];
+      }
       // t = (M U_i)_a ; G_ij = sum_a U_ja t_a
       gii += (double)U[i * k + a] * t;
       if (i + 1 < k) gi1 += (double)U[(i + 1) * k + a] * t;
@@ -144,6 +169,9 @@ __global__ void k_rademacher(uint64_t seed, int64_t first_probe, int64_t n, T* _
   }
 }
 
+constexpr int kSmallLdsDepth = 120;   // up to here the k x k work matrices of the two kernels above live in LDS
+constexpr int kSmallMaxDepth = 2048;  // d, e (or lam, f, f', u0) still do: 4 k doubles
+
 template <typename F>
 static int allow_big_lds(F fn, size_t bytes) {
   if (bytes > 64 * 1024) {
@@ -163,17 +191,24 @@ int mfx_tridiag_eigh(const void* alpha, const void* beta, int64_t ldbeta, int64_
                      void* evals, void* evecs, void* stream) {
   MFX_REQUIRE(alpha && evals && evecs && (beta || k == 1), MFX_ERR_INVALID, "null argument");
   MFX_REQUIRE(p >= 1 && k >= 1, MFX_ERR_INVALID, "p, k must be positive");
-  MFX_REQUIRE(k <= 120, MFX_ERR_UNSUPPORTED, "tridiagonal eigensolver supports k <= 120 (got %lld)", (long long)k);
+  const bool deep = k > kSmallLdsDepth;
+  MFX_REQUIRE(!deep || dtype == MFX_F64, MFX_ERR_UNSUPPORTED,
+              "tridiagonal eigensolver: k > %d needs fp64 buffers (the rotations are accumulated in evecs itself; got k = %lld in fp32)",
+              kSmallLdsDepth, (long long)k);
+  MFX_REQUIRE(k <= kSmallMaxDepth, MFX_ERR_UNSUPPORTED, "tridiagonal eigensolver supports k <= %d (got %lld)", kSmallMaxDepth, (long long)k);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const size_t sh = (size_t)(2 * k + k * (k | 1)) * sizeof(double);
+  const size_t sh = (size_t)(2 * k + (deep ? 0 : k * (k | 1))) * sizeof(double);
   if (dtype == MFX_F32) {
-    MFX_TRY(allow_big_lds(k_tridiag_eigh<float>, sh));
-    k_tridiag_eigh<float><<<(unsigned)p, 64, sh, s>>>((const float*)alpha, (const float*)beta, ldbeta, (int)k,
-                                                      (float*)evals, (float*)evecs);
+    MFX_TRY(allow_big_lds(k_tridiag_eigh<float, false>, sh));
+    k_tridiag_eigh<float, false><<<(unsigned)p, 64, sh, s>>>((const float*)alpha, (const float*)beta, ldbeta, (int)k,
+                                                             (float*)evals, (float*)evecs);
+  } else if (dtype == MFX_F64 && deep) {
+    k_tridiag_eigh<double, true><<<(unsigned)p, 64, sh, s>>>((const double*)alpha, (const double*)beta, ldbeta, (int)k,
+                                                             (double*)evals, (double*)evecs);
   } else if (dtype == MFX_F64) {
-    MFX_TRY(allow_big_lds(k_tridiag_eigh<double>, sh));
-    k_tridiag_eigh<double><<<(unsigned)p, 64, sh, s>>>((const double*)alpha, (const double*)beta, ldbeta, (int)k,
-                                                       (double*)evals, (double*)evecs);
+    MFX_TRY(allow_big_lds(k_tridiag_eigh<double, false>, sh));
+    k_tridiag_eigh<double, false><<<(unsigned)p, 64, sh, s>>>((const double*)alpha, (const double*)beta, ldbeta, (int)k,
+                                                              (double*)evals, (double*)evecs);
   } else {
     set_error("unsupported dtype %d", dtype);
     return MFX_ERR_UNSUPPORTED;
@@ -186,24 +221,32 @@ int mfx_slq_quadform_bwd(const void* evals, const void* evecs, const void* fvals
                          const void* gout, int64_t p, int64_t k, int dtype, void* dalpha, void* dbeta,
                          int64_t lddbeta, void* stream) {
   MFX_REQUIRE(evals && evecs && fvals && dfvals && gout && dalpha && (dbeta || k == 1), MFX_ERR_INVALID, "null argument");
-  MFX_REQUIRE(k >= 1 && k <= 120, MFX_ERR_UNSUPPORTED, "quadform backward supports k <= 120");
+  MFX_REQUIRE(k >= 1 && k <= kSmallMaxDepth, MFX_ERR_UNSUPPORTED, "quadform backward supports k <= %d (got %lld)", kSmallMaxDepth, (long long)k);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const size_t sh = (size_t)k * k * sizeof(double);
+  const bool deep = k > kSmallLdsDepth;
+  const size_t sh = (size_t)(deep ? 4 * k : k * k) * sizeof(double);
+#define MFX_QF_LAUNCH(T, DEEP)                                                                                                 \
+  k_quadform_bwd<T, DEEP><<<(unsigned)p, 64, sh, s>>>((const T*)evals, (const T*)evecs, (const T*)fvals, (const T*)dfvals,    \
+                                                      (const T*)gout, (int)k, (T*)dalpha, (T*)dbeta, lddbeta)
   if (dtype == MFX_F32) {
-    MFX_TRY(allow_big_lds(k_quadform_bwd<float>, sh));
-    k_quadform_bwd<float><<<(unsigned)p, 64, sh, s>>>((const float*)evals, (const float*)evecs, (const float*)fvals,
-                                                      (const float*)dfvals, (const float*)gout, (int)k,
-                                                      (float*)dalpha, (float*)dbeta, lddbeta);
+    if (deep) {
+      MFX_QF_LAUNCH(float, true);
+    } else {
+      MFX_TRY(allow_big_lds(k_quadform_bwd<float, false>, sh));
+      MFX_QF_LAUNCH(float, false);
+    }
   } else if (dtype == MFX_F64) {
-    MFX_TRY(allow_big_lds(k_quadform_bwd<double>, sh));
-    k_quadform_bwd<double><<<(unsigned)p, 64, sh, s>>>((const double*)evals, (const double*)evecs,
-                                                       (const double*)fvals, (const double*)dfvals,
-                                                       (const double*)gout, (int)k, (double*)dalpha, (double*)dbeta,
-                                                       lddbeta);
+    if (deep) {
+      MFX_QF_LAUNCH(double, true);
+    } else {
+      MFX_TRY(allow_big_lds(k_quadform_bwd<double, false>, sh));
+      MFX_QF_LAUNCH(double, false);
+    }
   } else {
     set_error("unsupported dtype %d", dtype);
     return MFX_ERR_UNSUPPORTED;
   }
+#undef MFX_QF_LAUNCH
   MFX_CHECK_LAUNCH();
   return MFX_OK;
 }

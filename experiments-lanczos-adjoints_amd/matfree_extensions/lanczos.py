@@ -263,11 +263,15 @@ class _QuadformFn(torch.autograd.Function):
         diag, off = diag.contiguous(), off.contiguous()
         p, k = diag.shape
         dt, dev = diag.dtype, diag.device
-        evals = torch.empty((p, k), dtype=dt, device=dev)
-        evecs = torch.empty((p, k, k), dtype=dt, device=dev)
-        _lib.check(lib.mfx_tridiag_eigh(_lib.ptr(diag), _lib.ptr(off) if k > 1 else None, max(k - 1, 1), p, k,
-                                        _lib.dtype_code(dt), _lib.ptr(evals), _lib.ptr(evecs),
+        # beyond depth 120 the eigensolver accumulates its rotations in the fp64 output itself (include/mfx.h): fp32 problems are cast
+        et = torch.float64 if k > 120 else dt
+        diag_e, off_e = diag.to(et), off.to(et)
+        evals = torch.empty((p, k), dtype=et, device=dev)
+        evecs = torch.empty((p, k, k), dtype=et, device=dev)
+        _lib.check(lib.mfx_tridiag_eigh(_lib.ptr(diag_e), _lib.ptr(off_e) if k > 1 else None, max(k - 1, 1), p, k,
+                                        _lib.dtype_code(et), _lib.ptr(evals), _lib.ptr(evecs),
                                         _lib.stream_ptr(dev)))
+        evals, evecs = evals.to(dt), evecs.to(dt)
         with torch.enable_grad():
             lam = evals.detach().requires_grad_(True)
             fx = matfun(lam)  # vmap(matfun)(eigvals), lanczos.py:58

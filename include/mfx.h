@@ -200,7 +200,9 @@ int mfx_lanczos_adjoint(const mfx_operator* op, int64_t n, int64_t k, int64_t p,
 
 /* jnp.linalg.eigh of the k x k tridiagonal (lanczos.py:48-53), batched: alpha (p, k),
  * beta (p, k-1 values, leading dimension ldbeta) -> evals (p, k) (unordered), evecs (p, k, k) with
- * evecs[b][i][a] = component i of eigenvector a.  fp64 arithmetic inside, k <= 120.  The call is asynchronous, so
+ * evecs[b][i][a] = component i of eigenvector a.  fp64 arithmetic inside.  k <= 120 in either dtype (work matrix in LDS);
+ * 120 < k <= 2048 with fp64 buffers only (the rotations are accumulated in evecs itself; MFX_ERR_UNSUPPORTED in fp32 -- the Python
+ * layer casts the k x k problem to fp64 there).  The call is asynchronous, so
  * a QL iteration that fails to converge (200 sweeps per eigenvalue) cannot be reported through the return code:
  * that probe's evals are set to NaN instead (never silently wrong numbers). */
 int mfx_tridiag_eigh(const void* alpha, const void* beta, int64_t ldbeta, int64_t p, int64_t k,
@@ -208,7 +210,8 @@ int mfx_tridiag_eigh(const void* alpha, const void* beta, int64_t ldbeta, int64_
 
 /* VJP of  value_b = sum_a evecs[b][0][a]^2 f(evals[b][a])  w.r.t. (alpha, beta) -- what autodiff
  * through eigh + vmap(matfun) + dot yields in lanczos.py:53-59, in divided-difference form.
- * fvals = f(evals), dfvals = f'(evals) (p, k); gout (p) upstream cotangent. */
+ * fvals = f(evals), dfvals = f'(evals) (p, k); gout (p) upstream cotangent.  k <= 2048 (beyond 120 the divided differences are
+ * evaluated where they are used instead of stored in LDS). */
 int mfx_slq_quadform_bwd(const void* evals, const void* evecs, const void* fvals,
                          const void* dfvals, const void* gout, int64_t p, int64_t k, int dtype,
                          void* dalpha, void* dbeta, int64_t lddbeta, void* stream);

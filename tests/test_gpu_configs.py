@@ -229,6 +229,89 @@ def test_c4_fp64_hip_rows_against_the_numpy_oracle_at_full_size():
             assert abs(a - b) <= 1e-10 * max(abs(b), abs(g_l), abs(g_s)), (row0, name, a, b)
 
 
+def test_beyond_the_stated_sizes_one_million_points():
+    """n = 1 000 003 (7.6 x config 4: n^2 = 1e12 kernel entries, 15 626 row blocks of 64 with a ragged last one, 2^31 crossed 465 times by
+    the flat entry index), d = 5, RBF with C4's hyper-parameters: nothing in the index arithmetic, the tile counts, the column splits or the
+    workspace carve may depend on n staying near 131 072.
+      (a) the fp64 HIP matvec (2 vectors) on three row blocks against NumPy fp64 slabs of the oracle, 1e-12;
+      (b) the default-mode matvec with 2 (pre-packed kernel), 8 (fat-wave kernel, <= 32 vectors) and 64 vectors (fat-wave, 64) against (a)'s
+          path -- relative to the largest output, 2e-5 (the stated per-matvec accuracy of the split arithmetic);
+      (c) the default-mode parameter sweep (batch 8) against the fp64 sweep, 2e-4 of the largest component."""
+    from matfree_extensions.operators import RbfGramOp
+
+    n, d = 1_000_003, 5
+    gen = torch.Generator().manual_seed(11)
+    X64 = torch.randn((n, d), generator=gen, dtype=torch.float32).double()
+    raw = (INV(2.0), INV(1.0), INV(0.1))
+    ls, s, noise = (orc.softplus(np.float64(r)) for r in raw)
+    V = torch.randn((64, n), generator=gen, dtype=torch.float32)
+    op64 = RbfGramOp(X64.to(DEV), noise_minval=0.0)
+    op32 = RbfGramOp(X64.float().to(DEV), noise_minval=0.0)  # the default mode
+    p64 = [torch.tensor(r, dtype=torch.float64, device=DEV) for r in raw]
+    p32 = [torch.tensor(r, dtype=torch.float32, device=DEV) for r in raw]
+    V64, V32 = V.double().to(DEV), V.to(DEV)
+    with torch.no_grad():
+        ref8 = op64(V64[:8], *p64)
+    Xn, Vn = X64.numpy(), V[:2].double().numpy()
+    for row0, nrows in [(0, 64), (524288 - 32, 64), (n - 35, 35)]:
+        rows = slice(row0, row0 + nrows)
+        K = orc.kernel_matrix("rbf", Xn[rows], Xn, ls, s)
+        want = Vn @ K.T + noise * Vn[:, rows]
+        got = ref8[:2, rows].cpu().numpy()
+        assert np.allclose(got, want, rtol=1e-12, atol=1e-12 * np.abs(want).max()), (row0, np.abs(got - want).max())
+    with torch.no_grad():
+        for p in (2, 8, 64):
+            y = op32(V32[:p], *p32).double()
+            q = min(p, 8)
+            err = ((y[:q] - ref8[:q]).abs().amax(dim=1) / ref8[:q].abs().amax(dim=1)).max().item()
+            assert err <= 2e-5, (p, err)
+            if p == 64:  # the other 56 columns: the operator is symmetric, <u, K v> = <v, K u>
+                a, b = (V64[8:36] * y[36:64]).sum().item(), (V64[36:64] * y[8:36]).sum().item()
+                assert abs(a - b) <= 1e-5 * max(abs(a), abs(b), float(n)), (a, b)
+    L = torch.randn((8, n), generator=gen, dtype=torch.float32).to(DEV)
+    pg32 = [t.clone().requires_grad_(True) for t in p32]
+    pg64 = [t.clone().requires_grad_(True) for t in p64]
+    g32 = torch.autograd.grad((L * op32(V32[:8], *pg32)).sum(), pg32)
+    g64 = torch.autograd.grad((L.double() * op64(V64[:8], *pg64)).sum(), pg64)
+    g32, g64 = np.array([t.item() for t in g32]), np.array([t.item() for t in g64])
+    assert np.all(np.abs(g32 - g64) <= 2e-4 * np.abs(g64).max()), (g32, g64)
+
+
+def test_krylov_kernels_with_more_than_2_to_31_basis_elements():
+    """64 probes x 40 basis vectors x 1 000 003 rows = 2.56e9 stored fp32 elements per basis (10 GB; the adjoint keeps as many again): every
+    (probe, column, row) offset of the Krylov kernels has to be 64-bit.  A cheap operator (CSR, 1-D Laplacian + 3 I, 3e6 stored values), SLQ
+    log-det value and gradient w.r.t. all stored values: the 64-probe batch against the same probes in two batches of 32 (1.28e9 elements
+    each, below 2^31) -- the kernels treat the probes of a batch independently, so the two must agree to fp32 round-off."""
+    n, k, p = 1_000_003, 40, 64
+    i = np.arange(n - 1)
+    r = np.concatenate([np.arange(n), i, i + 1])
+    c = np.concatenate([np.arange(n), i + 1, i])
+    rng = np.random.default_rng(5)
+    off = -1.0 + 0.2 * rng.random(n - 1)
+    v = np.concatenate([3.0 + rng.random(n), off, off])
+    op, vals, _ = CsrOp.from_coo(r, c, v, n, DEV)
+    vals = vals.float()
+    probes = hutchinson.sampler_rademacher(torch.empty(n, dtype=torch.float32, device=DEV), num=p)(3)
+    integrand = lanczos.integrand_spd(torch.log, k, op)
+
+    def run(P):
+        vt = vals.clone().requires_grad_(True)
+        out = integrand(P, vt)
+        (g,) = torch.autograd.grad(out.sum(), vt)
+        return out.detach().double(), g.double()
+
+    va, ga = run(probes)
+    torch.cuda.empty_cache()
+    vb0, gb0 = run(probes[:32])
+    vb1, gb1 = run(probes[32:])
+    vb, gb = torch.cat([vb0, vb1]), gb0 + gb1
+    assert torch.isfinite(va).all() and torch.isfinite(ga).all()
+    assert ((va - vb).abs() <= 1e-6 * vb.abs()).all(), (va - vb).abs().max().item()
+    assert ((ga - gb).abs().max() <= 1e-5 * gb.abs().max()).item(), ((ga - gb).abs().max().item(), gb.abs().max().item())
+    # and the values are right: log det of a diagonally dominant tridiagonal matrix, n log(3.5) to within its off-diagonal correction
+    assert abs(va.mean().item() / n - np.log(3.5)) < 0.1
+
+
 # ------------------------------------------------------------------------------------------------------------------------
 # C3: bloweybq
 # ------------------------------------------------------------------------------------------------------------------------

@@ -21,12 +21,17 @@ SWEEPS = [
     ("tests/fuzz_krylov.py", 100, 2),    # Krylov drivers in fp64 against the oracle
     ("tests/fuzz_gp.py", 60, 6),         # partial Cholesky, preconditioner, (P)CG
     ("tools/fuzz_pde.py", 25, 11),       # wave operator + expm_arnoldi against scipy expm, adjoint identity; Hutchinson against the trace
+    ("tools/fuzz_matvec.py", 60, 51, {"FUZZ_WIDE_D": "1"}),  # the same sweep at d = 17 .. 32 (DPAD = 32: no BASELINE config goes there)
 ]
+IDS = [s[0].split("/")[-1][:-3] + ("_" + "_".join(k.lower() for k in s[3]) if len(s) > 3 else "") for s in SWEEPS]
 
 
-@pytest.mark.parametrize("script,cases,seed", SWEEPS, ids=[s[0].split("/")[-1][:-3] for s in SWEEPS])
-def test_random_shape_sweep(script, cases, seed):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, script), str(cases), str(seed)], cwd=ROOT, capture_output=True, text=True, timeout=900)
+@pytest.mark.parametrize("sweep", SWEEPS, ids=IDS)
+def test_random_shape_sweep(sweep):
+    script, cases, seed = sweep[:3]
+    env = dict(os.environ, **(sweep[3] if len(sweep) > 3 else {}))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, script), str(cases), str(seed)], cwd=ROOT, capture_output=True, text=True, timeout=900,
+                         env=env)
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     tail = "\n".join(lines[-25:]) + out.stderr[-1500:]
     assert lines, tail

@@ -578,17 +578,43 @@ def test_error_paths_on_device():
 
     with pytest.raises(ZeroDivisionError, match="on purpose"):  # exceptions in Python matvecs cross the C loop intact
         arnoldi.hessenberg(boom, 3, reortho="full")(v, A)
-    # the on-device tridiagonal eigen-solver is LDS-resident: k <= 120
+    # plain tridiagonalisation has no depth limit (the SLQ quadrature's: 2048, next test)
     big = T(orc.spd_diag_plus_lowrank(256, 2, seed=0))
-    with pytest.raises(_lib.MfxError, match="k <= 120"):
-        lanczos.integrand_spd(torch.log, 121, DenseOp())(T(np.ones(256)), big)
-    # ... while plain tridiagonalisation has no such limit
     (Q, (d, e)), _ = lanczos.tridiag(DenseOp(), 200, reortho="full")(T(np.ones(256) + np.arange(256) * 1e-3), big)
     assert Q.shape == (200, 256) and torch.isfinite(d).all()
+    with pytest.raises(_lib.MfxError, match="needs fp64 buffers"):  # the C-ABI states it; the Python layer casts (next test)
+        lib = _lib.get()
+        a32 = torch.ones((1, 130), dtype=torch.float32, device=DEV)
+        out = torch.empty((1, 130 * 130 + 130), dtype=torch.float32, device=DEV)
+        _lib.check(lib.mfx_tridiag_eigh(_lib.ptr(a32), _lib.ptr(a32), 129, 1, 130, _lib.dtype_code(torch.float32), _lib.ptr(out),
+                                        _lib.ptr(out[:, 130:]), _lib.stream_ptr(DEV)))
     with pytest.raises(ValueError, match="square"):
         DenseOp()(v, T(np.ones((n, n + 1))))
     with pytest.raises(TypeError):
         arnoldi.hessenberg(DenseOp(), 3, reortho="full")(v.to(torch.float16), A.to(torch.float16))
+
+
+@pytest.mark.parametrize("dtype,vtol,gtol", [(torch.float64, 1e-10, 1e-7), (torch.float32, 2e-5, 2e-3)])
+@pytest.mark.parametrize("k", [121, 150, 255])
+def test_slq_beyond_depth_120(k, dtype, vtol, gtol):
+    """The reference's SuiteSparse sweeps run to depth 150 (experiments/benchmarks/.../benchmark.py:21,83; plot_quadrant.py:22) and
+    integrand_spd has no depth limit (lanczos.py:14-61).  Up to k = 120 the on-device eigen-solver and the quadrature's VJP keep their
+    k x k work matrices in LDS; beyond, the rotations are accumulated in the fp64 output and the divided differences evaluated in place
+    (fp32 problems are cast for the k x k part).  Against the oracle, value and gradient w.r.t. a dense symmetric parameter; k = 255 of
+    n = 256 is (nearly) the exact log-quadratic form v^T log(A) v."""
+    n = 256
+    A = orc.spd_diag_plus_lowrank(n, 4, seed=3)
+    v = np.where(np.random.default_rng(k).random(n) < 0.5, -1.0, 1.0)
+    At = torch.tensor(A, dtype=dtype, device=DEV, requires_grad=True)
+    val = lanczos.integrand_spd(torch.log, k, DenseOp())(torch.tensor(v, dtype=dtype, device=DEV), At)
+    (g,) = torch.autograd.grad(val, At)
+    ref, _, (gref,) = orc.integrand_spd_value_and_grad(orc.DenseOp(), k, v, (A,))
+    assert abs(val.item() - ref) <= vtol * abs(ref), (val.item(), ref)
+    assert np.abs(N(g.double()) - gref).max() <= gtol * np.abs(gref).max()
+    if k == 255:
+        lam, U = np.linalg.eigh(A)
+        exact = (U.T @ v) ** 2 @ np.log(lam)
+        assert abs(val.item() - exact) <= 10 * vtol * abs(exact)
 
 
 @pytest.mark.parametrize("which", ["arnoldi", "lanczos-none", "lanczos-full"])

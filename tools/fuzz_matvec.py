@@ -34,6 +34,8 @@ for case in range(cases):
     if os.environ.get("FUZZ_LARGE"):  # a few cases at the headline's size class: unsplit sweeps with many chain folds, 2048 tiles
         n = int(rng.integers(60000, 140000))
     d = int(rng.integers(1, 17))
+    if os.environ.get("FUZZ_WIDE_D"):  # d = 17 .. 32: the widest padded row (DPAD = 32), which no BASELINE config uses
+        d = int(rng.integers(17, 33))
     p = int(rng.choice([1, 2, 3, 7, 8, 16, 31, 32, 33, 47, 64, 65, 96, 100, 128, 130]))
     kernel = str(rng.choice(["rbf", "rbf", "matern32", "matern12"]))
     ard = bool(rng.integers(0, 2))

@@ -1,5 +1,5 @@
 """The on-device tridiagonal eigen-solver and the quadrature's VJP (lanczos.py:48-59 of the reference) on random tridiagonals against NumPy:
-k = 1 ... 120, batches, graded / clustered / nearly-decoupled matrices, matfun log / exp / inverse, fp64 and fp32.
+k = 1 ... 400 (the LDS-resident kernels up to 120, the deep variants beyond), batches, graded / clustered / nearly-decoupled matrices, matfun log / exp / inverse, fp64 and fp32.
     python tools/fuzz_small.py [cases] [seed]"""
 import os
 import sys
@@ -16,8 +16,10 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 for case in range(cases):
-    k = int(rng.choice([1, 2, 3, rng.integers(4, 41), rng.integers(41, 121)]))
+    k = int(rng.choice([1, 2, 3, rng.integers(4, 41), rng.integers(41, 121), rng.integers(121, 200), rng.integers(200, 401)]))
     p = int(rng.choice([1, 2, 7, 64, 200]))
+    if k > 120:  # (the deep variants rotate in global memory, ~1 us per rotation, and the NumPy check is O(p k^3): small batches there)
+        p = min(p, 7)
     kind = str(rng.choice(["lanczos_like", "graded", "clustered", "decoupled"]))
     dtype = torch.float64 if rng.integers(0, 3) else torch.float32
     fname = str(rng.choice(["log", "exp", "inv"]))
