@@ -296,6 +296,192 @@ __global__ __launch_bounds__(256) void k_rbf_grad(const T* __restrict__ xs, cons
   if (tid < DPAD + 2) partial[(int64_t)blockIdx.x * (DPAD + 2) + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wide inputs, d > 32 (round 5).  The reference's kernel functions take any input dimension (util/gp_util.py:151-184) and its UCI
+// loaders go to d = 90 (song) and 385 (slice) (util/uci_util.py:85-99,303-310): refusing them is not an option for a drop-in.  The
+// kernels above keep a point in registers (xi[DPAD]); here the scaled points are padded to a multiple of 32 and the distance is a
+// small GEMM: a workgroup = 256 rows i x a tile of columns j, the d axis in chunks staged TRANSPOSED through LDS (xiT[c][row],
+// xjT[c][col]), each thread accumulating <x_i, x_j> for its row and every column of the tile.  VALU arithmetic in the operator's
+// dtype, every mode: correctness and the API first -- these shapes are not on the matrix cores.
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct Wide { static constexpr int CH = sizeof(T) == 4 ? 32 : 16; };  // d-chunk: 32 KB of LDS for xiT
+constexpr int kWideTJ = 32;   // columns per tile, matvec
+constexpr int kWideGJ = 16;   // columns per tile, parameter sweep
+constexpr int kWideGC = 32;   // ARD dimensions a workgroup of the sweep accumulates (blockIdx.y selects them)
+
+// dot[jj] += <x_i, x_j> over all chunks of the padded d axis; TJ columns j0 .. j0 + TJ
+template <typename T, int TJ>
+__device__ __forceinline__ void wide_dots(const T* __restrict__ xs, int64_t n, int dpad, const T* __restrict__ xrow, int64_t ic,
+                                          int64_t j0, T (*xiT)[256], T (*xjT)[TJ], T (&dot)[TJ]) {
+  constexpr int CH = Wide<T>::CH;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int jj = 0; jj < TJ; ++jj) dot[jj] = T(0);
+  for (int c0 = 0; c0 < dpad; c0 += CH) {
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < CH; ++c) xiT[c][tid] = xrow[ic * dpad + c0 + c];
+    for (int t = tid; t < TJ * CH; t += 256) {
+      const int jj = t / CH, c = t % CH;
+      xjT[c][jj] = (j0 + jj < n) ? xs[(j0 + jj) * dpad + c0 + c] : T(0);
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int c = 0; c < CH; ++c) {
+      const T xic = xiT[c][tid];
+#pragma unroll
+      for (int jj = 0; jj < TJ; ++jj) dot[jj] += xic * xjT[c][jj];
+    }
+  }
+}
+
+template <typename T, int PB>
+__global__ __launch_bounds__(256) void k_rbf_apply_wide(const T* __restrict__ xs, const T* __restrict__ sq, int64_t n, int dpad,
+                                                        const T* __restrict__ outputscale, const T* __restrict__ noise,
+                                                        const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy,
+                                                        int64_t p, int kind, const T* __restrict__ xrow,
+                                                        const T* __restrict__ sqrow, int64_t m, int64_t row0) {
+  // rows, row0: as k_rbf_apply
+  constexpr int CH = Wide<T>::CH;
+  const bool self = row0 >= 0;
+  __shared__ __attribute__((aligned(16))) T xiT[CH][256];
+  __shared__ __attribute__((aligned(16))) T xjT[CH][kWideTJ];
+  __shared__ T sqj[kWideTJ];
+  __shared__ T vj[PB][kWideTJ];
+  const int tid = threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * 256 + tid;
+  const int64_t b0 = (int64_t)blockIdx.y * PB;
+  const int64_t ic = i < m ? i : m - 1;
+  const T sqi = sqrow[ic];
+  T acc[PB];
+#pragma unroll
+  for (int q = 0; q < PB; ++q) acc[q] = T(0);
+  for (int64_t j0 = 0; j0 < n; j0 += kWideTJ) {
+    __syncthreads();  // the previous tile's vj / sqj are read no more
+    if (tid < kWideTJ) sqj[tid] = (j0 + tid < n) ? sq[j0 + tid] : T(0);
+    for (int t = tid; t < PB * kWideTJ; t += 256) {
+      const int q = t / kWideTJ, jj = t % kWideTJ;
+      vj[q][jj] = (b0 + q < p && j0 + jj < n) ? x[(b0 + q) * ldx + j0 + jj] : T(0);
+    }
+    T dot[kWideTJ];
+    wide_dots<T, kWideTJ>(xs, n, dpad, xrow, ic, j0, xiT, xjT, dot);  // (its barriers publish vj / sqj too)
+#pragma unroll
+    for (int jj = 0; jj < kWideTJ; ++jj) {
+      T dist = sqi + sqj[jj] - T(2) * dot[jj];
+      dist = dist > T(0) ? dist : T(0);
+      T kv, wl;
+      if (kind == MFX_KERNEL_RBF) {
+        kv = exp_neg_half(dist);
+      } else {
+        if (self && j0 + jj == row0 + i) dist = T(0);
+        kernel_eval<T>(kind, dist, kv, wl);
+      }
+#pragma unroll
+      for (int q = 0; q < PB; ++q) acc[q] += kv * vj[q][jj];  // (columns j >= n carry v = 0)
+    }
+  }
+  if (i < m) {
+    const T s = outputscale[0], nz = noise[0];
+#pragma unroll
+    for (int q = 0; q < PB; ++q)
+      if (b0 + q < p) y[(b0 + q) * ldy + i] = self ? s * acc[q] + nz * x[(b0 + q) * ldx + row0 + i] : s * acc[q];
+  }
+}
+
+// Parameter sweep for wide inputs: as k_rbf_grad; with ARD the d lengthscale derivatives do not fit a thread's registers, so the
+// grid's second axis selects kWideGC of them (S_ij and the kernel weights are re-evaluated per selection: d / 32 times the work of
+// a scalar lengthscale -- the price of keeping the direct, cancellation-free form sum_ij w_ij (x_ic - x_jc)^2).
+template <typename T>
+__global__ __launch_bounds__(256) void k_rbf_grad_wide(const T* __restrict__ xs, const T* __restrict__ sq, int64_t n, int dpad,
+                                                       int ard, int kind, const T* __restrict__ L, int64_t ldl,
+                                                       const T* __restrict__ R, int64_t ldr, int64_t batch,
+                                                       double* __restrict__ partial /* (nblocks, dpad + 2) */, int64_t row0,
+                                                       int64_t nrow) {
+  constexpr int CH = Wide<T>::CH;
+  __shared__ __attribute__((aligned(16))) T xiT[CH][256];
+  __shared__ __attribute__((aligned(16))) T xjT[CH][kWideGJ];
+  __shared__ __attribute__((aligned(16))) T xjg[kWideGJ][kWideGC];
+  __shared__ T sqj[kWideGJ];
+  __shared__ T rj[kGradBC][kWideGJ];
+  __shared__ double red[4][kWideGC + 2];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int gc = (int)blockIdx.y;  // ARD: dimensions gc * 32 .. gc * 32 + 31; scalar lengthscale: one selection
+  const int64_t il = (int64_t)blockIdx.x * 256 + tid;
+  const bool live = il < nrow;
+  const int64_t i = row0 + il;
+  const int64_t ic = live ? i : row0 + nrow - 1;
+  const T sqi = sq[ic];
+  T xig[kWideGC];
+#pragma unroll
+  for (int c = 0; c < kWideGC; ++c) xig[c] = ard ? xs[ic * dpad + gc * kWideGC + c] : T(0);
+  double g[kWideGC + 2];  // [0 .. 32): this selection's lengthscale dims (scalar: [0]); [32]: outputscale; [33]: noise (selection 0 only)
+#pragma unroll
+  for (int c = 0; c < kWideGC + 2; ++c) g[c] = 0.0;
+  for (int64_t j0 = 0; j0 < n; j0 += kWideGJ) {
+    T S[kWideGJ];
+#pragma unroll
+    for (int jj = 0; jj < kWideGJ; ++jj) S[jj] = T(0);
+    for (int64_t bt0 = 0; bt0 < batch; bt0 += kGradBC) {
+      __syncthreads();
+      for (int t = tid; t < kGradBC * kWideGJ; t += 256) {
+        const int q = t / kWideGJ, jj = t % kWideGJ;
+        rj[q][jj] = (bt0 + q < batch && j0 + jj < n) ? R[(bt0 + q) * ldr + j0 + jj] : T(0);
+      }
+      __syncthreads();
+      const int qmax = (int)((batch - bt0) < kGradBC ? (batch - bt0) : kGradBC);
+      for (int q = 0; q < qmax; ++q) {
+        const T l = live ? L[(bt0 + q) * ldl + il] : T(0);
+#pragma unroll
+        for (int jj = 0; jj < kWideGJ; ++jj) S[jj] += l * rj[q][jj];
+      }
+    }
+    __syncthreads();
+    if (tid < kWideGJ) sqj[tid] = (j0 + tid < n) ? sq[j0 + tid] : T(0);
+    if (ard)
+      for (int t = tid; t < kWideGJ * kWideGC; t += 256) {
+        const int jj = t / kWideGC, c = t % kWideGC;
+        xjg[jj][c] = (j0 + jj < n) ? xs[(j0 + jj) * dpad + gc * kWideGC + c] : T(0);
+      }
+    T dot[kWideGJ];
+    wide_dots<T, kWideGJ>(xs, n, dpad, xs, ic, j0, xiT, xjT, dot);
+#pragma unroll
+    for (int jj = 0; jj < kWideGJ; ++jj) {
+      if (j0 + jj >= n) continue;
+      T dist = sqi + sqj[jj] - T(2) * dot[jj];
+      dist = dist > T(0) ? dist : T(0);
+      if (kind != MFX_KERNEL_RBF && j0 + jj == i) dist = T(0);
+      T kv, wl;
+      kernel_eval<T>(kind, dist, kv, wl);
+      const T w = S[jj] * wl;
+      if (gc == 0) {
+        g[kWideGC] += (double)(S[jj] * kv);
+        if (j0 + jj == i) g[kWideGC + 1] += (double)S[jj];
+      }
+      if (ard) {
+#pragma unroll
+        for (int c = 0; c < kWideGC; ++c) {
+          const T df = xig[c] - xjg[jj][c];
+          g[c] += (double)(w * df * df);
+        }
+      } else {
+        g[0] += (double)(w * dist);
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < kWideGC + 2; ++c) {
+    const double v = wave_sum(live ? g[c] : 0.0);
+    if (lane == 0) red[wid][c] = v;
+  }
+  __syncthreads();
+  double* out = partial + (int64_t)blockIdx.x * (dpad + 2);
+  if (tid < kWideGC && (ard || tid == 0)) out[gc * kWideGC + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+  if (!ard)  // (the columns k_rbf_grad_final sums and drops)
+    for (int c = 1 + tid; c < dpad; c += 256) out[c] = 0.0;
+  if (gc == 0 && tid >= kWideGC && tid < kWideGC + 2)
+    out[dpad + tid - kWideGC] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
 // grads += factors * sum_blocks partial  (chain to the constrained parameters l, s, noise)
 template <typename T>
 __global__ __launch_bounds__(256) void k_rbf_grad_final(const double* __restrict__ partial, int64_t nblocks, int dpad, int d,
@@ -324,7 +510,8 @@ __global__ __launch_bounds__(256) void k_rbf_grad_final(const double* __restrict
   }
 }
 
-static int rbf_dpad(int d) { return d <= 4 ? 4 : d <= 8 ? 8 : d <= 12 ? 12 : d <= 16 ? 16 : d <= 32 ? 32 : -1; }
+constexpr int kRbfMaxD = 1024;  // wide inputs (d > 32): padded to a multiple of 32, k_rbf_apply_wide / k_rbf_grad_wide
+static int rbf_dpad(int d) { return d <= 4 ? 4 : d <= 8 ? 8 : d <= 12 ? 12 : d <= 16 ? 16 : d <= kRbfMaxD ? (d + 31) / 32 * 32 : -1; }
 
 struct RbfWs {
   void *xs, *sq;
@@ -429,10 +616,37 @@ static int rbf_apply_d(const mfx_operator* op, const RbfWs& w, const T* x, int64
 }
 
 template <typename T>
+static int rbf_apply_wide(const mfx_operator* op, const RbfWs& w, int dpad, const T* x, int64_t ldx, T* y, int64_t ldy, int64_t p,
+                          hipStream_t stream, const T* xrow = nullptr, const T* sqrow = nullptr, int64_t m = 0) {
+  int64_t row0 = -1;
+  if (!xrow) {
+    row0 = op_row0(op);
+    m = op_nrows(op);
+    xrow = (const T*)w.xs + row0 * dpad;
+    sqrow = (const T*)w.sq + row0;
+  }
+  const unsigned gx = (unsigned)((m + 255) / 256);
+#define MFX_RBF_LAUNCH(PB)                                                                                 \
+  k_rbf_apply_wide<T, PB><<<dim3(gx, (unsigned)((p + PB - 1) / PB)), 256, 0, stream>>>(                     \
+      (const T*)w.xs, (const T*)w.sq, op->n, dpad, (const T*)op->outputscale, (const T*)op->noise, x, ldx, y, ldy, p, \
+      op->kernel_fn, xrow, sqrow, m, row0)
+  if (p == 1) {
+    MFX_RBF_LAUNCH(1);
+  } else if (p <= 4 || sizeof(T) == 8) {  // (8 fp64 vectors next to the 32 fp64 dot products of a tile would spill)
+    MFX_RBF_LAUNCH(4);
+  } else {
+    if constexpr (sizeof(T) == 4) MFX_RBF_LAUNCH(8);
+  }
+#undef MFX_RBF_LAUNCH
+  MFX_CHECK_LAUNCH();
+  return MFX_OK;
+}
+
+template <typename T>
 static int rbf_apply(const mfx_operator* op, const T* x, int64_t ldx, T* y, int64_t ldy, int64_t p, void* ws,
                      int64_t ws_bytes, hipStream_t stream) {
   const int dpad = rbf_dpad(op->d);
-  MFX_REQUIRE(dpad > 0, MFX_ERR_UNSUPPORTED, "RBF operator supports d <= 32 (got %d)", op->d);
+  MFX_REQUIRE(dpad > 0, MFX_ERR_UNSUPPORTED, "RBF operator supports d <= 1024 (got %d)", op->d);
   RbfWs w;
   MFX_REQUIRE(rbf_carve(op, ws, ws_bytes, &w, 0, p) <= ws_bytes && ws, MFX_ERR_WORKSPACE, "RBF workspace too small");
   MFX_TRY(rbf_prep<T>(op, w, dpad, stream));
@@ -452,7 +666,8 @@ static int rbf_apply(const mfx_operator* op, const T* x, int64_t ldx, T* y, int6
     case 8: return rbf_apply_d<T, 8>(op, w, x, ldx, y, ldy, p, stream);
     case 12: return rbf_apply_d<T, 12>(op, w, x, ldx, y, ldy, p, stream);
     case 16: return rbf_apply_d<T, 16>(op, w, x, ldx, y, ldy, p, stream);
-    default: return rbf_apply_d<T, 32>(op, w, x, ldx, y, ldy, p, stream);
+    case 32: return rbf_apply_d<T, 32>(op, w, x, ldx, y, ldy, p, stream);
+    default: return rbf_apply_wide<T>(op, w, dpad, x, ldx, y, ldy, p, stream);
   }
 }
 
@@ -461,7 +676,7 @@ template <typename T>
 static int rbf_cross_apply(const mfx_operator* op, const T* xnew, int64_t m, const T* v, int64_t ldv, T* y, int64_t ldy,
                            int64_t p, void* ws, int64_t ws_bytes, hipStream_t stream) {
   const int dpad = rbf_dpad(op->d);
-  MFX_REQUIRE(dpad > 0, MFX_ERR_UNSUPPORTED, "RBF operator supports d <= 32 (got %d)", op->d);
+  MFX_REQUIRE(dpad > 0, MFX_ERR_UNSUPPORTED, "RBF operator supports d <= 1024 (got %d)", op->d);
   RbfWs w;
   const int64_t base = rbf_carve(op, ws, ws_bytes, &w);
   Carver cv(ws ? (char*)ws + base : nullptr, ws_bytes - base);
@@ -477,7 +692,8 @@ static int rbf_cross_apply(const mfx_operator* op, const T* xnew, int64_t m, con
     case 8: return rbf_apply_d<T, 8>(op, w, v, ldv, y, ldy, p, stream, xr, sqr, m);
     case 12: return rbf_apply_d<T, 12>(op, w, v, ldv, y, ldy, p, stream, xr, sqr, m);
     case 16: return rbf_apply_d<T, 16>(op, w, v, ldv, y, ldy, p, stream, xr, sqr, m);
-    default: return rbf_apply_d<T, 32>(op, w, v, ldv, y, ldy, p, stream, xr, sqr, m);
+    case 32: return rbf_apply_d<T, 32>(op, w, v, ldv, y, ldy, p, stream, xr, sqr, m);
+    default: return rbf_apply_wide<T>(op, w, dpad, v, ldv, y, ldy, p, stream, xr, sqr, m);
   }
 }
 
@@ -500,7 +716,7 @@ template <typename T>
 static int rbf_grad(const mfx_operator* op, const T* L, int64_t ldl, const T* R, int64_t ldr, int64_t batch, int64_t inner,
                     const mfx_op_grads* grads, void* ws, int64_t ws_bytes, hipStream_t stream) {
   const int dpad = rbf_dpad(op->d);
-  MFX_REQUIRE(dpad > 0, MFX_ERR_UNSUPPORTED, "RBF operator supports d <= 32 (got %d)", op->d);
+  MFX_REQUIRE(dpad > 0, MFX_ERR_UNSUPPORTED, "RBF operator supports d <= 1024 (got %d)", op->d);
   RbfWs w;
   MFX_REQUIRE(rbf_carve(op, ws, ws_bytes, &w, batch) <= ws_bytes && ws, MFX_ERR_WORKSPACE, "RBF workspace too small");
   MFX_TRY(rbf_prep<T>(op, w, dpad, stream));
@@ -530,7 +746,11 @@ static int rbf_grad(const mfx_operator* op, const T* L, int64_t ldl, const T* R,
       case 8: MFX_RBF_GRAD(8); break;
       case 12: MFX_RBF_GRAD(12); break;
       case 16: MFX_RBF_GRAD(16); break;
-      default: MFX_RBF_GRAD(32); break;
+      case 32: MFX_RBF_GRAD(32); break;
+      default:
+        k_rbf_grad_wide<T><<<dim3((unsigned)nblocks, op->ard ? (unsigned)(dpad / kWideGC) : 1u), 256, 0, stream>>>(
+            (const T*)w.xs, (const T*)w.sq, op->n, dpad, op->ard, op->kernel_fn, L, ldl, R, ldr, batch, w.partial, row0, nrow);
+        break;
     }
 #undef MFX_RBF_GRAD
     MFX_CHECK_LAUNCH();

@@ -34,6 +34,8 @@ def check(name, got, ref, tol, info):
 for case in range(cases):
     kernel = str(rng.choice(["rbf", "matern32", "matern12"]))
     d = int(rng.integers(1, 13))
+    if os.environ.get("FUZZ_WIDE_D"):  # up to the wide kernels (d > 32); the inputs below are scaled so that distances stay O(1)
+        d = int(rng.integers(13, 100))
     if case % 3 != 2:
         n = int(rng.choice([rng.integers(8, 100), rng.integers(100, 1500)]))
         rank = int(rng.integers(1, min(n, 48) + 1))
@@ -41,7 +43,7 @@ for case in range(cases):
         steps = int(rng.integers(1, 7))  # (CG amplifies a 1e-16 difference ~ 15x per step at these condition numbers: first run of this script)
         info = f"case {case}: {kernel} n={n} d={d} rank={rank} rhs={nrhs} steps={steps}"
         try:
-            X = rng.uniform(-1, 1, (n, d))
+            X = rng.uniform(-1, 1, (n, d)) * min(1.0, 3.5 / np.sqrt(d))
             raw = (np.float64(rng.uniform(-0.5, 0.8)), np.float64(0.4), np.float64(rng.uniform(-4.0, -1.0)))
             oop = orc.RbfGramOp(X, noise_minval=1e-4, kernel=kernel)
             ls, s, noise = oop.constrained(*raw)
@@ -89,7 +91,7 @@ for case in range(cases):
         mode = str(rng.choice(["f16x3", "f16x3-matvec", "fp32"]))
         info = f"case {case}: {kernel} n={n} d={d} rhs={nrhs} steps={steps} {mode} vs fp64"
         try:
-            X = rng.standard_normal((n, d))
+            X = rng.standard_normal((n, d)) * min(1.0, 3.5 / np.sqrt(d))
             raw = (0.7, 0.3, -1.0)
             V = rng.standard_normal((nrhs, n))
             sol = {}

@@ -32,12 +32,14 @@ for case in range(cases):
             print(f"FAIL rows_per_rank refused a layout that exists: n={n} ranks={ranks}", flush=True)
         n = ranks * (-(-n // (64 * ranks)) * 64) - int(rng.integers(0, 64))  # the next n whose last shard is not empty
     d = int(rng.integers(1, 17))
+    if os.environ.get("FUZZ_WIDE_D"):  # up to the wide kernels (d > 32)
+        d = int(rng.integers(17, 130))
     p = int(rng.choice([1, 4, 8, 16, 33, 64, 70]))
     k = int(rng.integers(2, 14))
     kernel = str(rng.choice(["rbf", "rbf", "matern32"]))
     dtype, mode = [(torch.float64, "fp32"), (torch.float32, "f16x3"), (torch.float32, "f16x3-matvec"), (torch.float32, "fp32")][int(rng.integers(0, 4))]
     ard = bool(rng.integers(0, 2))
-    X = torch.tensor(rng.standard_normal((n, d)), dtype=dtype, device=dev)
+    X = torch.tensor(rng.standard_normal((n, d)) * min(1.0, 4.0 / np.sqrt(d)), dtype=dtype, device=dev)
     raw = [np.full(d, 0.8) if ard else np.array(0.8), np.array(0.3), np.array(-0.7)]
     info = f"case {case}: ranks={ranks} n={n} d={d} p={p} k={k} {kernel} ard={ard} {str(dtype).split('.')[-1]} {mode}"
     try:

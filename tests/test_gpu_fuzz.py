@@ -22,8 +22,10 @@ SWEEPS = [
     ("tests/fuzz_gp.py", 60, 6),         # partial Cholesky, preconditioner, (P)CG
     ("tools/fuzz_pde.py", 25, 11),       # wave operator + expm_arnoldi against scipy expm, adjoint identity; Hutchinson against the trace
     ("tools/fuzz_matvec.py", 60, 51, {"FUZZ_WIDE_D": "1"}),  # the same sweep at d = 17 .. 32 (DPAD = 32: no BASELINE config goes there)
+    ("tools/fuzz_matvec.py", 40, 61, {"FUZZ_WIDE_D": "2"}),  # ... and at d = 33 .. 200: the wide kernels (UCI song: 90, slice: 385)
+    ("tools/fuzz_slq.py", 12, 62, {"FUZZ_WIDE_D": "1"}),     # SLQ value and gradient at d = 17 .. 129
 ]
-IDS = [s[0].split("/")[-1][:-3] + ("_" + "_".join(k.lower() for k in s[3]) if len(s) > 3 else "") for s in SWEEPS]
+IDS = [s[0].split("/")[-1][:-3] + ("_" + "_".join(f"{k.lower()}{v}" for k, v in s[3].items()) if len(s) > 3 else "") for s in SWEEPS]
 
 
 @pytest.mark.parametrize("sweep", SWEEPS, ids=IDS)

@@ -141,6 +141,42 @@ def test_rbf_op_apply_and_param_sweep(dtype, tol, precision, ard, n, d, p, kerne
         assert close(g.reshape(np.shape(rr)), rr, gtol, atol_rel=gtol * np.sqrt(n))
 
 
+@pytest.mark.parametrize("dtype,tol,precision", [(torch.float64, 1e-11, "fp32"), (torch.float32, 5e-5, "fp32"), (torch.float32, 5e-5, "f16x3")])
+@pytest.mark.parametrize("kernel", ["rbf", "matern32", "matern12"])
+@pytest.mark.parametrize("ard", [False, True])
+@pytest.mark.parametrize("n,d,p", [(300, 33, 3), (515, 90, 8), (260, 385, 5), (700, 64, 1), (257, 100, 11)])
+def test_rbf_wide_inputs_apply_and_param_sweep(dtype, tol, precision, ard, n, d, p, kernel):
+    """d > 32: the reference's kernels take any input dimension (util/gp_util.py:151-184) and its UCI loaders reach d = 90 (song) and
+    385 (slice) (util/uci_util.py:85-99,303-310).  The wide kernels of csrc/mfx_ops.hip (distance as a small GEMM over chunks of the d
+    axis; with ARD the sweep's grid selects 32 lengthscale derivatives at a time) against the NumPy oracle: matvec, its transpose
+    through autograd, all parameter gradients (d of them with ARD), the cross-covariance matvec of the posterior mean.  Every mode
+    runs the same VALU arithmetic here (these shapes are not on the matrix cores).  Inputs scaled by 1 / sqrt(d): distances O(1)."""
+    rng = np.random.default_rng(d)
+    X = rng.standard_normal((n, d)) / np.sqrt(d) * 1.5
+    raw = (rng.standard_normal(d) * 0.3 + 0.5 if ard else np.array(0.7), np.array(0.4), np.array(-1.0))
+    V, Cc = rng.standard_normal((p, n)), rng.standard_normal((p, n))
+    o = orc.RbfGramOp(X, noise_minval=1e-4, kernel=kernel, eps=float(torch.finfo(dtype).eps))
+    op = RbfGramOp(T(X, dtype), noise_minval=1e-4, precision=precision, kernel=kernel)
+    params = [T(r, dtype, True) for r in raw]
+    Vt = T(V, dtype, True)
+    y = op(Vt, *params)
+    assert close(y, o.apply(V, *raw), tol)
+    grads = torch.autograd.grad(y, (Vt, *params), T(Cc, dtype))
+    assert close(grads[0], o.apply(Cc, *raw), tol)
+    ref = o.param_vjp(V, Cc, *raw)
+    gtol = tol * (50 if dtype == torch.float32 else 10)
+    for g, rr in zip(grads[1:], ref):
+        assert close(g.reshape(np.shape(rr)), rr, gtol, atol_rel=gtol * np.sqrt(n))
+    # K(X_new, X) v without the noise term (util/gp_util.py:299-305)
+    m = 70
+    Xn = rng.standard_normal((m, d)) / np.sqrt(d) * 1.5
+    ls, s = orc.softplus(np.asarray(raw[0], dtype=np.float64)), orc.softplus(np.float64(raw[1]))
+    Kx = orc.kernel_matrix(kernel, Xn, X, ls, s, eps=float(torch.finfo(dtype).eps))
+    with torch.no_grad():
+        got = op.cross_apply(T(Xn, dtype), T(V, dtype), *[q.detach() for q in params])
+    assert close(got, V @ Kx.T, tol)
+
+
 @pytest.mark.parametrize("decay,batch", [(0.0, 96), (9.0, 96), (9.0, 200), (30.0, 77)])
 def test_split_param_sweep_with_rows_of_very_different_size(decay, batch):
     """The split gradient GEMM packs the batch rows by decreasing size and multiplies the tail -- the smallest rows whose bounds add

@@ -34,12 +34,16 @@ for case in range(cases):
     if os.environ.get("FUZZ_LARGE"):  # a few cases at the headline's size class: unsplit sweeps with many chain folds, 2048 tiles
         n = int(rng.integers(60000, 140000))
     d = int(rng.integers(1, 17))
-    if os.environ.get("FUZZ_WIDE_D"):  # d = 17 .. 32: the widest padded row (DPAD = 32), which no BASELINE config uses
+    wide = os.environ.get("FUZZ_WIDE_D", "")
+    if wide == "1":  # d = 17 .. 32: the widest padded row of the register kernels (DPAD = 32), which no BASELINE config uses
         d = int(rng.integers(17, 33))
+    elif wide:       # d = 33 .. 200: the wide kernels (the d axis in chunks through LDS); the sweeps cost d / 32 times more with ARD
+        d = int(rng.integers(33, 201))
+        n = min(n, 5000)
     p = int(rng.choice([1, 2, 3, 7, 8, 16, 31, 32, 33, 47, 64, 65, 96, 100, 128, 130]))
     kernel = str(rng.choice(["rbf", "rbf", "matern32", "matern12"]))
     ard = bool(rng.integers(0, 2))
-    X = rng.standard_normal((n, d)) * rng.choice([0.3, 1.0, 3.0])
+    X = rng.standard_normal((n, d)) * rng.choice([0.3, 1.0, 3.0]) * min(1.0, 4.0 / np.sqrt(d))  # (distances stay O(1) .. O(100) at any d)
     raw = (rng.standard_normal(d) * 0.3 + 0.6 if ard else np.array(0.6 + 0.3 * rng.standard_normal()), np.array(0.3), np.array(-1.0))
     V = rng.standard_normal((p, n)) * np.exp(rng.standard_normal((p, 1)) * 2.0)
     mode = str(rng.choice(["f16x3", "f16x3-matvec", "fp32"]))

@@ -21,12 +21,15 @@ for case in range(cases):
     if os.environ.get("FUZZ_LARGE"):  # the headline's size class (the fp64 leg takes ~10-40 s per case)
         n = int(rng.integers(60000, 140000))
     d = int(rng.integers(1, 17))
+    if os.environ.get("FUZZ_WIDE_D"):  # up to the wide kernels (d > 32)
+        d = int(rng.integers(17, 130))
+        n = min(n, 12000)
     p = int(rng.choice([1, 3, 8, 16, 31, 33, 64, 65, 100, 130]))
     k = int(rng.integers(3, 25))
     kernel = str(rng.choice(["rbf", "rbf", "matern32"]))
     ard = bool(rng.integers(0, 2))
     mode = str(rng.choice(["f16x3", "f16x3", "f16x3-matvec", "fp32"]))
-    X = torch.tensor(rng.standard_normal((n, d)), dtype=torch.float64, device=dev)
+    X = torch.tensor(rng.standard_normal((n, d)) * min(1.0, 4.0 / np.sqrt(d)), dtype=torch.float64, device=dev)
     raw = [np.full(d, 0.9) + 0.2 * rng.standard_normal(d) if ard else np.array(0.9), np.array(0.3), np.array(-0.5)]
     res = {}
     for dt, prec in ((torch.float64, "fp32"), (torch.float32, mode)):
