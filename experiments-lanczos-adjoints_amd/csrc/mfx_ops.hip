@@ -556,6 +556,8 @@ int rbf_mfma_grad_h(const mfx_operator* op, const float* xs, const float* sq, in
                     const float* R, int64_t ldr, int64_t batch, int64_t inner, double* partial, int64_t* nblocks_out, void* hws,
                     const float** scales_out, hipStream_t stream);
 bool rbf_mfma_grad_supported(const mfx_operator* op, int64_t batch);
+bool rbf_mfma_exact_wide_supported(const mfx_operator* op, int64_t p);         // 16 < d <= 64: the exact-fp32 kernels, in every mode
+bool rbf_mfma_grad_exact_wide_supported(const mfx_operator* op, int64_t batch);  // 16 < d <= 32
 int rbf_mfma_grad(const mfx_operator* op, const float* xs, const float* sq, int dpad, const float* L, int64_t ldl,
                   const float* R, int64_t ldr, int64_t batch, double* partial, int64_t* nblocks_out,
                   hipStream_t stream);
@@ -660,6 +662,8 @@ static int rbf_apply(const mfx_operator* op, const T* x, int64_t ldx, T* y, int6
         return rbf_mfma_apply_h3(op, (const float*)w.xs, (const float*)w.sq, dpad, x, ldx, y, ldy, p, w.vscale, w.pk, stream);
       return rbf_mfma_apply(op, (const float*)w.xs, (const float*)w.sq, dpad, x, ldx, y, ldy, p, stream);
     }
+    if (rbf_mfma_exact_wide_supported(op, p))
+      return rbf_mfma_apply(op, (const float*)w.xs, (const float*)w.sq, dpad, x, ldx, y, ldy, p, stream);
   }
   switch (dpad) {
     case 4: return rbf_apply_d<T, 4>(op, w, x, ldx, y, ldy, p, stream);
@@ -731,7 +735,7 @@ static int rbf_grad(const mfx_operator* op, const T* L, int64_t ldl, const T* R,
       MFX_TRY(rbf_mfma_grad_h(op, (const float*)w.xs, (const float*)w.sq, dpad, L, ldl, R, ldr, batch, inner, w.partial, &nblocks,
                               w.hws, &scales, stream));
       done = true;
-    } else if (rbf_mfma_grad_supported(op, batch)) {
+    } else if (rbf_mfma_grad_supported(op, batch) || rbf_mfma_grad_exact_wide_supported(op, batch)) {
       MFX_TRY(rbf_mfma_grad(op, (const float*)w.xs, (const float*)w.sq, dpad, L, ldl, R, ldr, batch, w.partial,
                             &nblocks, stream));
       done = true;

@@ -1851,6 +1851,14 @@ bool rbf_mfma_supported(const mfx_operator* op, int64_t p) {
   return op->dtype == MFX_F32 && p >= 4 && op->d <= 16;
 }
 
+// 16 < d <= 64 (round 5): the split kernels keep their distance operands resident and stop at d = 16, the exact-fp32 kernels of this
+// file are generic in the padded dimension (the distance product is KD / 2 = 17 or 33 fp32 MFMAs per block) -- every arithmetic mode
+// runs them there.  About half of the datasets the reference's UCI loaders fetch have 17 .. 27 input columns (util/uci_util.py:68-316);
+// the VALU kernel they fell to is 18 x slower per matvec than d = 16 on the matrix cores (profiles/r05k_*).
+bool rbf_mfma_exact_wide_supported(const mfx_operator* op, int64_t p) {
+  return op->dtype == MFX_F32 && op->d > 16 && op->d <= 64 && (p >= 4 || op->n >= 2048);
+}
+
 template <int DPAD, int NB, int MI, int TJ>
 static int launch_apply_mi(const mfx_operator* op, const float* xs, const float* sq, const float* x, int64_t ldx,
                            float* y, int64_t ldy, int64_t p, hipStream_t stream) {
@@ -1875,9 +1883,11 @@ template <int DPAD, int NB>
 static int launch_apply(const mfx_operator* op, const float* xs, const float* sq, const float* x, int64_t ldx,
                         float* y, int64_t ldy, int64_t p, hipStream_t stream) {
   // 64 rows per wave (2 workgroups per CU at n = 131072) unless the problem is too small to fill the chip
+  // (DPAD = 64: the resident row operand of the distance product is 33 registers per 32 rows -- one row block per wave)
   const bool small = (op_nrows(op) + 255) / 256 < 512;
-  if (small) return launch_apply_mi<DPAD, NB, 1, 64>(op, xs, sq, x, ldx, y, ldy, p, stream);
-  return launch_apply_mi<DPAD, NB, 2, 64>(op, xs, sq, x, ldx, y, ldy, p, stream);
+  if (small || DPAD > 32) return launch_apply_mi<DPAD, NB, 1, 64>(op, xs, sq, x, ldx, y, ldy, p, stream);
+  if constexpr (DPAD <= 32) return launch_apply_mi<DPAD, NB, 2, 64>(op, xs, sq, x, ldx, y, ldy, p, stream);
+  return MFX_ERR_UNSUPPORTED;
 }
 
 template <int DPAD>
@@ -1894,7 +1904,9 @@ int rbf_mfma_apply(const mfx_operator* op, const float* xs, const float* sq, int
     case 8: return launch_apply_d<8>(op, xs, sq, x, ldx, y, ldy, p, stream);
     case 12: return launch_apply_d<12>(op, xs, sq, x, ldx, y, ldy, p, stream);
     case 16: return launch_apply_d<16>(op, xs, sq, x, ldx, y, ldy, p, stream);
-    default: set_error("RBF MFMA path supports d <= 16"); return MFX_ERR_UNSUPPORTED;
+    case 32: return launch_apply_d<32>(op, xs, sq, x, ldx, y, ldy, p, stream);
+    case 64: return launch_apply_d<64>(op, xs, sq, x, ldx, y, ldy, p, stream);
+    default: set_error("exact-fp32 matrix-core Gram matvec supports d <= 64"); return MFX_ERR_UNSUPPORTED;
   }
 }
 
@@ -1970,7 +1982,7 @@ __device__ __forceinline__ void grad_load_stage(float4 (&ra)[4], float4 (&rb)[4]
 }
 
 template <int DPAD, bool VEC4>
-__global__ __launch_bounds__(256, 2) void k_rbf_mfma_grad(const float* __restrict__ xs, const float* __restrict__ sq,
+__global__ __launch_bounds__(256, DPAD > 16 ? 1 : 2) /* DPAD = 32: 97 KB of LDS, one workgroup per CU anyway */ void k_rbf_mfma_grad(const float* __restrict__ xs, const float* __restrict__ sq,
                                                           int64_t n, int ard, int kind, const float* __restrict__ L,
                                                           int64_t ldl, const float* __restrict__ R, int64_t ldr,
                                                           int64_t batch, int tiles_per_block,
@@ -2135,6 +2147,10 @@ bool rbf_mfma_grad_supported(const mfx_operator* op, int64_t batch) {
   return op->dtype == MFX_F32 && (batch >= 16 || op->n >= 2048) && op->d <= 16 && op->n >= 256;
 }
 
+bool rbf_mfma_grad_exact_wide_supported(const mfx_operator* op, int64_t batch) {  // 16 < d <= 32: see rbf_mfma_exact_wide_supported
+  return op->dtype == MFX_F32 && (batch >= 16 || op->n >= 2048) && op->d > 16 && op->d <= 32 && op->n >= 256;
+}
+
 int64_t rbf_mfma_grad_partial_rows(int64_t n) { return ((n + kGM - 1) / kGM) * kGSplit * kGSub; }
 
 template <int DPAD>
@@ -2170,7 +2186,8 @@ int rbf_mfma_grad(const mfx_operator* op, const float* xs, const float* sq, int 
     case 8: return launch_grad<8>(op, xs, sq, L, ldl, R, ldr, batch, partial, nblocks_out, stream);
     case 12: return launch_grad<12>(op, xs, sq, L, ldl, R, ldr, batch, partial, nblocks_out, stream);
     case 16: return launch_grad<16>(op, xs, sq, L, ldl, R, ldr, batch, partial, nblocks_out, stream);
-    default: set_error("RBF MFMA path supports d <= 16"); return MFX_ERR_UNSUPPORTED;
+    case 32: return launch_grad<32>(op, xs, sq, L, ldl, R, ldr, batch, partial, nblocks_out, stream);
+    default: set_error("exact-fp32 matrix-core parameter sweep supports d <= 32"); return MFX_ERR_UNSUPPORTED;
   }
 }
 
