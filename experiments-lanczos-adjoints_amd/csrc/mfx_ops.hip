@@ -536,7 +536,7 @@ static int64_t rbf_carve(const mfx_operator* op, void* ws, int64_t ws_bytes, Rbf
   r.xs = cv.take(op->n * (dpad > 0 ? dpad : 1) * es);
   r.sq = cv.take(op->n * es);
   // per-workgroup gradient partials: VALU sweep n/256 rows, MFMA sweep 8 * n/128 rows, <= 34 doubles each
-  r.partial = static_cast<double*>(cv.take(((op->n + 127) / 128) * 64 * 34 * sizeof(double)));  // 8 XCDs x 8 sub-ranges
+  r.partial = static_cast<double*>(cv.take(((op->n + 127) / 128) * 64 * (dpad > 32 && dpad <= 64 ? dpad + 2 : 34) * sizeof(double)));  // 8 XCDs x 8 sub-ranges (DPAD 64: the matrix-core sweep writes 66 per workgroup; wider: the VALU sweep, dpad + 2 per 256 rows)
   r.vscale = static_cast<float*>(cv.take(65536 * 3 * sizeof(float)));  // [s, 1/s] per row + |max| bit patterns
   r.hws_bytes = (op->dtype == MFX_F32 && rbf_mode(op) == MFX_RBF_F16X3 && batch_hint > 0) ? rbf_grad_h_ws_bytes(op->n, batch_hint) : 0;
   r.hws = r.hws_bytes ? cv.take(r.hws_bytes) : nullptr;
@@ -556,8 +556,8 @@ int rbf_mfma_grad_h(const mfx_operator* op, const float* xs, const float* sq, in
                     const float* R, int64_t ldr, int64_t batch, int64_t inner, double* partial, int64_t* nblocks_out, void* hws,
                     const float** scales_out, hipStream_t stream);
 bool rbf_mfma_grad_supported(const mfx_operator* op, int64_t batch);
-bool rbf_mfma_exact_wide_supported(const mfx_operator* op, int64_t p);         // 16 < d <= 64: the exact-fp32 kernels, in every mode
-bool rbf_mfma_grad_exact_wide_supported(const mfx_operator* op, int64_t batch);  // 16 < d <= 32
+bool rbf_mfma_exact_wide_supported(const mfx_operator* op, int64_t p);         // 16 < d <= 128: the exact-fp32 kernels, in every mode
+bool rbf_mfma_grad_exact_wide_supported(const mfx_operator* op, int64_t batch);  // 16 < d <= 64
 int rbf_mfma_grad(const mfx_operator* op, const float* xs, const float* sq, int dpad, const float* L, int64_t ldl,
                   const float* R, int64_t ldr, int64_t batch, double* partial, int64_t* nblocks_out,
                   hipStream_t stream);

@@ -1856,7 +1856,7 @@ bool rbf_mfma_supported(const mfx_operator* op, int64_t p) {
 // runs them there.  About half of the datasets the reference's UCI loaders fetch have 17 .. 27 input columns (util/uci_util.py:68-316);
 // the VALU kernel they fell to is 18 x slower per matvec than d = 16 on the matrix cores (profiles/r05k_*).
 bool rbf_mfma_exact_wide_supported(const mfx_operator* op, int64_t p) {
-  return op->dtype == MFX_F32 && op->d > 16 && op->d <= 64 && (p >= 4 || op->n >= 2048);
+  return op->dtype == MFX_F32 && op->d > 16 && op->d <= 128 && (p >= 4 || op->n >= 2048);
 }
 
 template <int DPAD, int NB, int MI, int TJ>
@@ -1906,7 +1906,9 @@ int rbf_mfma_apply(const mfx_operator* op, const float* xs, const float* sq, int
     case 16: return launch_apply_d<16>(op, xs, sq, x, ldx, y, ldy, p, stream);
     case 32: return launch_apply_d<32>(op, xs, sq, x, ldx, y, ldy, p, stream);
     case 64: return launch_apply_d<64>(op, xs, sq, x, ldx, y, ldy, p, stream);
-    default: set_error("exact-fp32 matrix-core Gram matvec supports d <= 64"); return MFX_ERR_UNSUPPORTED;
+    case 96: return launch_apply_d<96>(op, xs, sq, x, ldx, y, ldy, p, stream);
+    case 128: return launch_apply_d<128>(op, xs, sq, x, ldx, y, ldy, p, stream);
+    default: set_error("exact-fp32 matrix-core Gram matvec supports d <= 128"); return MFX_ERR_UNSUPPORTED;
   }
 }
 
@@ -2147,8 +2149,9 @@ bool rbf_mfma_grad_supported(const mfx_operator* op, int64_t batch) {
   return op->dtype == MFX_F32 && (batch >= 16 || op->n >= 2048) && op->d <= 16 && op->n >= 256;
 }
 
-bool rbf_mfma_grad_exact_wide_supported(const mfx_operator* op, int64_t batch) {  // 16 < d <= 32: see rbf_mfma_exact_wide_supported
-  return op->dtype == MFX_F32 && (batch >= 16 || op->n >= 2048) && op->d > 16 && op->d <= 32 && op->n >= 256;
+bool rbf_mfma_grad_exact_wide_supported(const mfx_operator* op, int64_t batch) {  // 16 < d <= 64: see rbf_mfma_exact_wide_supported
+  // (beyond: x_i and x_j of a 128 x 128 tile, 2 x 128 x DPAD floats, no longer fit the LDS next to the operand stages)
+  return op->dtype == MFX_F32 && (batch >= 16 || op->n >= 2048) && op->d > 16 && op->d <= 64 && op->n >= 256;
 }
 
 int64_t rbf_mfma_grad_partial_rows(int64_t n) { return ((n + kGM - 1) / kGM) * kGSplit * kGSub; }
@@ -2187,7 +2190,8 @@ int rbf_mfma_grad(const mfx_operator* op, const float* xs, const float* sq, int 
     case 12: return launch_grad<12>(op, xs, sq, L, ldl, R, ldr, batch, partial, nblocks_out, stream);
     case 16: return launch_grad<16>(op, xs, sq, L, ldl, R, ldr, batch, partial, nblocks_out, stream);
     case 32: return launch_grad<32>(op, xs, sq, L, ldl, R, ldr, batch, partial, nblocks_out, stream);
-    default: set_error("exact-fp32 matrix-core parameter sweep supports d <= 32"); return MFX_ERR_UNSUPPORTED;
+    case 64: return launch_grad<64>(op, xs, sq, L, ldl, R, ldr, batch, partial, nblocks_out, stream);
+    default: set_error("exact-fp32 matrix-core parameter sweep supports d <= 64"); return MFX_ERR_UNSUPPORTED;
   }
 }
 

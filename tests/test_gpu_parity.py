@@ -145,16 +145,17 @@ def test_rbf_op_apply_and_param_sweep(dtype, tol, precision, ard, n, d, p, kerne
 @pytest.mark.parametrize("kernel", ["rbf", "matern32", "matern12"])
 @pytest.mark.parametrize("ard", [False, True])
 @pytest.mark.parametrize("n,d,p", [(300, 33, 3), (515, 90, 8), (260, 385, 5), (700, 64, 1), (257, 100, 11),
-                                   # 16 < d <= 64 in fp32 with >= 4 vectors (or n >= 2048): the exact-fp32 matrix-core matvec in EVERY mode;
+                                   # 16 < d <= 128 in fp32 with >= 4 vectors (or n >= 2048): the exact-fp32 matrix-core matvec in EVERY mode;
                                    # d <= 32 and batch >= 16 (or n >= 2048): the exact-fp32 matrix-core sweep as well
-                                   (600, 20, 8), (2304, 32, 3), (900, 27, 40), (520, 50, 8), (2100, 64, 5), (1000, 40, 70), (777, 17, 33)])
+                                   (600, 20, 8), (2304, 32, 3), (900, 27, 40), (520, 50, 8), (2100, 64, 5), (1000, 40, 70), (777, 17, 33),
+                                   (2100, 128, 5), (640, 97, 70), (300, 129, 8)])
 def test_rbf_wide_inputs_apply_and_param_sweep(dtype, tol, precision, ard, n, d, p, kernel):
     """d > 32: the reference's kernels take any input dimension (util/gp_util.py:151-184) and its UCI loaders reach d = 90 (song) and
     385 (slice) (util/uci_util.py:85-99,303-310).  The wide kernels of csrc/mfx_ops.hip (distance as a small GEMM over chunks of the d
     axis; with ARD the sweep's grid selects 32 lengthscale derivatives at a time) against the NumPy oracle: matvec, its transpose
     through autograd, all parameter gradients (d of them with ARD), the cross-covariance matvec of the posterior mean.  Every mode
-    runs the same arithmetic here: VALU for d > 64 (and for fp64, few vectors at small n, the cross-covariance), the exact-fp32 matrix-core
-    kernels for 16 < d <= 64 (sweep: <= 32) -- the split kernels stop at d = 16.  Inputs scaled by 1 / sqrt(d): distances O(1)."""
+    runs the same arithmetic here: VALU for d > 128 (and for fp64, few vectors at small n, the cross-covariance), the exact-fp32 matrix-core
+    kernels for 16 < d <= 128 (sweep: <= 32) -- the split kernels stop at d = 16.  Inputs scaled by 1 / sqrt(d): distances O(1)."""
     rng = np.random.default_rng(d)
     X = rng.standard_normal((n, d)) / np.sqrt(d) * 1.5
     raw = (rng.standard_normal(d) * 0.3 + 0.5 if ard else np.array(0.7), np.array(0.4), np.array(-1.0))
