@@ -557,6 +557,7 @@ int rbf_mfma_grad_h(const mfx_operator* op, const float* xs, const float* sq, in
                     const float** scales_out, hipStream_t stream);
 bool rbf_mfma_grad_supported(const mfx_operator* op, int64_t batch);
 bool rbf_mfma_exact_wide_supported(const mfx_operator* op, int64_t p);         // 16 < d <= 128: the exact-fp32 kernels, in every mode
+bool rbf_mfma_h3_wide_supported(const mfx_operator* op, int64_t p);            // 16 < d <= 32, split modes: fp32 distances + f16x3 contraction
 bool rbf_mfma_grad_exact_wide_supported(const mfx_operator* op, int64_t batch);  // 16 < d <= 64
 int rbf_mfma_grad(const mfx_operator* op, const float* xs, const float* sq, int dpad, const float* L, int64_t ldl,
                   const float* R, int64_t ldr, int64_t batch, double* partial, int64_t* nblocks_out,
@@ -662,6 +663,8 @@ static int rbf_apply(const mfx_operator* op, const T* x, int64_t ldx, T* y, int6
         return rbf_mfma_apply_h3(op, (const float*)w.xs, (const float*)w.sq, dpad, x, ldx, y, ldy, p, w.vscale, w.pk, stream);
       return rbf_mfma_apply(op, (const float*)w.xs, (const float*)w.sq, dpad, x, ldx, y, ldy, p, stream);
     }
+    if (rbf_mfma_h3_wide_supported(op, p) && rbf_mode(op) >= MFX_RBF_F16X3_MATVEC)
+      return rbf_mfma_apply_h3(op, (const float*)w.xs, (const float*)w.sq, dpad, x, ldx, y, ldy, p, w.vscale, nullptr, stream);
     if (rbf_mfma_exact_wide_supported(op, p))
       return rbf_mfma_apply(op, (const float*)w.xs, (const float*)w.sq, dpad, x, ldx, y, ldy, p, stream);
   }

@@ -1045,7 +1045,10 @@ static int launch_apply_h3k(const mfx_operator* op, const float* xs, const float
   const int64_t n = op->n;
   const int64_t row0 = op_row0(op), nrow = op_nrows(op), rend = row0 + nrow;
   MFX_REQUIRE(row0 % 64 == 0, MFX_ERR_INVALID, "matrix-core Gram matvec: row0 = %lld must be a multiple of 64", (long long)row0);
-  const bool pack = pk != nullptr;  // the pre-packed tile images need the caller's pack workspace (mfx_workspace_bytes sizes it)
+  // the pre-packed tile images need the caller's pack workspace (mfx_workspace_bytes sizes it); DPAD = 32 (16 < d <= 32, round 5): only the
+  // in-kernel-split form with fp32-MFMA distances is built -- the packed images and the fat-wave kernel keep 3 KD / 16 f16 distance operands
+  // per block resident or in the 160 KB of LDS next to the chain masters, which stops at DPAD = 16
+  const bool pack = pk != nullptr && DPAD <= 16;
   // vscale region (65536 x 3 floats): [0, 2p) scales, [2p, 3p) |max| bit patterns (in-kernel-split path only), [3p] f16 range flag,
   // [3p + 64, ...) slice maxima of the pre-packed path
   int* rangeflag = reinterpret_cast<int*>(vscale + 3 * p);
@@ -1075,11 +1078,13 @@ static int launch_apply_h3k(const mfx_operator* op, const float* xs, const float
   const int nsplit = part ? rbf_split_count(nrow, n, p, DPAD) : 1;
   const dim3 grid3(grid.x, grid.y, (unsigned)nsplit);
   const dim3 grid_pk((unsigned)((nrow + 511) / 512), grid.y, (unsigned)nsplit);
-  if (pack) {
-    pkv = static_cast<uintx4*>(pk);
-    pka = reinterpret_cast<uintx4*>(static_cast<char*>(pk) + off_a);
-    k_pack_tiles<DPAD, NB, KIND><<<dim3((unsigned)ntile, chunks + 1), 256, 0, stream>>>(xs, sq, n, vscale, amax_part, (int)gx, x, ldx, p, pkv, pka, rangeflag);
-    MFX_CHECK_LAUNCH();
+  if constexpr (DPAD <= 16) {
+    if (pack) {
+      pkv = static_cast<uintx4*>(pk);
+      pka = reinterpret_cast<uintx4*>(static_cast<char*>(pk) + off_a);
+      k_pack_tiles<DPAD, NB, KIND><<<dim3((unsigned)ntile, chunks + 1), 256, 0, stream>>>(xs, sq, n, vscale, amax_part, (int)gx, x, ldx, p, pkv, pka, rangeflag);
+      MFX_CHECK_LAUNCH();
+    }
   }
   // LDS: the two tile buffers + (pre-packed variant) the chain masters of 8 waves x (2 NB - 1) blocks x 16 registers x 64 lanes
 #define MFX_H3_LAUNCH(V4, DHV, PKV, FLAG)                                                                            \
@@ -1091,7 +1096,9 @@ static int launch_apply_h3k(const mfx_operator* op, const float* xs, const float
     k_rbf_mfma_apply_h3<DPAD, NB, V4, KIND, DHV, PKV><<<(PKV) ? grid_pk : grid3, 64 * H3Waves<PKV>::value, kSm, stream>>>( \
         xs, sq, n, (const float*)op->outputscale, (const float*)op->noise, vscale, x, ldx, y, ldy, p, pkv, pka, part, FLAG, ldpart, row0, rend); \
   }
-  if (pack) {
+  if constexpr (DPAD > 16) {
+    if (vec4) MFX_H3_LAUNCH(true, false, false, nullptr) else MFX_H3_LAUNCH(false, false, false, nullptr)
+  } else if (pack) {
     bool done = false;
     if constexpr (KIND == MFX_KERNEL_RBF) {
       if (rbf_fat()) {  // fat waves (mfx_rbf_fat.hip): four waves of 128 rows, one per SIMD
@@ -1140,7 +1147,8 @@ int rbf_mfma_apply_h3(const mfx_operator* op, const float* xs, const float* sq, 
     MFX_H3_CASE(8);
     MFX_H3_CASE(12);
     MFX_H3_CASE(16);
-    default: set_error("RBF MFMA path supports d <= 16"); return MFX_ERR_UNSUPPORTED;
+    MFX_H3_CASE(32);
+    default: set_error("split matrix-core Gram matvec supports d <= 32"); return MFX_ERR_UNSUPPORTED;
   }
 #undef MFX_H3_CASE
 }
@@ -1855,6 +1863,10 @@ bool rbf_mfma_supported(const mfx_operator* op, int64_t p) {
 // file are generic in the padded dimension (the distance product is KD / 2 = 17 or 33 fp32 MFMAs per block) -- every arithmetic mode
 // runs them there.  About half of the datasets the reference's UCI loaders fetch have 17 .. 27 input columns (util/uci_util.py:68-316);
 // the VALU kernel they fell to is 18 x slower per matvec than d = 16 on the matrix cores (profiles/r05k_*).
+// 16 < d <= 32 in the split modes: the h3 kernel's in-kernel-split form -- fp32-MFMA distances (17 per block), the CONTRACTION on the f16 pipe
+bool rbf_mfma_h3_wide_supported(const mfx_operator* op, int64_t p) {
+  return op->dtype == MFX_F32 && op->d > 16 && op->d <= 32 && (p >= 4 || op->n >= 2048);
+}
 bool rbf_mfma_exact_wide_supported(const mfx_operator* op, int64_t p) {
   return op->dtype == MFX_F32 && op->d > 16 && op->d <= 128 && (p >= 4 || op->n >= 2048);
 }
