@@ -664,7 +664,7 @@ static int rbf_apply(const mfx_operator* op, const T* x, int64_t ldx, T* y, int6
       return rbf_mfma_apply(op, (const float*)w.xs, (const float*)w.sq, dpad, x, ldx, y, ldy, p, stream);
     }
     if (rbf_mfma_h3_wide_supported(op, p) && rbf_mode(op) >= MFX_RBF_F16X3_MATVEC)
-      return rbf_mfma_apply_h3(op, (const float*)w.xs, (const float*)w.sq, dpad, x, ldx, y, ldy, p, w.vscale, nullptr, stream);
+      return rbf_mfma_apply_h3(op, (const float*)w.xs, (const float*)w.sq, dpad, x, ldx, y, ldy, p, w.vscale, w.pk, stream);
     if (rbf_mfma_exact_wide_supported(op, p))
       return rbf_mfma_apply(op, (const float*)w.xs, (const float*)w.sq, dpad, x, ldx, y, ldy, p, stream);
   }

@@ -683,7 +683,7 @@ __global__ __launch_bounds__(64 * H3Waves<PK>::value, PK ? 1 : 2) void k_rbf_mfm
             blb[buf][s][nb] = *reinterpret_cast<const half8*>(&tl.vlo[row][(nb * 32 + l31) * 8]);
           }
       };
-      constexpr bool kPrefB = PK && (NB == 1 || DPAD <= 8);  // elsewhere the second fragment set does not fit in 256 VGPRs
+      constexpr bool kPrefB = PK && DPAD <= 16 && (NB == 1 || DPAD <= 8);  // elsewhere the second fragment set does not fit in 256 VGPRs
       if (kPrefB) load_b(0, 0);
       {
         static_assert(kMI == 2, "block order (jb, mi) = (0,0), (0,1), (1,0), (1,1)");
@@ -717,8 +717,17 @@ __global__ __launch_bounds__(64 * H3Waves<PK>::value, PK ? 1 : 2) void k_rbf_mfm
           __builtin_amdgcn_sched_barrier(0);
           acc[mi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w == 2 ? al[s] : ah[s], w == 1 ? blb[cur][s][nb] : bhb[cur][s][nb],
                                                                acc[mi][nb], 0, 0, 0);
-          if (has_next2 && m >= MD && m - MD < NKD)
-            kdn2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ajs[m - MD], bih[mi2][m - MD], kdn2, 0, 0, 0);
+          if constexpr (MD >= 0) {
+            if (has_next2 && m >= MD && m - MD < NKD)
+              kdn2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ajs[m - MD], bih[mi2][m - MD], kdn2, 0, 0, 0);
+          } else {  // more distance MFMAs than contraction slots behind which to hide them (DPAD 32, one probe block: 7 against 6): spread evenly
+            if (has_next2) {
+#pragma unroll
+              for (int q = 0; q < NKD; ++q)
+                if (q >= NKD * m / NM && q < NKD * (m + 1) / NM)
+                  kdn2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ajs[q], bih[mi2][q], kdn2, 0, 0, 0);
+            }
+          }
           if (kPrefB && m == 0 && blk == 0 && 2 * kMI > kMI) load_b(1, 1);  // the second column block's fragments, two blocks ahead
           __builtin_amdgcn_sched_barrier(0);
           if (has_next) {
@@ -1006,8 +1015,8 @@ static int rbf_split_count(int64_t nrow, int64_t n, int64_t p, int dpad) {
     const char* e = getenv("MFX_RBF_SPLIT");  // A/B: force the split count
     return e ? atoi(e) : 0;
   }();
-  (void)dpad;
-  const int64_t wgs = ((nrow + 511) / 512) * ((p + (p <= 32 ? 32 : 64) - 1) / (p <= 32 ? 32 : 64));
+  const int64_t pw = (p <= 32 || dpad > 16) ? 32 : 64;  // vectors per chunk (DPAD 32: one probe block per chunk)
+  const int64_t wgs = ((nrow + 511) / 512) * ((p + pw - 1) / pw);
   const int64_t ntile = (n + 63) / 64;
   int64_t smax = ntile / 8;
   if (forced > 0) return forced <= 16 && forced <= ntile ? forced : 1;
@@ -1026,16 +1035,16 @@ static int rbf_split_count(int64_t nrow, int64_t n, int64_t p, int dpad) {
   return best;
 }
 
-static int64_t rbf_pack_bytes_v(int64_t n, int64_t p) {
-  const int64_t P = p <= 32 ? 32 : 64, chunks = (p + P - 1) / P, ntile = (n + 63) / 64;
+static int64_t rbf_pack_bytes_v(int64_t n, int64_t p, int dpad) {
+  const int64_t P = (p <= 32 || dpad > 16) ? 32 : 64, chunks = (p + P - 1) / P, ntile = (n + 63) / 64;
   return chunks * ntile * 2 * 8 * P * 16;
 }
 int64_t rbf_pack_ws_bytes(const mfx_operator* op, int64_t p) {
-  if (op->dtype != MFX_F32 || op->d > 16 || p < 1) return 0;
+  if (op->dtype != MFX_F32 || op->d > 32 || p < 1) return 0;
   const int64_t ntile = (op->n + 63) / 64;
-  const int dpad = op->d <= 4 ? 4 : op->d <= 8 ? 8 : op->d <= 12 ? 12 : 16;
+  const int dpad = op->d <= 4 ? 4 : op->d <= 8 ? 8 : op->d <= 12 ? 12 : op->d <= 16 ? 16 : 32;
   const int64_t arow = ((3 * (dpad + 2) + 15) / 16) * 16 + 8;
-  return align_up(rbf_pack_bytes_v(op->n, p), 256) + align_up(ntile * 64 * arow * 2, 256) +
+  return align_up(rbf_pack_bytes_v(op->n, p, dpad), 256) + align_up(ntile * 64 * arow * 2, 256) +
          align_up((int64_t)rbf_split_count(op_nrows(op), op->n, p, dpad) * p * align_up(op_nrows(op), 4) * 4, 256);
 }
 
@@ -1048,7 +1057,7 @@ static int launch_apply_h3k(const mfx_operator* op, const float* xs, const float
   // the pre-packed tile images need the caller's pack workspace (mfx_workspace_bytes sizes it); DPAD = 32 (16 < d <= 32, round 5): only the
   // in-kernel-split form with fp32-MFMA distances is built -- the packed images and the fat-wave kernel keep 3 KD / 16 f16 distance operands
   // per block resident or in the 160 KB of LDS next to the chain masters, which stops at DPAD = 16
-  const bool pack = pk != nullptr && DPAD <= 16;
+  const bool pack = pk != nullptr && (DPAD <= 16 || NB == 1);
   // vscale region (65536 x 3 floats): [0, 2p) scales, [2p, 3p) |max| bit patterns (in-kernel-split path only), [3p] f16 range flag,
   // [3p + 64, ...) slice maxima of the pre-packed path
   int* rangeflag = reinterpret_cast<int*>(vscale + 3 * p);
@@ -1078,7 +1087,7 @@ static int launch_apply_h3k(const mfx_operator* op, const float* xs, const float
   const int nsplit = part ? rbf_split_count(nrow, n, p, DPAD) : 1;
   const dim3 grid3(grid.x, grid.y, (unsigned)nsplit);
   const dim3 grid_pk((unsigned)((nrow + 511) / 512), grid.y, (unsigned)nsplit);
-  if constexpr (DPAD <= 16) {
+  if constexpr (DPAD <= 16 || NB == 1) {
     if (pack) {
       pkv = static_cast<uintx4*>(pk);
       pka = reinterpret_cast<uintx4*>(static_cast<char*>(pk) + off_a);
@@ -1096,11 +1105,11 @@ static int launch_apply_h3k(const mfx_operator* op, const float* xs, const float
     k_rbf_mfma_apply_h3<DPAD, NB, V4, KIND, DHV, PKV><<<(PKV) ? grid_pk : grid3, 64 * H3Waves<PKV>::value, kSm, stream>>>( \
         xs, sq, n, (const float*)op->outputscale, (const float*)op->noise, vscale, x, ldx, y, ldy, p, pkv, pka, part, FLAG, ldpart, row0, rend); \
   }
-  if constexpr (DPAD > 16) {
+  if constexpr (DPAD > 16 && NB > 1) {
     if (vec4) MFX_H3_LAUNCH(true, false, false, nullptr) else MFX_H3_LAUNCH(false, false, false, nullptr)
   } else if (pack) {
     bool done = false;
-    if constexpr (KIND == MFX_KERNEL_RBF) {
+    if constexpr (KIND == MFX_KERNEL_RBF && DPAD <= 16) {
       if (rbf_fat()) {  // fat waves (mfx_rbf_fat.hip): four waves of 128 rows, one per SIMD
         MFX_TRY(rbf_fat_launch(DPAD, NB, vec4, grid_pk, stream, xs, sq, n, (const float*)op->outputscale, (const float*)op->noise, vscale,
                                x, ldx, y, ldy, p, pkv, pka, part, rangeflag, ldpart, row0, rend));
@@ -1147,7 +1156,9 @@ int rbf_mfma_apply_h3(const mfx_operator* op, const float* xs, const float* sq, 
     MFX_H3_CASE(8);
     MFX_H3_CASE(12);
     MFX_H3_CASE(16);
-    MFX_H3_CASE(32);
+    case 32:  // the pre-packed form exists with one probe block per chunk only (LDS); without the pack workspace: in-kernel split
+      return (p <= 32 || pk) ? launch_apply_h3<32, 1>(op, xs, sq, x, ldx, y, ldy, p, vscale, pk, stream)
+                             : launch_apply_h3<32, 2>(op, xs, sq, x, ldx, y, ldy, p, vscale, pk, stream);
     default: set_error("split matrix-core Gram matvec supports d <= 32"); return MFX_ERR_UNSUPPORTED;
   }
 #undef MFX_H3_CASE

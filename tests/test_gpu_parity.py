@@ -796,13 +796,14 @@ def test_operator_and_vector_dtypes_must_agree():
         lanczos.tridiag(DenseOp(), 4, reortho="full")(v64, torch.eye(64, device=DEV, dtype=torch.float32))
 
 
+@pytest.mark.parametrize("d", [3, 20])  # (20: the pre-packed form of 16 < d <= 32 has the same guard and the same fallback)
 @pytest.mark.parametrize("kernel", ["rbf", "matern32"])
-def test_rbf_op_inputs_beyond_the_f16_range_fall_back(kernel):
+def test_rbf_op_inputs_beyond_the_f16_range_fall_back(kernel, d):
     """Scaled inputs with |x/l|^2 > 6e4 overflow the f16 image of the distance operands: the matvec must notice on the device and
     take the fp32-distance kernel (finite and right up to the cancellation error fp32 has at these magnitudes anyway)."""
     rng = np.random.default_rng(11)
-    n, d, p = 2304, 3, 8
-    X = 40.0 + rng.standard_normal((n, d))          # offset cloud: |x/l|^2 ~ 2e5 with l = 0.157
+    n, p = 2304, 8
+    X = 40.0 * np.sqrt(3.0 / d) + rng.standard_normal((n, d)) * np.sqrt(3.0 / d)  # offset cloud: |x/l|^2 ~ 2e5 with l = 0.157
     raw = (np.array(-1.77), np.array(0.4), np.array(-1.0))  # softplus(-1.77) = 0.157
     V = rng.standard_normal((p, n))
     o = orc.RbfGramOp(X.astype(np.float32).astype(np.float64), noise_minval=1e-4, kernel=kernel, eps=float(torch.finfo(torch.float32).eps))
