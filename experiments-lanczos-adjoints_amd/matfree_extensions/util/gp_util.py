@@ -265,6 +265,20 @@ def likelihood_pdf_p(matvec, logpdf_p, precondition, *, constrain):
     return likelihood, {"raw_noise": torch.empty(())}
 
 
+def logpdf_scipy_stats():
+    """Dense reference (util/gp_util.py:354-364: jax.scipy.stats.multivariate_normal.logpdf of the materialised covariance) -- here
+    torch.distributions.MultivariateNormal on the same materialised matrix; used by the reference's gpytorch comparison test and its
+    fixed-step training script (optim_logml_adjoints_fixed.py:136) as the exact baseline."""
+
+    def logpdf(y, /, *, mean, cov_matvec):
+        n = mean.shape[0]
+        cov_matrix = cov_matvec(torch.eye(n, dtype=mean.dtype, device=mean.device)).t()
+        cov_matrix = 0.5 * (cov_matrix + cov_matrix.t())  # (the distribution insists on exact symmetry)
+        return torch.distributions.MultivariateNormal(mean, covariance_matrix=cov_matrix).log_prob(y), {}
+
+    return logpdf
+
+
 def logpdf_cholesky():
     """Dense baseline (util/gp_util.py:367-393): materialise the covariance through the operator, then Cholesky."""
 

@@ -390,6 +390,10 @@ def test_logpdf_cholesky_and_unpreconditioned_likelihood():
     lik, _ = gp_util.likelihood_pdf(gp_util.gram_matvec(), gp_util.logpdf_cholesky(), constrain=constrain)
     value, _ = gp_util.target_logml(gp_util.model_gp(m_fun, k_fun), lik)(T(X), T(y), **kw)
     assert abs(float(value) - want) <= 1e-9 * abs(want)
+    # the reference's other dense baseline (util/gp_util.py:354-364, multivariate_normal.logpdf of the materialised covariance)
+    lik_s, _ = gp_util.likelihood_pdf(gp_util.gram_matvec(), gp_util.logpdf_scipy_stats(), constrain=constrain)
+    value_s, _ = gp_util.target_logml(gp_util.model_gp(m_fun, k_fun), lik_s)(T(X), T(y), **kw)
+    assert abs(float(value_s) - want) <= 1e-9 * abs(want)
     # Krylov logpdf with k = n Lanczos steps and many probes is the same number up to Monte-Carlo error; with an
     # exact solve the Mahalanobis term is exact, so compare that part tightly via the info dict
     sample = hutchinson.sampler_rademacher(torch.empty(n, dtype=torch.float64, device=DEV), num=64)
