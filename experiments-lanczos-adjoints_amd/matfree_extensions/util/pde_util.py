@@ -1,7 +1,8 @@
 """PDE matrix-function helpers on the Arnoldi path -- MI355X build ("next" tier).
 
 Covers the pieces of the reference's ``util/pde_util.py`` that are thin compositions of the hot path:
-``expm_arnoldi`` (:257-268), ``solver_expm`` (:240-252), ``sampler_lanczos`` (:335-356) and the 5-point wave operator
+``expm_arnoldi`` (:257-268), its dense baseline ``expm_pade`` (:271-280), ``solver_expm`` (:240-252), ``sampler_lanczos`` (:335-356),
+the small helpers ``mesh_tensorproduct`` / ``loss_mse`` / ``loss_mse_relative`` (:14-15, :160-173) and the 5-point wave operator
 (:18-20,126-157) expressed as a native CSR operator so that the non-symmetric Arnoldi forward/adjoint kernels run it
 end to end.  The dense k x k ``expm`` / ``eigh`` are torch calls (k <= ~100: plumbing, differentiable).
 """
@@ -35,6 +36,43 @@ def expm_arnoldi(krylov_depth, *, max_squarings: int = 32, reortho="full", custo
         return out, {"num_matvecs": krylov_depth}
 
     return expm
+
+
+def expm_pade():
+    """Dense baseline of expm_arnoldi (util/pde_util.py:271-280): materialise A through the matvec (the reference takes its Jacobian; the
+    matvec is linear, so n applications to the identity are the same matrix) and apply torch.linalg.matrix_exp(dt A) to y0.  Small n only."""
+
+    def expm(matvec, dt, y0_flat, *p):
+        n = y0_flat.shape[0]
+        op, _ = as_operator(matvec)
+        cols = op(torch.eye(n, dtype=y0_flat.dtype, device=y0_flat.device), *p)  # row b = A e_b
+        return torch.linalg.matrix_exp(dt * cols.t()) @ y0_flat
+
+    return expm
+
+
+def mesh_tensorproduct(x, y, /):
+    """util/pde_util.py:14-15: jnp.stack(jnp.meshgrid(x, y)) -- 'xy' indexing, shape (2, len(y), len(x))."""
+    return torch.stack(torch.meshgrid(x, y, indexing="xy"))
+
+
+def loss_mse():
+    """util/pde_util.py:160-164."""
+
+    def loss(sol, /, *, targets):
+        return torch.mean((sol - targets) ** 2)
+
+    return loss
+
+
+def loss_mse_relative(*, nugget, reduce=torch.mean):
+    """util/pde_util.py:167-173."""
+
+    def loss(sol, /, *, targets):
+        mse_abs = (sol - targets) ** 2
+        return reduce(mse_abs / (nugget + torch.abs(targets)))
+
+    return loss
 
 
 def solver_expm(t0, t1, vector_field, /, expm):

@@ -51,6 +51,27 @@ def test_expm_arnoldi_dense_nonsymmetric(dtype, tol, k):
         assert np.allclose(N(out), scipy.linalg.expm(dt * A) @ y0, rtol=max(tol, 1e-8), atol=max(tol, 1e-8))
 
 
+def test_expm_pade_baseline_and_small_pde_helpers():
+    """util/pde_util.py:271-280 (dense baseline of expm_arnoldi), :14-15 (mesh), :160-173 (losses): against scipy / NumPy."""
+    rng = np.random.default_rng(4)
+    n = 24
+    A = rng.standard_normal((n, n)) / np.sqrt(n)
+    y0 = rng.standard_normal(n)
+    want = scipy.linalg.expm(0.7 * A) @ y0
+    out = pde_util.expm_pade()(DenseOp(), 0.7, T(y0), T(A))
+    assert np.allclose(N(out), want, rtol=1e-10, atol=1e-12)
+    out_cb = pde_util.expm_pade()(lambda v, a: v @ a.T if v.dim() == 2 else a @ v, 0.7, T(y0), T(A))  # a plain callable
+    assert np.allclose(N(out_cb), want, rtol=1e-10, atol=1e-12)
+    full, _ = pde_util.expm_arnoldi(n)(DenseOp(), 0.7, T(y0), T(A))  # full depth: the Krylov form is exact
+    assert np.allclose(N(full), N(out), rtol=1e-8, atol=1e-10)
+    x, y = np.linspace(0, 1, 5), np.linspace(-1, 1, 3)
+    assert np.array_equal(N(pde_util.mesh_tensorproduct(T(x), T(y))), np.stack(np.meshgrid(x, y)))
+    sol, tg = rng.standard_normal((3, 4)), rng.standard_normal((3, 4))
+    assert np.isclose(float(pde_util.loss_mse()(T(sol), targets=T(tg))), np.mean((sol - tg) ** 2))
+    rel = pde_util.loss_mse_relative(nugget=0.1)(T(sol), targets=T(tg))
+    assert np.isclose(float(rel), np.mean((sol - tg) ** 2 / (0.1 + np.abs(tg))))
+
+
 def test_expm_arnoldi_gradient_matches_central_differences():
     rng = np.random.default_rng(4)
     n, k, dt = 16, 7, 0.5
