@@ -734,7 +734,9 @@ static int rbf_grad(const mfx_operator* op, const T* L, int64_t ldl, const T* R,
   if constexpr (sizeof(T) == 4) {
     // the split GEMM stages its packed operands through 32-bit byte offsets: 2 B x padded batch x padded n < 4 GiB
     const bool fits32 = ((batch + 31) / 32 * 32) * ((op->n + 255) / 256 * 256) * 2 < ((int64_t)1 << 32);
-    if (rbf_mfma_grad_supported(op, batch) && rbf_mode(op) == MFX_RBF_F16X3 && w.hws && fits32) {
+    // (16 < d <= 32: the split sweep's 256 x 128 form with 64-column epilogue passes -- 249 registers, 140 KB of LDS)
+    const bool split_ok = rbf_mfma_grad_supported(op, batch) || (rbf_mfma_grad_exact_wide_supported(op, batch) && op->d <= 32);
+    if (split_ok && rbf_mode(op) == MFX_RBF_F16X3 && w.hws && fits32) {
       MFX_TRY(rbf_mfma_grad_h(op, (const float*)w.xs, (const float*)w.sq, dpad, L, ldl, R, ldr, batch, inner, w.partial, &nblocks,
                               w.hws, &scales, stream));
       done = true;

@@ -1393,6 +1393,9 @@ constexpr int kHLd = kHM + 4;
 template <int DPAD, int NBW, bool REGEPI = false>
 struct GradSmemH {
   static constexpr int TN = 2 * NBW * 32;  // columns of the workgroup tile
+  // columns per pass of the LDS epilogue: 128; 64 for DPAD = 32 (16 < d <= 32, round 5), where x_i and x_j of the tile are twice as wide and a
+  // 128-column S^T overlay would push the workgroup over the 160 KB of LDS
+  static constexpr int GN = DPAD > 16 ? 64 : kGN;
   static constexpr int KQ = (DPAD + 2 + 3) / 4;  // k-steps of the epilogue's distance product (v_mfma_f32_16x16x4_f32)
   union {
     struct {
@@ -1401,13 +1404,13 @@ struct GradSmemH {
       _Float16 b_hi[2][4][TN][8];
       _Float16 b_lo[2][4][TN][8];
     } st;
-    float s_t[kGN][kHLd];  // S^T of ONE 128-column pass of the epilogue
+    float s_t[GN][kHLd];  // S^T of ONE pass of the epilogue
   } u;
   float xi[kHM][DPAD];
   float sqi[kHM];
-  float xj[kGN][DPAD];
-  float sqj[kGN];
-  float sgj[kGN];  // tau_j of the staged columns (+-1)
+  float xj[GN][DPAD];
+  float sqj[GN];
+  float sgj[GN];  // tau_j of the staged columns (+-1)
   float bq[REGEPI ? 4 * KQ : 1][REGEPI ? TN : 1];  // register epilogue: B' = [x_j, 1, |x_j|^2, 0..] of the tile's columns, k-major
   double red[8][DPAD + 2];
 };
@@ -1667,25 +1670,25 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
     // ---- epilogue, in passes of 128 columns (the S^T overlay holds one pass): the waves whose blocks lie in the pass
     //      dump them, then thread = row i walks 64 of the pass's columns (as in k_rbf_mfma_grad) -------------------------
 #pragma unroll
-    for (int pass = 0; pass < TN / kGN; ++pass) {
+    for (int pass = 0; pass < TN / Smem::GN; ++pass) {
       __syncthreads();  // all waves are done with the stage images (pass 0) / with the previous pass's S^T
 #pragma unroll
       for (int b = 0; b < NB16; ++b) {
         const int cb = wn * (NBW * 32) + b * 16;  // first column of the block within the tile
-        if (cb / kGN != pass) continue;
+        if (cb / Smem::GN != pass) continue;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
           float4 q;
           q.x = acc[a][b][0]; q.y = acc[a][b][1]; q.z = acc[a][b][2]; q.w = acc[a][b][3];
-          *reinterpret_cast<float4*>(&sm.u.s_t[(cb % kGN) + l15][wm * 64 + a * 16 + 4 * lq]) = q;
+          *reinterpret_cast<float4*>(&sm.u.s_t[(cb % Smem::GN) + l15][wm * 64 + a * 16 + 4 * lq]) = q;
         }
       }
-      const int64_t jp = j0 + pass * kGN;
-      for (int t = tid; t < kGN * DPAD; t += 512) {
+      const int64_t jp = j0 + pass * Smem::GN;
+      for (int t = tid; t < Smem::GN * DPAD; t += 512) {
         const int64_t g = jp * DPAD + t;
         (&sm.xj[0][0])[t] = g < n * DPAD ? xs[g] : 0.f;
       }
-      if (tid < kGN) {
+      if (tid < Smem::GN) {
         sm.sqj[tid] = (jp + tid < n) ? sq[jp + tid] : 0.f;
         sm.sgj[tid] = grad_col_sign(jp + tid, salt_r) ? -1.f : 1.f;
       }
@@ -1694,7 +1697,7 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
       //  it they spill around the K-loop, which has no register to spare)
       int tid_t = tid;
       asm volatile("" : "+v"(tid_t));
-      const int il = tid_t & (kHM - 1), jh = (tid_t >> 8) * 64;
+      const int il = tid_t & (kHM - 1), jh = (tid_t >> 8) * (Smem::GN / 2);
       const int64_t i = row0 + i0 + il;  // the point; L / the packs are indexed by the local row i0 + il
       const float sgi = grad_col_sign(i0 + il, salt_l) ? -1.f : 1.f;  // sigma_i: the accumulators hold sigma_i tau_j S_ij
       float xiv[DPAD];
@@ -1707,8 +1710,8 @@ __global__ __launch_bounds__(512, 1) void k_rbf_mfma_grad_h(const float* __restr
       float gt[DPAD + 2];
 #pragma unroll
       for (int c = 0; c < DPAD + 2; ++c) gt[c] = 0.f;
-#pragma unroll 2
-      for (int jj = 0; jj < 64; ++jj) {
+#pragma unroll(DPAD > 16 ? 1 : 2)  // (DPAD 32: x_j of two columns in flight is 64 registers -- with one, no spills)
+      for (int jj = 0; jj < Smem::GN / 2; ++jj) {
         const int jl = jh + jj;
         const int64_t j = jp + jl;
         float xjv[DPAD];
@@ -1858,7 +1861,8 @@ int rbf_mfma_grad_h(const mfx_operator* op, const float* xs, const float* sq, in
     case 8: return launch_grad_h<8>(op, xs, sq, L, ldl, R, ldr, batch, inner, partial, nblocks_out, hws, stream);
     case 12: return launch_grad_h<12>(op, xs, sq, L, ldl, R, ldr, batch, inner, partial, nblocks_out, hws, stream);
     case 16: return launch_grad_h<16>(op, xs, sq, L, ldl, R, ldr, batch, inner, partial, nblocks_out, hws, stream);
-    default: set_error("RBF MFMA path supports d <= 16"); return MFX_ERR_UNSUPPORTED;
+    case 32: return launch_grad_h<32>(op, xs, sq, L, ldl, R, ldr, batch, inner, partial, nblocks_out, hws, stream);
+    default: set_error("split parameter sweep supports d <= 32"); return MFX_ERR_UNSUPPORTED;
   }
 }
 

@@ -99,8 +99,8 @@ typedef struct mfx_operator {
 
   /* RBF Gram: X row-major (n, d); constrained hyper-parameters live on the device so that no host
    * synchronisation is needed: lengthscale (d values if ard else 1), outputscale (1), noise (1).
-   * d <= 1024 (MFX_ERR_UNSUPPORTED beyond; the reference's kernels take any d, util/gp_util.py:151-184).  Which kernels run: fp32, d <= 16
-   * (matvec: <= 32): the f16-split matrix-core kernels (rbf_mode); fp32, up to d = 128 (parameter sweep: 16 < d <= 64): the exact-fp32
+   * d <= 1024 (MFX_ERR_UNSUPPORTED beyond; the reference's kernels take any d, util/gp_util.py:151-184).  Which kernels run: fp32, d <= 32:
+   * the f16-split matrix-core kernels (rbf_mode); fp32, up to d = 128 (parameter sweep: 64): the exact-fp32
    * matrix-core kernels in every rbf_mode; everything else (fp64, wider inputs, 1-3 vectors at n < 2048): VALU kernels. */
   const void* x;
   int32_t d;

@@ -175,7 +175,7 @@ def test_hot_kernels_scratch_budget_from_the_code_object():
       The <*, *, 1> forms: none.
     * k_rbf_mfma_grad_h: the register-epilogue forms (RBF, one lengthscale, d <= 8: config 4) none; the 256 x 256 tile with the LDS
       epilogue (Matern / ARD, d <= 8): <= 64 B -- row quantities of the epilogue, reloaded once per TILE (80 stages), nothing in the
-      stage loop; the 256 x 128 forms: none.
+      stage loop; the 256 x 128 forms: none, except the one for padded dimension 32 (16 < d <= 32): <= 64 B, the same way.
     * k_rbf_mfma_grad<64> (16 < d <= 64 in fp32, end of round 5): no scratch; <= 8 registers moved to AGPRs.
     * every other kernel of the library: none."""
     meta = _kernel_metadata()
@@ -191,7 +191,8 @@ def test_hot_kernels_scratch_budget_from_the_code_object():
         elif "k_rbf_mfma_grad_h" in name:
             hot += 1
             big_tile_lds_epilogue = re.search(r"k_rbf_mfma_grad_hILi\d+ELi4ELb0E", name) is not None
-            assert scratch <= (64 if big_tile_lds_epilogue else 0), (name, scratch)
+            widest = "k_rbf_mfma_grad_hILi32E" in name  # 16 < d <= 32 (round 5): 32 + 32 + 34 epilogue registers per thread, 44 B parked per TILE
+            assert scratch <= (64 if big_tile_lds_epilogue or widest else 0), (name, scratch)
             assert vgpr <= 256  # two waves per SIMD
         elif "k_rbf_mfma_gradILi64E" in name:
             # the exact-fp32 sweep at padded dimension 64 (one workgroup per CU: 130 KB of LDS): 66 fp64 sums per thread next to the 64 x 64
